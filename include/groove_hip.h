@@ -1,0 +1,141 @@
+/* groove_hip.h -- C ABI of libgroove_hip.so: the MI355X (gfx950) hot path of the GrooveTransformer
+ * train / predict step.
+ *
+ * The reference has no FFI: its hot path sits behind a *Python module API* supplied by the
+ * un-vendored submodule `BaseGrooveTransformers` (ref:train.py:12 `initialize_model, calculate_loss,
+ * train_loop`; ref:evaluator.py:173 `model.predict`).  Each entry point below names the reference
+ * interface it replaces; INTEGRATION.md shows the ctypes stub a maintainer of the reference adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch caching allocator); the library
+ *     never allocates, frees or synchronises; every call enqueues on the given hipStream_t and is
+ *     hipGraph-capturable (no host reads of device data, no host-dependent launch parameters
+ *     except the gt_config);
+ *   - return value 0 = ok, <0 = error; gt_last_error() gives the message (thread-local);
+ *   - activations are row-major (M, features), M = batch*32 rows, row m = b*32 + t -- the layout
+ *     the reference's DataLoader hands over ((B,32,S) / (B,32,27) contiguous fp32,
+ *     ref:dataset.py:263-264,355-356);
+ *   - HVO tensors are (M,27) = [hits(9) | velocities(9) | offsets(9)] (ref:utils.py:38-47,
+ *     ref:evaluator.py:173-177);
+ *   - parameters live in ONE flat fp32 buffer in state-dict order (names = the demo checkpoint's keys,
+ *     ref:demo/transformer_run_171tyqit_Epoch_1.Model); gt_param_layout() gives each tensor's offset.
+ *     Gradients use the same layout in a second flat buffer (one RCCL all-reduce, one fused update).
+ */
+#ifndef GROOVE_HIP_H
+#define GROOVE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gt_stream_t;   /* a hipStream_t (ihipStream_t*), passed opaquely so C callers need no HIP headers */
+
+#define GT_T 32          /* max_len, hard-coded by the reference: ref:train.py:128 */
+#define GT_TGT 27        /* embedding_size_tgt: ref:train.py:132 */
+#define GT_VOICES 9
+#define GT_MAX_D 512     /* largest d_model in the reference's sweeps: ref:configs/InfillingClosedHH_sweep.yaml */
+
+/* params["model"] of ref:train.py:115-134 */
+typedef struct gt_config {
+  int32_t batch;          /* sequences in this call (B) */
+  int32_t src_dim;        /* embedding_size_src: 16 (MSO) or 27 (symbolic), ref:train.py:129-131 */
+  int32_t d_model;
+  int32_t n_heads;
+  int32_t dim_ff;
+  int32_t n_enc_layers;
+  int32_t n_dec_layers;   /* 0 = encoder_only (ref:train.py:125-127) */
+  float dropout;
+} gt_config;
+
+/* device-resident per-step state, so that a captured hipGraph replays with fresh dropout masks,
+ * Adam bias correction and learning rate without host-side kernel-argument changes */
+typedef struct gt_step_state {
+  uint32_t seed_lo, seed_hi;   /* dropout RNG seed */
+  uint32_t step;               /* incremented by gt_optimizer_step (dropout stream id, Adam t-1) */
+  uint32_t pad;
+  float lr;                    /* ref:train.py:136 learning_rate */
+  float grad_scale;            /* 1/world_size for data-parallel averaging, else 1 */
+  float beta1, beta2, eps;     /* Adam (torch defaults 0.9 / 0.999 / 1e-8) */
+  float pad2[3];
+} gt_step_state;
+
+/* ---- dropout RNG (shared with oracle/numpy_groove.py) ------------------------------------------
+ * fmix32 = murmur3 finaliser.  key(site) = fmix32((fmix32((seed_lo ^ fmix32(step)) ^ site*0x9E3779B9)
+ * ^ seed_hi) + 0x7F4A7C15);  r(idx) = fmix32((idx*0x9E3779B1) ^ key);  keep iff (r>>8) >= p*2^24;
+ * kept values are scaled by 1/(1-p).  idx = flat element index of the dropped tensor
+ * ((M,d) / (M,F): m*cols+c; attention probabilities: ((b*H+h)*32+i)*32+j).  Sites: */
+#define GT_SITE_PE_ENC 0
+#define GT_SITE_PE_DEC 1
+#define GT_SITE_LAYER0 16   /* site = 16 + 8*global_layer + kind; decoder layers follow the encoder's */
+#define GT_SITE_ATTN 0      /* self-attention probabilities */
+#define GT_SITE_DROP1 1     /* dropout1 after self-attn out-proj */
+#define GT_SITE_FFN 2       /* dropout inside the FFN */
+#define GT_SITE_DROPF 3     /* dropout on the FFN output (encoder dropout2 / decoder dropout3) */
+#define GT_SITE_XATTN 4     /* decoder cross-attention probabilities */
+#define GT_SITE_DROP2 5     /* decoder dropout2 after cross-attn out-proj */
+
+const char* gt_last_error(void);
+int gt_version(void);
+
+/* Parameter layout in the flat buffer.  n_tensors / n_floats may be NULL.
+ * Replaces: model.state_dict() ordering of the reference's nn.Module (ckpt key order). */
+int gt_param_count(const gt_config* cfg, int64_t* n_tensors, int64_t* n_floats);
+/* offsets[i], sizes[i] in floats; rows[i], cols[i] the 2-D shape (cols = 0 for vectors). */
+int gt_param_layout(const gt_config* cfg, int64_t* offsets, int64_t* sizes, int32_t* rows, int32_t* cols);
+
+/* Bytes of scratch the forward/backward of this config needs (saved activations + temporaries). */
+size_t gt_workspace_bytes(const gt_config* cfg);
+/* Test/debug: locate a named saved activation inside the workspace (offset & count in floats).
+ * names: "x0","a0","qkv","P","ctx","xhat1","rstd1","x1","hact","xhat2","rstd2","x2","memory",
+ * "enc_xhat","dlogits" ... ; layer = global layer index (decoder layers follow the encoder's). */
+int gt_ws_find(const gt_config* cfg, const char* name, int layer, int64_t* offset, int64_t* count);
+
+/* Replaces GrooveTransformer(Encoder).forward(src[, tgt]) (ref:train.py:195-215 via train_loop;
+ * module tree pinned by the demo checkpoint).  x (M,src_dim); tgt_in (M,27) teacher-forcing input
+ * or NULL when n_dec_layers==0; pe (32,d_model) the registered positional-encoding buffer;
+ * hvo_out (M,27) = [h logits | sigmoid v | 0.5 tanh o].  state==NULL or train==0 -> eval mode
+ * (no dropout).  Saved activations for gt_backward are left in ws. */
+int gt_forward(const gt_config* cfg, const float* params, const float* pe, const float* x,
+               const float* tgt_in, float* hvo_out, float* ws, const gt_step_state* state, int train,
+               gt_stream_t stream);
+
+/* Replaces calculate_loss(pred, y, bce_fn, mse_fn, hit_loss_penalty) (ref:train.py:201-203,213;
+ * bce/mse: ref:train.py:176-179; penalty: ref:train.py:55-58).  stats (8 floats, zeroed by the
+ * call): [0] loss, [1] hit accuracy, [2] unused (perplexity = exp(stats[3]) on the host), [3] bce,
+ * [4] mse_v, [5] mse_o.  d_hvo (M,27) or NULL: d loss / d (h,v,o). */
+int gt_loss(const gt_config* cfg, const float* hvo, const float* y, float hit_loss_penalty,
+            float* stats, float* d_hvo, gt_stream_t stream);
+
+/* Replaces loss.backward() for the same module.  d_hvo (M,27) = grad w.r.t. forward's outputs.
+ * grads: flat buffer, same layout as params; zeroed first unless accumulate != 0. */
+int gt_backward(const gt_config* cfg, const float* params, float* grads, const float* x,
+                const float* tgt_in, const float* hvo, const float* d_hvo, float* ws,
+                const gt_step_state* state, int train, int accumulate, gt_stream_t stream);
+
+/* Replaces optimizer.step() of torch.optim.SGD(lr, momentum=0) (ckpt: optimizer param_groups) /
+ * torch.optim.Adam(lr) (ref:train.py:40-42).  algo 0 = sgd, 1 = adam (m, v: flat moment buffers).
+ * Reads lr/grad_scale/betas from *state and increments state->step. */
+int gt_optimizer_step(int algo, float* params, const float* grads, float* m, float* v, int64_t n,
+                      gt_step_state* state, gt_stream_t stream);
+
+/* One whole train step of train_loop's batch body (ref:train.py:195-215): [shift y for the decoder]
+ * forward, loss, backward, optimizer update.  tgt_scratch (M,27) is only used when n_dec_layers>0.
+ * With skip_update != 0 the optimizer is left to the caller (data-parallel: all-reduce grads first). */
+int gt_train_step(const gt_config* cfg, int algo, float* params, float* grads, float* m, float* v,
+                  const float* pe, const float* x, const float* y, float hit_loss_penalty,
+                  float* hvo_out, float* stats, float* tgt_scratch, float* ws, gt_step_state* state,
+                  int skip_update, gt_stream_t stream);
+
+/* Replaces model.predict(src, use_thres=True, thres=0.5) (ref:evaluator.py:173-177): eval forward,
+ * h = sigmoid(logit) > thres ? 1 : 0 (or the probability when use_thres == 0); the encoder-decoder
+ * runs the 32-step greedy decode.  hvo_out (M,27) is the concatenated HVO the evaluator builds. */
+int gt_predict(const gt_config* cfg, const float* params, const float* pe, const float* x,
+               float* hvo_out, float thres, int use_thres, float* tgt_scratch, float* ws,
+               gt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GROOVE_HIP_H */

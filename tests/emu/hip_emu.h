@@ -1,0 +1,207 @@
+// TEST INFRASTRUCTURE ONLY -- a single-threaded fiber emulator of the HIP execution model.
+//
+// Purpose: compile transformergrooveinfilling_amd/csrc/groove_hip.hip as plain host C++
+// (-DGT_EMU) so that the kernels' index math, LDS staging, MFMA fragment maps and barrier
+// structure can be debugged and sanitised (ASan/UBSan) in the build container, which has no GPU.
+// It is built into tests/emu/libgroove_emu.so by tests/emu/build_emu.sh and loaded ONLY by
+// tests that pass its path explicitly.  The product package never loads it and has no CPU
+// fallback: transformergrooveinfilling_amd/_lib.py fails loudly when libgroove_hip.so is absent.
+//
+// Model: every thread of a workgroup is a ucontext fiber; fibers run round-robin and yield at
+// __syncthreads() and at wave-level collectives (shuffles, MFMA).  v_mfma_f32_16x16x4_f32 is
+// emulated as the k-ordered fmaf chain the hardware performs (cdna_hip_programming.md 3,
+// "FP32-input MFMA"), with the documented lane maps A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+// D[row=4*(l>>4)+reg][col=l&15].
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef int hipStream_t_dummy;
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+namespace emu {
+extern dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+extern unsigned char* dyn_smem_;
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+void block_sync();
+float wave_shfl(float v, int src_lane);
+f32x4 mfma16(float a, float b, f32x4 c);
+}  // namespace emu
+
+#define threadIdx emu::threadIdx_
+#define blockIdx emu::blockIdx_
+#define blockDim emu::blockDim_
+#define gridDim emu::gridDim_
+
+static inline void __syncthreads() { emu::block_sync(); }
+static inline float __shfl_xor(float v, int m) {
+  int lane = (threadIdx.x + threadIdx.y * blockDim.x) & 63;
+  return emu::wave_shfl(v, lane ^ m);
+}
+static inline float __shfl(float v, int src) { return emu::wave_shfl(v, src & 63); }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+#define GT_MFMA16(a, b, c) emu::mfma16((a), (b), (c))
+
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+#define hipMemcpyDeviceToDevice 3
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+#ifdef GT_EMU_IMPL
+namespace emu {
+dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+unsigned char* dyn_smem_ = nullptr;
+
+namespace {
+enum { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+struct Fiber { ucontext_t ctx; char* stack; int state; };
+constexpr size_t kStack = 256 * 1024;
+std::vector<Fiber> fibers;
+ucontext_t sched_ctx;
+int cur = -1, nthreads = 0;
+const std::function<void()>* body_ = nullptr;
+float scratchA[16][64], scratchB[16][64];
+
+void yield_to_sched() { swapcontext(&fibers[cur].ctx, &sched_ctx); }
+void trampoline() {
+  (*body_)();
+  fibers[cur].state = DONE;
+  swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+void set_tid(int t) {
+  threadIdx_.x = t % blockDim_.x;
+  threadIdx_.y = (t / blockDim_.x) % blockDim_.y;
+  threadIdx_.z = t / (blockDim_.x * blockDim_.y);
+}
+void run_block() {
+  for (int t = 0; t < nthreads; ++t) {
+    Fiber& f = fibers[t];
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = &sched_ctx;
+    f.state = RUN;
+    makecontext(&f.ctx, trampoline, 0);
+  }
+  int nwaves = (nthreads + 63) / 64;
+  for (;;) {
+    int done = 0, progressed = 0;
+    for (int t = 0; t < nthreads; ++t) {
+      if (fibers[t].state == DONE) { ++done; continue; }
+      if (fibers[t].state != RUN) continue;
+      cur = t;
+      set_tid(t);
+      swapcontext(&sched_ctx, &fibers[t].ctx);
+      ++progressed;
+    }
+    if (done == nthreads) break;
+    // release barriers whose participants have all arrived
+    int wb = 0, live = 0;
+    for (int t = 0; t < nthreads; ++t) {
+      if (fibers[t].state != DONE) ++live;
+      if (fibers[t].state == WAIT_BLOCK) ++wb;
+    }
+    bool released = false;
+    if (live > 0 && wb == live) {
+      for (int t = 0; t < nthreads; ++t) if (fibers[t].state == WAIT_BLOCK) fibers[t].state = RUN;
+      released = true;
+    }
+    for (int w = 0; w < nwaves; ++w) {
+      int ww = 0, wl = 0;
+      for (int t = w * 64; t < nthreads && t < w * 64 + 64; ++t) {
+        if (fibers[t].state != DONE) ++wl;
+        if (fibers[t].state == WAIT_WAVE) ++ww;
+      }
+      if (wl > 0 && ww == wl) {
+        for (int t = w * 64; t < nthreads && t < w * 64 + 64; ++t) if (fibers[t].state == WAIT_WAVE) fibers[t].state = RUN;
+        released = true;
+      }
+    }
+    if (!released && !progressed) {
+      fprintf(stderr, "hip_emu: deadlock (divergent barrier?) block=(%u,%u,%u)\n", blockIdx_.x, blockIdx_.y, blockIdx_.z);
+      abort();
+    }
+  }
+}
+void wave_sync() { fibers[cur].state = WAIT_WAVE; yield_to_sched(); }
+}  // namespace
+
+void block_sync() { fibers[cur].state = WAIT_BLOCK; yield_to_sched(); }
+
+float wave_shfl(float v, int src_lane) {
+  int w = cur / 64, l = cur % 64;
+  scratchA[w][l] = v;
+  wave_sync();
+  float r = scratchA[w][src_lane];
+  wave_sync();
+  return r;
+}
+
+f32x4 mfma16(float a, float b, f32x4 c) {
+  int w = cur / 64, l = cur % 64;
+  scratchA[w][l] = a;
+  scratchB[w][l] = b;
+  wave_sync();
+  int col = l & 15, g = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * g + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(scratchA[w][row + 16 * k], scratchB[w][col + 16 * k], acc);
+    c[r] = acc;
+  }
+  wave_sync();
+  return c;
+}
+
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+  nthreads = block.x * block.y * block.z;
+  if (nthreads > 1024 || (nthreads % 64) != 0) { fprintf(stderr, "hip_emu: bad block size %d\n", nthreads); abort(); }
+  if (smem > 160 * 1024) { fprintf(stderr, "hip_emu: dynamic LDS %zu > 160 KiB\n", smem); abort(); }
+  if ((int)fibers.size() < nthreads) {
+    size_t old = fibers.size();
+    fibers.resize(nthreads);
+    for (size_t t = old; t < fibers.size(); ++t) fibers[t].stack = (char*)malloc(kStack);
+  }
+  std::vector<unsigned char> dyn(smem + 16, 0xA5);   // poison: uninitialised LDS reads show up
+  dyn_smem_ = dyn.data();
+  blockDim_ = block;
+  gridDim_ = grid;
+  body_ = &body;
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) {
+        blockIdx_ = dim3(x, y, z);
+        run_block();
+      }
+  dyn_smem_ = nullptr;
+}
+}  // namespace emu
+#endif  // GT_EMU_IMPL

@@ -1,0 +1,148 @@
+"""Shared test driver: runs the C ABI (include/groove_hip.h) on either the real HIP library
+(torch CUDA buffers) or the host fiber-emulator build of the same sources (numpy buffers), and
+exposes results as numpy arrays for comparison with the oracle."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from transformergrooveinfilling_amd import _lib, layout  # noqa: E402
+
+EMU_SO = os.path.join(ROOT, "tests", "emu", "libgroove_emu.so")
+_SRC = [os.path.join(ROOT, "transformergrooveinfilling_amd", "csrc", f)
+        for f in ("groove_hip.hip", "gt_common.h", "gt_gemm.h", "gt_attn.h", "gt_misc.h")] + \
+       [os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "include", "groove_hip.h")]
+
+
+def emu_lib():
+    if (not os.path.exists(EMU_SO)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in _SRC):
+        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
+    return _lib.GrooveLib(EMU_SO)
+
+
+class NpBuf:
+    def __init__(self, arr):
+        self.a = np.ascontiguousarray(arr)
+        self.ptr = ctypes.c_void_p(self.a.ctypes.data)
+
+    def numpy(self):
+        return self.a
+
+
+class CudaBuf:
+    def __init__(self, arr):
+        import torch
+        self.t = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+        self.ptr = ctypes.c_void_p(self.t.data_ptr())
+
+    def numpy(self):
+        import torch
+        torch.cuda.synchronize()
+        return self.t.cpu().numpy()
+
+
+def cfg_dict(d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_layers=0, embedding_size_src=16,
+             dropout=0.0):
+    return dict(d_model=d_model, n_heads=n_heads, dim_feedforward=dim_feedforward,
+                num_encoder_layers=num_encoder_layers, num_decoder_layers=num_decoder_layers,
+                embedding_size_src=embedding_size_src, dropout=dropout)
+
+
+class Runner:
+    """One model instance behind the C ABI.  backend = 'emu' | 'hip'."""
+
+    def __init__(self, cfg, B, backend="emu", rng=(1234, 99, 0), lr=0.094):
+        self.cfgd, self.B, self.backend = cfg, B, backend
+        self.lib = emu_lib() if backend == "emu" else _lib.get_lib()
+        self.Buf = NpBuf if backend == "emu" else CudaBuf
+        self.c = _lib.make_config(B, cfg["embedding_size_src"], cfg["d_model"], cfg["n_heads"], cfg["dim_feedforward"],
+                                  cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0), cfg.get("dropout", 0.0))
+        self.total, self.entries = self.lib.param_layout(self.c)
+        self.names = layout.param_names(cfg["d_model"], cfg["dim_feedforward"], cfg["embedding_size_src"],
+                                        cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0))
+        assert len(self.names) == len(self.entries)
+        for (n, shp), (off, size, rows, cols) in zip(self.names, self.entries):
+            assert int(np.prod(shp)) == size and shp[0] == rows, (n, shp, size, rows, cols)
+        self.M = B * 32
+        self.ws = self.Buf(np.zeros(self.lib.workspace_floats(self.c), np.float32))
+        self.pe = self.Buf(layout.positional_encoding(cfg["d_model"]))
+        self.hvo = self.Buf(np.zeros((self.M, 27), np.float32))
+        self.grads = self.Buf(np.zeros(self.total, np.float32))
+        self.stats = self.Buf(np.zeros(8, np.float32))
+        self.d_hvo = self.Buf(np.zeros((self.M, 27), np.float32))
+        self.tgt = self.Buf(np.zeros((self.M, 27), np.float32))
+        st = _lib.GtStepState(rng[0], rng[1], rng[2], 0, lr, 1.0, 0.9, 0.999, 1e-8)
+        self.state = self.Buf(np.frombuffer(bytes(st), dtype=np.uint8).copy())
+        self.stream = ctypes.c_void_p(0)
+        self.params = None
+
+    # ---- parameters -------------------------------------------------------------------------
+    def flatten(self, P):
+        flat = np.zeros(self.total, np.float32)
+        for (n, shp), (off, size, _, _) in zip(self.names, self.entries):
+            flat[off:off + size] = np.asarray(P[n], np.float32).reshape(-1)
+        return flat
+
+    def unflatten(self, flat):
+        return {n: flat[off:off + size].reshape(shp).copy() for (n, shp), (off, size, _, _) in zip(self.names, self.entries)}
+
+    def set_params(self, P):
+        self.params = self.Buf(self.flatten(P))
+
+    # ---- calls ------------------------------------------------------------------------------
+    def forward(self, x, tgt_in=None, train=False):
+        self.x = self.Buf(np.asarray(x, np.float32).reshape(self.M, -1))
+        self.tgt_in = self.Buf(np.asarray(tgt_in, np.float32).reshape(self.M, 27)) if tgt_in is not None else None
+        self.lib.call("gt_forward", ctypes.byref(self.c), self.params.ptr, self.pe.ptr, self.x.ptr,
+                      self.tgt_in.ptr if self.tgt_in else None, self.hvo.ptr, self.ws.ptr, self.state.ptr, int(train),
+                      self.stream)
+        return self.hvo.numpy().reshape(self.B, 32, 27).copy()
+
+    def loss(self, y, penalty, want_grad=True):
+        self.y = self.Buf(np.asarray(y, np.float32).reshape(self.M, 27))
+        self.lib.call("gt_loss", ctypes.byref(self.c), self.hvo.ptr, self.y.ptr, ctypes.c_float(penalty), self.stats.ptr,
+                      self.d_hvo.ptr if want_grad else None, self.stream)
+        return self.stats.numpy().copy(), self.d_hvo.numpy().reshape(self.B, 32, 27).copy()
+
+    def backward(self, d_hvo=None, train=False):
+        if d_hvo is not None:
+            self.d_hvo = self.Buf(np.asarray(d_hvo, np.float32).reshape(self.M, 27))
+        self.lib.call("gt_backward", ctypes.byref(self.c), self.params.ptr, self.grads.ptr, self.x.ptr,
+                      self.tgt_in.ptr if self.tgt_in else None, self.hvo.ptr, self.d_hvo.ptr, self.ws.ptr, self.state.ptr,
+                      int(train), 0, self.stream)
+        return self.unflatten(self.grads.numpy())
+
+    def optimizer_step(self, algo=0):
+        if algo == 1 and not hasattr(self, "m"):
+            self.m, self.v = self.Buf(np.zeros(self.total, np.float32)), self.Buf(np.zeros(self.total, np.float32))
+        self.lib.call("gt_optimizer_step", algo, self.params.ptr, self.grads.ptr, self.m.ptr if algo == 1 else None,
+                      self.v.ptr if algo == 1 else None, ctypes.c_int64(self.total), self.state.ptr, self.stream)
+        return self.unflatten(self.params.numpy())
+
+    def train_step(self, x, y, penalty, algo=0, skip_update=False):
+        self.x = self.Buf(np.asarray(x, np.float32).reshape(self.M, -1))
+        self.y = self.Buf(np.asarray(y, np.float32).reshape(self.M, 27))
+        if algo == 1 and not hasattr(self, "m"):
+            self.m, self.v = self.Buf(np.zeros(self.total, np.float32)), self.Buf(np.zeros(self.total, np.float32))
+        self.lib.call("gt_train_step", ctypes.byref(self.c), algo, self.params.ptr, self.grads.ptr,
+                      self.m.ptr if algo == 1 else None, self.v.ptr if algo == 1 else None, self.pe.ptr, self.x.ptr, self.y.ptr,
+                      ctypes.c_float(penalty), self.hvo.ptr, self.stats.ptr, self.tgt.ptr, self.ws.ptr, self.state.ptr,
+                      int(skip_update), self.stream)
+        return self.stats.numpy().copy()
+
+    def predict(self, x, thres=0.5, use_thres=True):
+        self.x = self.Buf(np.asarray(x, np.float32).reshape(self.M, -1))
+        self.lib.call("gt_predict", ctypes.byref(self.c), self.params.ptr, self.pe.ptr, self.x.ptr, self.hvo.ptr,
+                      ctypes.c_float(thres), int(use_thres), self.tgt.ptr, self.ws.ptr, self.stream)
+        return self.hvo.numpy().reshape(self.B, 32, 27).copy()
+
+    def ws_get(self, name, layer=0):
+        off, cnt = self.lib.ws_find(self.c, name, layer)
+        return self.ws.numpy()[off:off + cnt].copy()
+
+    def step_state(self):
+        return _lib.GtStepState.from_buffer_copy(self.state.numpy().tobytes())

@@ -1,0 +1,121 @@
+"""ctypes binding of libgroove_hip.so (C ABI declared in include/groove_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module raises, it never
+substitutes another implementation.  (tests/ may call ``load(path)`` with the host-emulator build
+of the same sources, tests/emu/libgroove_emu.so, to debug kernels without a GPU.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libgroove_hip.so")
+
+GT_T = 32
+GT_TGT = 27
+GT_VOICES = 9
+
+
+class GtConfig(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("src_dim", ctypes.c_int32), ("d_model", ctypes.c_int32),
+                ("n_heads", ctypes.c_int32), ("dim_ff", ctypes.c_int32), ("n_enc_layers", ctypes.c_int32),
+                ("n_dec_layers", ctypes.c_int32), ("dropout", ctypes.c_float)]
+
+
+class GtStepState(ctypes.Structure):
+    _fields_ = [("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32), ("step", ctypes.c_uint32),
+                ("pad", ctypes.c_uint32), ("lr", ctypes.c_float), ("grad_scale", ctypes.c_float),
+                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("pad2", ctypes.c_float * 3)]
+
+
+STEP_STATE_BYTES = ctypes.sizeof(GtStepState)   # 48
+
+_vp, _cfgp = ctypes.c_void_p, ctypes.POINTER(GtConfig)
+_SIGS = {
+    "gt_last_error": (ctypes.c_char_p, []),
+    "gt_version": (ctypes.c_int, []),
+    "gt_param_count": (ctypes.c_int, [_cfgp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "gt_param_layout": (ctypes.c_int, [_cfgp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                       ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "gt_workspace_bytes": (ctypes.c_size_t, [_cfgp]),
+    "gt_ws_find": (ctypes.c_int, [_cfgp, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                  ctypes.POINTER(ctypes.c_int64)]),
+    # cfg, params, pe, x, tgt_in, hvo_out, ws, state, train, stream
+    "gt_forward": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
+    # cfg, hvo, y, penalty, stats, d_hvo, stream
+    "gt_loss": (ctypes.c_int, [_cfgp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp]),
+    # cfg, params, grads, x, tgt_in, hvo, d_hvo, ws, state, train, accumulate, stream
+    "gt_backward": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    # algo, params, grads, m, v, n, state, stream
+    "gt_optimizer_step": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    # cfg, algo, params, grads, m, v, pe, x, y, penalty, hvo_out, stats, tgt_scratch, ws, state, skip_update, stream
+    "gt_train_step": (ctypes.c_int, [_cfgp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp,
+                                     _vp, _vp, _vp, ctypes.c_int, _vp]),
+    # cfg, params, pe, x, hvo_out, thres, use_thres, tgt_scratch, ws, stream
+    "gt_predict": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+class GrooveLibError(RuntimeError):
+    pass
+
+
+class GrooveLib:
+    """Thin checked wrapper: every entry point raises GrooveLibError(gt_last_error()) on failure."""
+
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise GrooveLibError(
+                "HIP library %s not found. Build it with transformergrooveinfilling_amd/csrc/build.sh "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % path)
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self.cdll, name)      # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise GrooveLibError("%s failed: %s" % (what, self.cdll.gt_last_error().decode()))
+
+    def call(self, name, *args):
+        self._chk(getattr(self.cdll, name)(*args), name)
+
+    def param_layout(self, cfg):
+        """-> (total_floats, [(offset, size, rows, cols)]) in state-dict order."""
+        nt, nf = ctypes.c_int64(), ctypes.c_int64()
+        self.call("gt_param_count", ctypes.byref(cfg), ctypes.byref(nt), ctypes.byref(nf))
+        n = nt.value
+        off, siz = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+        rows, cols = (ctypes.c_int32 * n)(), (ctypes.c_int32 * n)()
+        self.call("gt_param_layout", ctypes.byref(cfg), off, siz, rows, cols)
+        return nf.value, [(off[i], siz[i], rows[i], cols[i]) for i in range(n)]
+
+    def workspace_floats(self, cfg):
+        b = self.cdll.gt_workspace_bytes(ctypes.byref(cfg))
+        if b == 0:
+            raise GrooveLibError("gt_workspace_bytes failed: %s" % self.cdll.gt_last_error().decode())
+        return b // 4
+
+    def ws_find(self, cfg, name, layer=0):
+        o, c = ctypes.c_int64(), ctypes.c_int64()
+        self.call("gt_ws_find", ctypes.byref(cfg), name.encode(), layer, ctypes.byref(o), ctypes.byref(c))
+        return o.value, c.value
+
+
+_default = None
+
+
+def get_lib():
+    """The process-wide HIP library (loaded on first use; raises if it is not built)."""
+    global _default
+    if _default is None:
+        _default = GrooveLib()
+    return _default
+
+
+def make_config(batch, src_dim, d_model, n_heads, dim_ff, n_enc_layers, n_dec_layers=0, dropout=0.0):
+    return GtConfig(int(batch), int(src_dim), int(d_model), int(n_heads), int(dim_ff), int(n_enc_layers),
+                    int(n_dec_layers), float(dropout))

@@ -1,0 +1,595 @@
+// libgroove_hip.so -- C ABI (include/groove_hip.h) over the gfx950 kernels of the GrooveTransformer
+// train / predict step.  Host side here only sequences launches on the caller's stream: no
+// allocation, no synchronisation, no host reads of device data -> every entry point is
+// hipGraph-capturable.
+//
+// Op order follows the third-party torch modules the reference's un-vendored submodule wires
+// (SURVEY.md 3.2-3.4): encoder layer torch:nn/modules/transformer.py:951-956,961-982; decoder layer
+// :1143-1153; MHA torch:nn/functional.py:5820-5850,6504-6642; module tree / parameter names from the
+// reference's demo checkpoint (ref:demo/transformer_run_171tyqit_Epoch_1.Model).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "gt_attn.h"
+#include "gt_common.h"
+#include "gt_gemm.h"
+#include "gt_misc.h"
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int gt_fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+extern "C" const char* gt_last_error(void) { return g_err; }
+extern "C" int gt_version(void) { return 1; }
+
+static int check_cfg(const gt_config* c) {
+  if (!c) return gt_fail("gt_config is NULL");
+  if (c->batch <= 0) return gt_fail("batch must be > 0 (got %d)", c->batch);
+  if (c->d_model <= 0 || c->d_model > GT_MAX_D) return gt_fail("d_model %d outside 1..%d", c->d_model, GT_MAX_D);
+  if (c->n_heads <= 0 || c->d_model % c->n_heads != 0)   // torch:nn/functional.py:6415-6417
+    return gt_fail("embed_dim %d not divisible by num_heads %d", c->d_model, c->n_heads);
+  if (c->d_model % 2 != 0) return gt_fail("d_model %d must be even (sin/cos positional encoding)", c->d_model);
+  if (c->dim_ff <= 0 || c->src_dim <= 0) return gt_fail("dim_ff / src_dim must be > 0");
+  if (c->n_enc_layers <= 0 || c->n_enc_layers > 64 || c->n_dec_layers < 0 || c->n_dec_layers > 64)
+    return gt_fail("layer counts out of range (enc %d, dec %d)", c->n_enc_layers, c->n_dec_layers);
+  if (!(c->dropout >= 0.f && c->dropout < 1.f)) return gt_fail("dropout %f outside [0,1)", (double)c->dropout);
+  if ((int64_t)c->batch * 32 * (c->dim_ff > 3 * c->d_model ? c->dim_ff : 3 * c->d_model) >= (1ll << 31))
+    return gt_fail("batch %d too large for 32-bit element indices", c->batch);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ parameter layout
+struct AttnP { int64_t in_w, in_b, out_w, out_b; };
+struct LayerP { AttnP sa, xa; int64_t w1, b1, w2, b2, n1w, n1b, n2w, n2b, n3w, n3b; };
+struct PEntry { int64_t off, size; int rows, cols; };
+struct PLayout {
+  int64_t in_w, in_b, encn_w, encn_b, din_w, din_b, decn_w, decn_b, out_w, out_b, total;
+  std::vector<LayerP> enc, dec;
+  std::vector<PEntry> entries;
+};
+static PLayout param_layout(const gt_config& c) {
+  PLayout L;
+  int64_t cur = 0;
+  auto add = [&](int rows, int cols) {
+    const int64_t size = (int64_t)rows * (cols ? cols : 1);
+    const int64_t off = cur;
+    L.entries.push_back(PEntry{off, size, rows, cols});
+    cur += (size + 63) / 64 * 64;          // 256-byte aligned tensors: float4 loads, clean all-reduce buckets
+    return off;
+  };
+  const int d = c.d_model, F = c.dim_ff;
+  auto attn = [&](AttnP& a) { a.in_w = add(3 * d, d); a.in_b = add(3 * d, 0); a.out_w = add(d, d); a.out_b = add(d, 0); };
+  L.in_w = add(d, c.src_dim); L.in_b = add(d, 0);
+  L.enc.resize(c.n_enc_layers);
+  for (auto& l : L.enc) {
+    attn(l.sa);
+    l.w1 = add(F, d); l.b1 = add(F, 0); l.w2 = add(d, F); l.b2 = add(d, 0);
+    l.n1w = add(d, 0); l.n1b = add(d, 0); l.n2w = add(d, 0); l.n2b = add(d, 0);
+  }
+  L.encn_w = add(d, 0); L.encn_b = add(d, 0);
+  L.dec.resize(c.n_dec_layers);
+  if (c.n_dec_layers > 0) {
+    L.din_w = add(d, GT_TGT); L.din_b = add(d, 0);
+    for (auto& l : L.dec) {
+      attn(l.sa); attn(l.xa);
+      l.w1 = add(F, d); l.b1 = add(F, 0); l.w2 = add(d, F); l.b2 = add(d, 0);
+      l.n1w = add(d, 0); l.n1b = add(d, 0); l.n2w = add(d, 0); l.n2b = add(d, 0); l.n3w = add(d, 0); l.n3b = add(d, 0);
+    }
+    L.decn_w = add(d, 0); L.decn_b = add(d, 0);
+  }
+  L.out_w = add(GT_TGT, d); L.out_b = add(GT_TGT, 0);
+  L.total = cur;
+  return L;
+}
+
+extern "C" int gt_param_count(const gt_config* cfg, int64_t* n_tensors, int64_t* n_floats) {
+  if (check_cfg(cfg)) return -1;
+  PLayout L = param_layout(*cfg);
+  if (n_tensors) *n_tensors = (int64_t)L.entries.size();
+  if (n_floats) *n_floats = L.total;
+  return 0;
+}
+extern "C" int gt_param_layout(const gt_config* cfg, int64_t* offsets, int64_t* sizes, int32_t* rows, int32_t* cols) {
+  if (check_cfg(cfg)) return -1;
+  PLayout L = param_layout(*cfg);
+  for (size_t i = 0; i < L.entries.size(); ++i) {
+    if (offsets) offsets[i] = L.entries[i].off;
+    if (sizes) sizes[i] = L.entries[i].size;
+    if (rows) rows[i] = L.entries[i].rows;
+    if (cols) cols[i] = L.entries[i].cols;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ workspace layout
+struct LayerW {
+  int64_t qkv, P, ctx, xhat1, rstd1, x1;            // self-attention block
+  int64_t qx, kvx, Px, ctxx, xhatx, rstdx, x2;      // decoder cross-attention block
+  int64_t hact, xhat2, rstd2, xout;                 // FFN block (xhat2/rstd2 = the layer's LAST norm)
+};
+struct WLayout {
+  int64_t x0, a0, enc_xhat, enc_rstd, memory, y0, b0, dec_xhat, dec_rstd, dec_final;
+  std::vector<LayerW> layers;                        // encoder layers then decoder layers
+  int64_t hvo_tmp, dlogits, dzA, dzAm, dzB, dzBm, dhid, dctx, dqkv, dmem, total;
+};
+static WLayout ws_layout(const gt_config& c) {
+  WLayout W;
+  int64_t cur = 0;
+  auto add = [&](int64_t n) { int64_t o = cur; cur += (n + 63) / 64 * 64; return o; };
+  const int64_t M = (int64_t)c.batch * 32, d = c.d_model, F = c.dim_ff, BH = (int64_t)c.batch * c.n_heads;
+  W.x0 = add(M * d); W.a0 = add(M * d);
+  const int nl = c.n_enc_layers + c.n_dec_layers;
+  W.layers.resize(nl);
+  for (int l = 0; l < nl; ++l) {
+    LayerW& w = W.layers[l];
+    w.qkv = add(M * 3 * d); w.P = add(BH * 1024); w.ctx = add(M * d);
+    w.xhat1 = add(M * d); w.rstd1 = add(M); w.x1 = add(M * d);
+    if (l >= c.n_enc_layers) {
+      w.qx = add(M * d); w.kvx = add(M * 2 * d); w.Px = add(BH * 1024); w.ctxx = add(M * d);
+      w.xhatx = add(M * d); w.rstdx = add(M); w.x2 = add(M * d);
+    } else {
+      w.qx = w.kvx = w.Px = w.ctxx = w.xhatx = w.rstdx = w.x2 = -1;
+    }
+    w.hact = add(M * F); w.xhat2 = add(M * d); w.rstd2 = add(M); w.xout = add(M * d);
+  }
+  W.enc_xhat = add(M * d); W.enc_rstd = add(M); W.memory = add(M * d);
+  if (c.n_dec_layers > 0) {
+    W.y0 = add(M * d); W.b0 = add(M * d); W.dec_xhat = add(M * d); W.dec_rstd = add(M); W.dec_final = add(M * d);
+    W.dmem = add(M * d); W.hvo_tmp = add(M * GT_TGT);
+  } else {
+    W.y0 = W.b0 = W.dec_xhat = W.dec_rstd = W.dec_final = W.dmem = W.hvo_tmp = -1;
+  }
+  W.dlogits = add(M * GT_TGT);
+  W.dzA = add(M * d); W.dzAm = add(M * d); W.dzB = add(M * d); W.dzBm = add(M * d);
+  W.dhid = add(M * F); W.dctx = add(M * d); W.dqkv = add(M * 3 * d);
+  W.total = cur;
+  return W;
+}
+extern "C" size_t gt_workspace_bytes(const gt_config* cfg) {
+  if (check_cfg(cfg)) return 0;
+  return (size_t)ws_layout(*cfg).total * sizeof(float);
+}
+extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int64_t* offset, int64_t* count) {
+  if (check_cfg(cfg)) return -1;
+  const gt_config& c = *cfg;
+  WLayout W = ws_layout(c);
+  const int64_t M = (int64_t)c.batch * 32, d = c.d_model, F = c.dim_ff, BH = (int64_t)c.batch * c.n_heads;
+  const std::string n(name);
+  int64_t off = -1, cnt = 0;
+  auto set = [&](int64_t o, int64_t k) { off = o; cnt = k; };
+  if (n == "x0") set(W.x0, M * d); else if (n == "a0") set(W.a0, M * d);
+  else if (n == "enc_xhat") set(W.enc_xhat, M * d); else if (n == "enc_rstd") set(W.enc_rstd, M);
+  else if (n == "memory") set(W.memory, M * d); else if (n == "y0") set(W.y0, M * d);
+  else if (n == "dec_final") set(W.dec_final, M * d); else if (n == "dlogits") set(W.dlogits, M * GT_TGT);
+  else if (n == "dmem") set(W.dmem, M * d);
+  else {
+    if (layer < 0 || layer >= (int)W.layers.size()) return gt_fail("gt_ws_find: layer %d out of range", layer);
+    const LayerW& w = W.layers[layer];
+    if (n == "qkv") set(w.qkv, M * 3 * d); else if (n == "P") set(w.P, BH * 1024); else if (n == "ctx") set(w.ctx, M * d);
+    else if (n == "xhat1") set(w.xhat1, M * d); else if (n == "rstd1") set(w.rstd1, M); else if (n == "x1") set(w.x1, M * d);
+    else if (n == "qx") set(w.qx, M * d); else if (n == "kvx") set(w.kvx, M * 2 * d); else if (n == "Px") set(w.Px, BH * 1024);
+    else if (n == "ctxx") set(w.ctxx, M * d); else if (n == "xhatx") set(w.xhatx, M * d); else if (n == "x2") set(w.x2, M * d);
+    else if (n == "hact") set(w.hact, M * F); else if (n == "xhat2") set(w.xhat2, M * d); else if (n == "rstd2") set(w.rstd2, M);
+    else if (n == "xout") set(w.xout, M * d);
+  }
+  if (off < 0) return gt_fail("gt_ws_find: unknown or absent buffer '%s'", name);
+  *offset = off; *count = cnt;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ launch helpers
+struct Ctx {
+  gt_config c;
+  PLayout P;
+  WLayout W;
+  int M, d, F, H, hd;
+  const float* prm;
+  float* grd;
+  float* ws;
+  const gt_step_state* st;
+  bool drop;                 // train mode with p > 0
+  hipStream_t s;
+};
+static DropArgs mk_drop(const Ctx& x, int site) {
+  DropArgs da;
+  da.st = x.drop ? x.st : nullptr;
+  da.site = (uint32_t)site;
+  da.thr = x.drop ? (uint32_t)(x.c.dropout * 16777216.0f) : 0u;
+  da.scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
+  return da;
+}
+static int lsite(int gl, int kind) { return GT_SITE_LAYER0 + 8 * gl + kind; }
+static GemmArgs mk_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.mask_scale = 1.0f;
+  g.drop.scale = 1.0f;
+  return g;
+}
+// y = x W^T + b  (forward "NT")
+static void linear_fwd(const Ctx& x, const float* in, int ldin, const float* W, const float* b, float* out, int ldout,
+                       int N, int K) {
+  GemmArgs g = mk_gemm(in, ldin, W, K, out, ldout, x.M, N, K);
+  g.bias = b;
+  gemm_launch<false, false, EPI_STORE>(g, x.s);
+}
+// dW (N_w x K_w) += dY^T X ; db += colsum(dY)       ("TN", split over tokens, fp32 atomics)
+static void wgrad(const Ctx& x, const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, int Nw, int Kw) {
+  GemmArgs g = mk_gemm(dY, ldy, X, ldx, dW, Kw, Nw, Kw, x.M);
+  g.dbias = db;
+  gemm_launch<true, true, EPI_ATOMIC>(g, x.s);
+}
+// dX = dY W   ("NN")
+static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, int ldw, float* dX, int N, int K, int accumulate) {
+  GemmArgs g = mk_gemm(dY, ldy, W, ldw, dX, N, x.M, N, K);
+  g.accumulate = accumulate;
+  gemm_launch<false, true, EPI_STORE>(g, x.s);
+}
+// dz = LNbwd(dY W + res) with the LayerNorm whose (xhat, rstd, gamma) are given; dzm = dz * dropout mask
+static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, int K, const float* res, const float* xhat,
+                       const float* rstd, int64_t gamma_off, float* dz, float* dzm, int site) {
+  GemmArgs g = mk_gemm(dY, ldy, W, x.d, dz, x.d, x.M, x.d, K);
+  g.res = res; g.ldres = x.d;
+  g.xhat = xhat; g.rstd = rstd; g.gamma = x.prm + gamma_off;
+  g.dgamma = x.grd + gamma_off; g.dbeta = x.grd + gamma_off + (x.d + 63) / 64 * 64;   // bias tensor follows the weight
+  g.C2 = x.drop ? dzm : nullptr;
+  g.drop = mk_drop(x, site);
+  return gemm_launch_row<false, true, EPI_RES_LNBWD>(g, x.s);
+}
+static void ln_bwd(const Ctx& x, const float* dy, const float* xhat, const float* rstd, int64_t gamma_off, float* dz, float* dzm,
+                   int site) {
+  const int rows_per_block = 4 * GT_LNB_ROWS;
+  gt_launch(ln_bwd_kernel, dim3((x.M + rows_per_block - 1) / rows_per_block), dim3(256), x.s, dy, xhat, rstd,
+            x.prm + gamma_off, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
+            x.grd + gamma_off + (x.d + 63) / 64 * 64, x.M, x.d);
+}
+// x_out = LN(drop(in W^T + b) + res)
+static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, int64_t b_off, const float* res, int64_t gamma_off,
+                         float* out, float* xhat, float* rstd, int site) {
+  GemmArgs g = mk_gemm(in, K, x.prm + w_off, K, out, x.d, x.M, x.d, K);
+  g.bias = x.prm + b_off;
+  g.res = res; g.ldres = x.d;
+  g.gamma = x.prm + gamma_off; g.beta = x.prm + gamma_off + (x.d + 63) / 64 * 64;
+  g.aux = xhat; g.aux2 = rstd;
+  g.drop = mk_drop(x, site);
+  return gemm_launch_row<false, false, EPI_RES_LN>(g, x.s);
+}
+static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, float* P, float* ctx,
+                          int causal, int site) {
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = P; a.ctx = ctx; a.ldc = x.d;
+  a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.causal = causal; a.drop = mk_drop(x, site);
+  gt_launch(attn_fwd_kernel, dim3(x.c.batch * x.H), dim3(256), x.s, a);
+}
+static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* P,
+                          const float* dctx, float* dq, int lddq, float* dk, float* dv, int lddkv, int site) {
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = const_cast<float*>(P);
+  a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.drop = mk_drop(x, site);
+  a.dctx = dctx; a.lddc = x.d; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddkv; a.lddv = lddkv;
+  gt_launch(attn_bwd_kernel, dim3(x.c.batch * x.H), dim3(256), x.s, a);
+}
+
+static int make_ctx(Ctx& x, const gt_config* cfg, const float* params, float* grads, float* ws, const gt_step_state* st,
+                    int train, gt_stream_t stream) {
+  if (check_cfg(cfg)) return -1;
+  if (!params || !ws) return gt_fail("params / ws must not be NULL");
+  x.c = *cfg;
+  x.P = param_layout(*cfg);
+  x.W = ws_layout(*cfg);
+  x.M = cfg->batch * 32; x.d = cfg->d_model; x.F = cfg->dim_ff; x.H = cfg->n_heads; x.hd = x.d / x.H;
+  x.prm = params; x.grd = grads; x.ws = ws; x.st = st;
+  x.drop = train && st != nullptr && cfg->dropout > 0.f;
+  x.s = (hipStream_t)stream;
+  return 0;
+}
+static int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return gt_fail("%s: HIP launch error: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ forward
+// InputLayer: Linear -> ReLU -> + pe[t] -> dropout        
+static void input_layer_fwd(const Ctx& x, const float* in, int S, int64_t w, int64_t b, const float* pe, float* a0, float* out,
+                            int site) {
+  GemmArgs g = mk_gemm(in, S, x.prm + w, S, out, x.d, x.M, x.d, S);
+  g.bias = x.prm + b; g.aux = a0; g.pe = pe; g.drop = mk_drop(x, site);
+  gemm_launch<false, false, EPI_RELU_PE>(g, x.s);
+}
+// FFN block + last norm of a layer:  xout = LN(xin + drop(W2 drop(relu(W1 xin + b1)) + b2))
+static int ffn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int64_t norm_w, int gl) {
+  float* ws = x.ws;
+  GemmArgs g = mk_gemm(xin, x.d, x.prm + p.w1, x.d, ws + w.hact, x.F, x.M, x.F, x.d);
+  g.bias = x.prm + p.b1; g.drop = mk_drop(x, lsite(gl, GT_SITE_FFN));
+  gemm_launch<false, false, EPI_RELU_DROP>(g, x.s);
+  return linear_res_ln(x, ws + w.hact, x.F, p.w2, p.b2, xin, norm_w, ws + w.xout, ws + w.xhat2, ws + w.rstd2,
+                       lsite(gl, GT_SITE_DROPF));
+}
+static int self_attn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int causal, int gl) {
+  float* ws = x.ws;
+  const int d = x.d;
+  linear_fwd(x, xin, d, x.prm + p.sa.in_w, x.prm + p.sa.in_b, ws + w.qkv, 3 * d, 3 * d, d);
+  attention_fwd(x, ws + w.qkv, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.P, ws + w.ctx, causal,
+                lsite(gl, GT_SITE_ATTN));
+  return linear_res_ln(x, ws + w.ctx, d, p.sa.out_w, p.sa.out_b, xin, p.n1w, ws + w.x1, ws + w.xhat1, ws + w.rstd1,
+                       lsite(gl, GT_SITE_DROP1));
+}
+
+static int encoder_fwd(const Ctx& x, const float* pe, const float* src) {
+  float* ws = x.ws;
+  input_layer_fwd(x, src, x.c.src_dim, x.P.in_w, x.P.in_b, pe, ws + x.W.a0, ws + x.W.x0, GT_SITE_PE_ENC);
+  const float* cur = ws + x.W.x0;
+  for (int l = 0; l < x.c.n_enc_layers; ++l) {
+    const LayerP& p = x.P.enc[l];
+    const LayerW& w = x.W.layers[l];
+    if (self_attn_fwd(x, p, w, cur, 0, l)) return gt_fail("d_model %d unsupported by the row-LayerNorm kernels", x.d);
+    if (ffn_fwd(x, p, w, ws + w.x1, p.n2w, l)) return -1;
+    cur = ws + w.xout;
+  }
+  gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, x.prm + x.P.encn_w, x.prm + x.P.encn_b, ws + x.W.memory,
+            ws + x.W.enc_xhat, ws + x.W.enc_rstd, x.M, x.d);
+  return 0;
+}
+static int decoder_fwd(const Ctx& x, const float* pe, const float* tgt_in) {
+  float* ws = x.ws;
+  const int d = x.d, L = x.c.n_enc_layers;
+  input_layer_fwd(x, tgt_in, GT_TGT, x.P.din_w, x.P.din_b, pe, ws + x.W.b0, ws + x.W.y0, GT_SITE_PE_DEC);
+  const float* cur = ws + x.W.y0;
+  for (int l = 0; l < x.c.n_dec_layers; ++l) {
+    const LayerP& p = x.P.dec[l];
+    const LayerW& w = x.W.layers[L + l];
+    const int gl = L + l;
+    if (self_attn_fwd(x, p, w, cur, 1, gl)) return -1;
+    // cross attention: q from the decoder stream (W[0:d]), k,v from the encoder memory (W[d:3d])
+    linear_fwd(x, ws + w.x1, d, x.prm + p.xa.in_w, x.prm + p.xa.in_b, ws + w.qx, d, d, d);
+    linear_fwd(x, ws + x.W.memory, d, x.prm + p.xa.in_w + (int64_t)d * d, x.prm + p.xa.in_b + d, ws + w.kvx, 2 * d, 2 * d, d);
+    attention_fwd(x, ws + w.qx, d, ws + w.kvx, ws + w.kvx + d, 2 * d, ws + w.Px, ws + w.ctxx, 0, lsite(gl, GT_SITE_XATTN));
+    if (linear_res_ln(x, ws + w.ctxx, d, p.xa.out_w, p.xa.out_b, ws + w.x1, p.n2w, ws + w.x2, ws + w.xhatx, ws + w.rstdx,
+                      lsite(gl, GT_SITE_DROP2))) return -1;
+    if (ffn_fwd(x, p, w, ws + w.x2, p.n3w, gl)) return -1;
+    cur = ws + w.xout;
+  }
+  gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, x.prm + x.P.decn_w, x.prm + x.P.decn_b, ws + x.W.dec_final,
+            ws + x.W.dec_xhat, ws + x.W.dec_rstd, x.M, x.d);
+  return 0;
+}
+static void output_layer_fwd(const Ctx& x, float* hvo_out) {
+  const float* fin = x.ws + (x.c.n_dec_layers > 0 ? x.W.dec_final : x.W.memory);
+  GemmArgs g = mk_gemm(fin, x.d, x.prm + x.P.out_w, x.d, hvo_out, GT_TGT, x.M, GT_TGT, x.d);
+  g.bias = x.prm + x.P.out_b;
+  gemm_launch<false, false, EPI_HEADS>(g, x.s);
+}
+
+extern "C" int gt_forward(const gt_config* cfg, const float* params, const float* pe, const float* xin, const float* tgt_in,
+                          float* hvo_out, float* ws, const gt_step_state* state, int train, gt_stream_t stream) {
+  Ctx x;
+  if (make_ctx(x, cfg, params, nullptr, ws, state, train, stream)) return -1;
+  if (!pe || !xin || !hvo_out) return gt_fail("gt_forward: pe / x / hvo_out must not be NULL");
+  if (cfg->n_dec_layers > 0 && !tgt_in) return gt_fail("gt_forward: encoder-decoder model needs tgt_in");
+  if (encoder_fwd(x, pe, xin)) return -1;
+  if (cfg->n_dec_layers > 0 && decoder_fwd(x, pe, tgt_in)) return -1;
+  output_layer_fwd(x, hvo_out);
+  return launch_status("gt_forward");
+}
+
+// ------------------------------------------------------------------------------------ loss
+extern "C" int gt_loss(const gt_config* cfg, const float* hvo, const float* y, float hit_loss_penalty, float* stats, float* d_hvo,
+                       gt_stream_t stream) {
+  if (check_cfg(cfg)) return -1;
+  if (!hvo || !y || !stats) return gt_fail("gt_loss: hvo / y / stats must not be NULL");
+  const int M = cfg->batch * 32;
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(stats, 0, 8 * sizeof(float), s);
+  gt_launch(loss_kernel, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, hvo, y, hit_loss_penalty, stats, d_hvo, M);
+  return launch_status("gt_loss");
+}
+
+// ------------------------------------------------------------------------------------ backward
+// FFN block backward.  In: dz (grad of the pre-norm sum of the layer's last norm) and its dropout-masked
+// copy dzm.  Out: dz_prev = LNbwd_prev(dhid W1 + dz) into (dzo, dzom) for the norm in front of the FFN.
+static int ffn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, const float* dz, const float* dzm,
+                   const float* xhat_prev, const float* rstd_prev, int64_t gamma_prev, float* dzo, float* dzom, int site_prev, int gl) {
+  float* ws = x.ws;
+  wgrad(x, dzm, x.d, ws + w.hact, x.F, x.grd + p.w2, x.grd + p.b2, x.d, x.F);
+  GemmArgs g = mk_gemm(dzm, x.d, x.prm + p.w2, x.F, ws + x.W.dhid, x.F, x.M, x.F, x.d);
+  g.res = ws + w.hact; g.ldres = x.F;
+  g.mask_scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
+  gemm_launch<false, true, EPI_MASK_NZ>(g, x.s);
+  wgrad(x, ws + x.W.dhid, x.F, xin, x.d, x.grd + p.w1, x.grd + p.b1, x.F, x.d);
+  (void)gl;
+  return dgrad_lnbwd(x, ws + x.W.dhid, x.F, x.prm + p.w1, x.F, dz, xhat_prev, rstd_prev, gamma_prev, dzo, dzom, site_prev);
+}
+// self-attention block backward.  In: dz1m (masked grad of the out-proj output).  Leaves dqkv in ws.
+static void self_attn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, const float* dz1m, int gl) {
+  float* ws = x.ws;
+  const int d = x.d;
+  wgrad(x, dz1m, d, ws + w.ctx, d, x.grd + p.sa.out_w, x.grd + p.sa.out_b, d, d);
+  dgrad_store(x, dz1m, d, x.prm + p.sa.out_w, d, ws + x.W.dctx, d, d, 0);
+  attention_bwd(x, ws + w.qkv, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.P, ws + x.W.dctx, ws + x.W.dqkv, 3 * d,
+                ws + x.W.dqkv + d, ws + x.W.dqkv + 2 * d, 3 * d, lsite(gl, GT_SITE_ATTN));
+  wgrad(x, ws + x.W.dqkv, 3 * d, xin, d, x.grd + p.sa.in_w, x.grd + p.sa.in_b, 3 * d, d);
+}
+// grad of the InputLayer: da = (dqkv Win + dz1) * dropmask * (a0 > 0); dW = da^T in; db = colsum(da)
+static void input_layer_bwd(const Ctx& x, const LayerP& first, const float* dz1, const float* a0, const float* in, int S, int64_t w,
+                            int64_t b, int site) {
+  float* ws = x.ws;
+  GemmArgs g = mk_gemm(ws + x.W.dqkv, 3 * x.d, x.prm + first.sa.in_w, x.d, ws + x.W.dctx, x.d, x.M, x.d, 3 * x.d);
+  g.res = dz1; g.ldres = x.d; g.aux_in = a0; g.drop = mk_drop(x, site);
+  gemm_launch<false, true, EPI_ADD_RELUMASK_DROP>(g, x.s);
+  wgrad(x, ws + x.W.dctx, x.d, in, S, x.grd + w, x.grd + b, x.d, S);
+}
+
+extern "C" int gt_backward(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
+                           const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
+                           gt_stream_t stream) {
+  Ctx x;
+  if (make_ctx(x, cfg, params, grads, ws, state, train, stream)) return -1;
+  if (!grads || !xin || !hvo || !d_hvo) return gt_fail("gt_backward: grads / x / hvo / d_hvo must not be NULL");
+  const int L = cfg->n_enc_layers, Ld = cfg->n_dec_layers, d = x.d, M = x.M;
+  if (Ld > 0 && !tgt_in) return gt_fail("gt_backward: encoder-decoder model needs tgt_in");
+  const WLayout& W = x.W;
+  const PLayout& P = x.P;
+  if (!accumulate) hipMemsetAsync(grads, 0, (size_t)P.total * sizeof(float), x.s);
+  float* dzA = ws + W.dzA; float* dzAm = x.drop ? ws + W.dzAm : dzA;
+  float* dzB = ws + W.dzB; float* dzBm = x.drop ? ws + W.dzBm : dzB;
+
+  // OutputLayer: dlogits, dW_out, then d(final) fused with the final norm's backward
+  gt_launch(heads_bwd_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, d_hvo, hvo, ws + W.dlogits, M * GT_TGT);
+  const float* fin = ws + (Ld > 0 ? W.dec_final : W.memory);
+  wgrad(x, ws + W.dlogits, GT_TGT, fin, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
+  {
+    const float* xh = ws + (Ld > 0 ? W.dec_xhat : W.enc_xhat);
+    const float* rs = ws + (Ld > 0 ? W.dec_rstd : W.enc_rstd);
+    if (dgrad_lnbwd(x, ws + W.dlogits, GT_TGT, params + P.out_w, GT_TGT, nullptr, xh, rs, Ld > 0 ? P.decn_w : P.encn_w,
+                    ws + W.dctx, nullptr, 0))
+      return gt_fail("d_model %d unsupported by the row-LayerNorm kernels", d);
+  }
+  // ws.dctx now holds the grad w.r.t. the last layer's output (the input of the final norm)
+  if (Ld > 0) {
+    hipMemsetAsync(ws + W.dmem, 0, (size_t)M * d * sizeof(float), x.s);
+    {
+      const LayerW& w = W.layers[L + Ld - 1];
+      ln_bwd(x, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.dec[Ld - 1].n3w, dzA, dzAm, lsite(L + Ld - 1, GT_SITE_DROPF));
+    }
+    for (int l = Ld - 1; l >= 0; --l) {
+      const LayerP& p = P.dec[l];
+      const LayerW& w = W.layers[L + l];
+      const int gl = L + l;
+      const float* yin = (l == 0) ? ws + W.y0 : ws + W.layers[L + l - 1].xout;
+      // FFN (+ norm3 handled by the producer of dzA) -> dz2 = LNbwd_norm2(...) in (dzB, dzBm), masked for cross out-proj
+      if (ffn_bwd(x, p, w, ws + w.x2, dzA, dzAm, ws + w.xhatx, ws + w.rstdx, p.n2w, dzB, dzBm, lsite(gl, GT_SITE_DROP2), gl)) return -1;
+      // cross attention
+      wgrad(x, dzBm, d, ws + w.ctxx, d, grads + p.xa.out_w, grads + p.xa.out_b, d, d);
+      dgrad_store(x, dzBm, d, params + p.xa.out_w, d, ws + W.dctx, d, d, 0);
+      float* dqx = ws + W.dqkv; float* dkvx = ws + W.dqkv + (int64_t)M * d;      // dq (M,d) then dkv (M,2d), both dense
+      attention_bwd(x, ws + w.qx, d, ws + w.kvx, ws + w.kvx + d, 2 * d, ws + w.Px, ws + W.dctx, dqx, d, dkvx, dkvx + d, 2 * d,
+                    lsite(gl, GT_SITE_XATTN));
+      wgrad(x, dqx, d, ws + w.x1, d, grads + p.xa.in_w, grads + p.xa.in_b, d, d);
+      wgrad(x, dkvx, 2 * d, ws + W.memory, d, grads + p.xa.in_w + (int64_t)d * d, grads + p.xa.in_b + d, 2 * d, d);
+      dgrad_store(x, dkvx, 2 * d, params + p.xa.in_w + (int64_t)d * d, d, ws + W.dmem, d, 2 * d, 1);
+      // dz1 = LNbwd_norm1(dqx Wq + dz2) -> (dzA, dzAm) masked for the self-attn out-proj
+      if (dgrad_lnbwd(x, dqx, d, params + p.xa.in_w, d, dzB, ws + w.xhat1, ws + w.rstd1, p.n1w, dzA, dzAm, lsite(gl, GT_SITE_DROP1)))
+        return -1;
+      self_attn_bwd(x, p, w, yin, dzAm, gl);
+      if (l > 0) {
+        const LayerW& wp = W.layers[L + l - 1];
+        // NOTE: result goes to dzB then is swapped into the "A" role for the next (lower) layer
+        if (dgrad_lnbwd(x, ws + W.dqkv, 3 * d, params + p.sa.in_w, 3 * d, dzA, ws + wp.xhat2, ws + wp.rstd2, P.dec[l - 1].n3w, dzB,
+                        dzBm, lsite(gl - 1, GT_SITE_DROPF)))
+          return -1;
+        float* t = dzA; dzA = dzB; dzB = t;
+        t = dzAm; dzAm = dzBm; dzBm = t;
+      } else {
+        input_layer_bwd(x, p, dzA, ws + W.b0, tgt_in, GT_TGT, P.din_w, P.din_b, GT_SITE_PE_DEC);
+      }
+    }
+    // encoder final norm backward (input: accumulated dmem) -> grad w.r.t. the last encoder layer's output
+    ln_bwd(x, ws + W.dmem, ws + W.enc_xhat, ws + W.enc_rstd, P.encn_w, ws + W.dctx, nullptr, 0);
+  }
+  {
+    const LayerW& w = W.layers[L - 1];
+    ln_bwd(x, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.enc[L - 1].n2w, dzA, dzAm, lsite(L - 1, GT_SITE_DROPF));
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerP& p = P.enc[l];
+    const LayerW& w = W.layers[l];
+    const float* lin = (l == 0) ? ws + W.x0 : ws + W.layers[l - 1].xout;
+    if (ffn_bwd(x, p, w, ws + w.x1, dzA, dzAm, ws + w.xhat1, ws + w.rstd1, p.n1w, dzB, dzBm, lsite(l, GT_SITE_DROP1), l)) return -1;
+    self_attn_bwd(x, p, w, lin, dzBm, l);
+    if (l > 0) {
+      const LayerW& wp = W.layers[l - 1];
+      if (dgrad_lnbwd(x, ws + W.dqkv, 3 * d, params + p.sa.in_w, 3 * d, dzB, ws + wp.xhat2, ws + wp.rstd2, P.enc[l - 1].n2w, dzA, dzAm,
+                      lsite(l - 1, GT_SITE_DROPF)))
+        return -1;
+    } else {
+      input_layer_bwd(x, p, dzB, ws + W.a0, xin, cfg->src_dim, P.in_w, P.in_b, GT_SITE_PE_ENC);
+    }
+  }
+  return launch_status("gt_backward");
+}
+
+// ------------------------------------------------------------------------------------ optimizer
+extern "C" int gt_optimizer_step(int algo, float* params, const float* grads, float* m, float* v, int64_t n, gt_step_state* state,
+                                 gt_stream_t stream) {
+  if (!params || !grads || !state || n <= 0) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((n + 1023) / 1024);
+  if (algo == 0) {
+    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, (const gt_step_state*)state);
+  } else if (algo == 1) {
+    if (!m || !v) return gt_fail("gt_optimizer_step: adam needs m and v");
+    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state);
+  } else {
+    return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
+  }
+  gt_launch(step_inc_kernel, dim3(1), dim3(64), s, state);
+  return launch_status("gt_optimizer_step");
+}
+
+// ------------------------------------------------------------------------------------ fused train step
+extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, float* grads, float* m, float* v, const float* pe,
+                             const float* xin, const float* y, float hit_loss_penalty, float* hvo_out, float* stats,
+                             float* tgt_scratch, float* ws, gt_step_state* state, int skip_update, gt_stream_t stream) {
+  if (check_cfg(cfg)) return -1;
+  if (!y || !state) return gt_fail("gt_train_step: y / state must not be NULL");
+  const int M = cfg->batch * 32;
+  hipStream_t s = (hipStream_t)stream;
+  const float* tgt_in = nullptr;
+  if (cfg->n_dec_layers > 0) {
+    if (!tgt_scratch) return gt_fail("gt_train_step: encoder-decoder model needs tgt_scratch");
+    gt_launch(shift_right_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), s, y, tgt_scratch, M * GT_TGT);
+    tgt_in = tgt_scratch;
+  }
+  if (gt_forward(cfg, params, pe, xin, tgt_in, hvo_out, ws, state, 1, stream)) return -1;
+  // d_hvo lives in the (not yet used) dqkv temporary
+  WLayout W = ws_layout(*cfg);
+  float* d_hvo = ws + W.dqkv;
+  if (gt_loss(cfg, hvo_out, y, hit_loss_penalty, stats, d_hvo, stream)) return -1;
+  if (gt_backward(cfg, params, grads, xin, tgt_in, hvo_out, d_hvo, ws, state, 1, 0, stream)) return -1;
+  if (!skip_update) {
+    PLayout P = param_layout(*cfg);
+    if (gt_optimizer_step(algo, params, grads, m, v, P.total, state, stream)) return -1;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ predict
+extern "C" int gt_predict(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, float thres,
+                          int use_thres, float* tgt_scratch, float* ws, gt_stream_t stream) {
+  Ctx x;
+  if (make_ctx(x, cfg, params, nullptr, ws, nullptr, 0, stream)) return -1;
+  if (!pe || !xin || !hvo_out) return gt_fail("gt_predict: pe / x / hvo_out must not be NULL");
+  const int M = x.M, B = cfg->batch;
+  if (encoder_fwd(x, pe, xin)) return -1;
+  if (cfg->n_dec_layers == 0) {
+    output_layer_fwd(x, hvo_out);
+    gt_launch(predict_head_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, (const float*)hvo_out, hvo_out, (float*)nullptr,
+              thres, use_thres, -1, B);
+    return launch_status("gt_predict");
+  }
+  if (!tgt_scratch) return gt_fail("gt_predict: encoder-decoder model needs tgt_scratch");
+  // greedy decode: tgt row 0 = zeros, row t+1 = thresholded step t.  The encoder memory is computed once
+  // (it does not depend on tgt); each step re-runs the decoder stack on the current tgt.
+  float* tmp = ws + x.W.hvo_tmp;
+  hipMemsetAsync(tgt_scratch, 0, (size_t)M * GT_TGT * sizeof(float), x.s);
+  for (int t = 0; t < 32; ++t) {
+    if (decoder_fwd(x, pe, tgt_scratch)) return -1;
+    output_layer_fwd(x, tmp);
+    gt_launch(predict_head_kernel, dim3((B * GT_TGT + 255) / 256), dim3(256), x.s, (const float*)tmp, hvo_out, tgt_scratch, thres,
+              use_thres, t, B);
+  }
+  return launch_status("gt_predict");
+}

@@ -1,0 +1,60 @@
+// Common device/host helpers for libgroove_hip.so (gfx950 / CDNA4 only).
+// GT_EMU is defined only by tests/emu/build_emu.sh (host fiber emulator, test infrastructure).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef GT_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15];
+// D[row=4*(l>>4)+reg][col=l&15].  Exact f32 fmaf chain (cdna_hip_programming.md section 3).
+#define GT_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
+#include "../../include/groove_hip.h"
+
+#define GT_LN_EPS 1e-5f
+
+template <typename... KArgs, typename... Args>
+static inline void gt_launch(void (*kern)(KArgs...), dim3 grid, dim3 block, hipStream_t s, Args... args) {
+#ifdef GT_EMU
+  (void)s;
+  emu::launch(grid, block, 0, [=]() { kern(args...); });
+#else
+  kern<<<grid, block, 0, s>>>(args...);
+#endif
+}
+
+// ---- dropout RNG (spec in include/groove_hip.h) ------------------------------------------------
+__host__ __device__ static inline uint32_t gt_fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+struct DropArgs {
+  const gt_step_state* st;   // nullptr -> disabled
+  uint32_t site;
+  uint32_t thr;              // p * 2^24; 0 -> disabled
+  float scale;               // 1/(1-p)
+};
+__device__ static inline uint32_t gt_drop_key(const DropArgs& d) {
+  if (d.thr == 0u || d.st == nullptr) return 0u;
+  uint32_t s = d.st->seed_lo ^ gt_fmix32(d.st->step);
+  uint32_t k = s ^ (d.site * 0x9E3779B9u);
+  k = gt_fmix32(k) ^ d.st->seed_hi;
+  return gt_fmix32(k + 0x7F4A7C15u);
+}
+// multiplier for element idx: scale if kept, 0 if dropped
+__device__ static inline float gt_drop_mul(const DropArgs& d, uint32_t key, uint32_t idx) {
+  if (d.thr == 0u || d.st == nullptr) return 1.0f;
+  return ((gt_fmix32((idx * 0x9E3779B1u) ^ key) >> 8) >= d.thr) ? d.scale : 0.0f;
+}
+
+__device__ static inline float gt_wave_sum(float v) {
+  v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);  v += __shfl_xor(v, 2);  v += __shfl_xor(v, 1);
+  return v;
+}
+__device__ static inline float gt_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

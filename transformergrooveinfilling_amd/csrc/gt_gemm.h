@@ -1,0 +1,383 @@
+// fp32 MFMA tile GEMM with fused epilogues -- the dominant kernel family of the train step.
+//
+//   C[M,N] (+)= sum_k A(m,k) * B(k,n)
+//
+// Operand storage (template flags):
+//   AKM=false : A(m,k) = A[m*lda + k]   (k contiguous; activations / incoming gradients)
+//   AKM=true  : A(m,k) = A[k*lda + m]   (m contiguous; wgrad: A = dY^T)
+//   BKM=false : B(k,n) = B[n*ldb + k]   (torch Linear weight (out,in) used as x W^T: forward "NT")
+//   BKM=true  : B(k,n) = B[k*ldb + n]   (dgrad "NN": dX = dY W;  wgrad "TN": dW = dY^T X)
+//
+// Workgroup = WM x WN waves; each wave owns TM x TN tiles of v_mfma_f32_16x16x4_f32 (exact fp32;
+// 64 FLOP/clk/SIMD = the chip's 157.3 TF fp32 matrix peak, MI355X_MICROARCH.md "Matrix cores").
+// K is walked in BK=16 slabs, double-buffered in LDS with register staging (global loads of slab
+// t+1 are in flight while slab t is multiplied; one barrier per slab).  Tiles are kept in LDS in
+// SOURCE orientation so both global->LDS copies are 16-byte vector moves:
+//   k-contiguous source : s[row][16+4]  -> fragment for 4 MFMA k-steps = ONE ds_read_b128
+//                         (lane (r=l&15, g=l>>4) reads k = 4g..4g+3; A and B use the same
+//                         k permutation, so the products pair up correctly)
+//   row-contiguous source: s[k][rows+4] -> fragment = 4 ds_read_b32 (stride%8==4: conflict-free)
+// Out-of-range rows/cols/k are zero-filled on load and masked on store, so every M, N, K works
+// (S=27 inputs, 27-wide HVO heads, d_model=16...).
+//
+// Row epilogues (EPI_RES_LN / EPI_RES_LNBWD) need BN >= N: the workgroup owns whole rows, stages
+// the accumulators through LDS and runs LayerNorm forward/backward with 64-lane wave reductions.
+#pragma once
+#include "gt_common.h"
+
+enum {
+  EPI_STORE = 0,          // C = acc + bias (+ C if accumulate)
+  EPI_ATOMIC = 1,         // atomicAdd(C, acc)            (split-K wgrad; + bias-grad column sums of A)
+  EPI_RELU_PE = 2,        // aux = acc+bias; C = drop(relu(aux) + pe[t])          (InputLayer)
+  EPI_RELU_DROP = 3,      // C = drop(relu(acc+bias))                               (FFN linear1)
+  EPI_HEADS = 4,          // C = [h | sigmoid v | 0.5 tanh o](acc+bias)             (OutputLayer)
+  EPI_MASK_NZ = 5,        // C = acc * (res != 0 ? mask_scale : 0)                  (FFN linear2 dgrad)
+  EPI_ADD_RELUMASK_DROP = 6,  // C = (acc + res) * dropmask * (aux_in > 0)          (InputLayer backward)
+  EPI_RES_LN = 7,         // z = drop(acc+bias) + res; C = LN(z); aux = xhat; aux2 = rstd
+  EPI_RES_LNBWD = 8       // g = acc (+ res); C = LNbwd(g); C2 = C*dropmask; dgamma/dbeta atomics
+};
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K, lda, ldb, ldc;
+  int k_chunk;               // K range per blockIdx.z (multiple of 16)
+  int accumulate;
+  const float* bias;         // [N] or nullptr
+  const float* res; int ldres;
+  const float* aux_in;       // a0 for EPI_ADD_RELUMASK_DROP (ld = N)
+  float* aux;                // [M,N] (ld = N): a0 / xhat
+  float* aux2;               // [M]: rstd
+  float* C2;                 // second output (ld = ldc) or nullptr
+  const float* gamma; const float* beta;
+  const float* xhat; const float* rstd;     // LN backward inputs (ld = N)
+  float* dgamma; float* dbeta;
+  const float* pe;           // [32, N]
+  float* dbias;              // EPI_ATOMIC: column sums of A over k (grad of the bias), or nullptr
+  float mask_scale;
+  DropArgs drop;
+};
+
+template <int ROWS, int COLS, int NT>
+struct TileStage {
+  static constexpr int CPR = COLS / 4;            // float4 chunks per row
+  static constexpr int CH = ROWS * CPR;
+  static constexpr int PER = (CH + NT - 1) / NT;
+  float4 v[PER];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int r0, int c0, int rmax,
+                                       int cmax, bool vec, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int ch = tid + i * NT;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (CH % NT == 0 || ch < CH) {
+        int r = ch / CPR, c = (ch % CPR) * 4;
+        int gr = r0 + r, gc = c0 + c;
+        if (gr < rmax && gc < cmax) {
+          const float* p = src + (size_t)gr * ld + gc;
+          if (vec && gc + 3 < cmax) {
+            t = *reinterpret_cast<const float4*>(p);
+          } else {
+            t.x = p[0];
+            if (gc + 1 < cmax) t.y = p[1];
+            if (gc + 2 < cmax) t.z = p[2];
+            if (gc + 3 < cmax) t.w = p[3];
+          }
+        }
+      }
+      v[i] = t;
+    }
+  }
+  __device__ __forceinline__ void store(float* s, int str, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int ch = tid + i * NT;
+      if (CH % NT == 0 || ch < CH) {
+        int r = ch / CPR, c = (ch % CPR) * 4;
+        *reinterpret_cast<float4*>(&s[r * str + c]) = v[i];
+      }
+    }
+  }
+};
+
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI>
+struct GemmCfg {
+  static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 16, NT = WM * WN * 64;
+  static constexpr int SA_STR = AKM ? BM + 4 : BK + 4, SA_ROWS = AKM ? BK : BM;
+  static constexpr int SB_STR = BKM ? BN + 4 : BK + 4, SB_ROWS = BKM ? BK : BN;
+  static constexpr int SA_SZ = SA_ROWS * SA_STR, SB_SZ = SB_ROWS * SB_STR;
+  static constexpr bool ROW = (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD);
+  static constexpr int CSTR = BN + 4;
+  static constexpr int MAIN_SZ = 2 * (SA_SZ + SB_SZ);
+  static constexpr int EPI_SZ = ROW ? BM * CSTR : 0;
+  static constexpr int SMEM = MAIN_SZ > EPI_SZ ? MAIN_SZ : EPI_SZ;
+};
+
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+  typedef GemmCfg<WM, WN, TM, TN, AKM, BKM, EPI> Cfg;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::NT;
+  constexpr int SA_STR = Cfg::SA_STR, SB_STR = Cfg::SB_STR, SA_SZ = Cfg::SA_SZ, SB_SZ = Cfg::SB_SZ;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.k_chunk;
+  const int kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  TileStage<Cfg::SA_ROWS, AKM ? BM : BK, NT> la;
+  TileStage<Cfg::SB_ROWS, BKM ? BN : BK, NT> lb;
+  float bsum = 0.f;   // EPI_ATOMIC: bias-grad partial (column sum of the A slab)
+
+  auto load_tiles = [&](int k0) {
+    if (AKM) la.load(g.A, g.lda, k0, m0, kend, g.M, vecA, tid);
+    else     la.load(g.A, g.lda, m0, k0, g.M, kend, vecA, tid);
+    if (BKM) lb.load(g.B, g.ldb, k0, n0, kend, g.N, vecB, tid);
+    else     lb.load(g.B, g.ldb, n0, k0, g.N, kend, vecB, tid);
+  };
+
+  if (nk > 0) {
+    load_tiles(kbeg);
+    la.store(smem, SA_STR, tid);
+    lb.store(smem + 2 * SA_SZ, SB_STR, tid);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const float* sA = smem + cur * SA_SZ;
+    const float* sB = smem + 2 * SA_SZ + cur * SB_SZ;
+    if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+
+    float af[TM][4], bf[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = (wm * TM + i) * 16 + l16;
+      if (!AKM) {
+        float4 t = *reinterpret_cast<const float4*>(&sA[row * SA_STR + 4 * lg]);
+        af[i][0] = t.x; af[i][1] = t.y; af[i][2] = t.z; af[i][3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[i][j] = sA[(4 * lg + j) * SA_STR + row];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int col = (wn * TN + i) * 16 + l16;
+      if (!BKM) {
+        float4 t = *reinterpret_cast<const float4*>(&sB[col * SB_STR + 4 * lg]);
+        bf[i][0] = t.x; bf[i][1] = t.y; bf[i][2] = t.z; bf[i][3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[i][j] = sB[(4 * lg + j) * SB_STR + col];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = GT_MFMA16(af[a][j], bf[b][j], acc[a][b]);
+
+    if (EPI == EPI_ATOMIC && AKM) {
+      if (g.dbias != nullptr && blockIdx.x == 0 && tid < BM) {
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) bsum += sA[kk * SA_STR + tid];
+      }
+    }
+    if (kt + 1 < nk) {
+      la.store(smem + (cur ^ 1) * SA_SZ, SA_STR, tid);
+      lb.store(smem + 2 * SA_SZ + (cur ^ 1) * SB_SZ, SB_STR, tid);
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------------------- epilogues
+  const uint32_t dkey = gt_drop_key(g.drop);
+
+  if (!Cfg::ROW) {
+    if (EPI == EPI_ATOMIC && AKM) {
+      if (g.dbias != nullptr && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) atomicAdd(&g.dbias[m0 + tid], bsum);
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + (wm * TM + a) * 16 + 4 * lg + r;
+          const int col = n0 + (wn * TN + b) * 16 + l16;
+          if (row < g.M && col < g.N) {
+            float v = acc[a][b][r];
+            const size_t ci = (size_t)row * g.ldc + col;
+            if (EPI == EPI_STORE) {
+              if (g.bias) v += g.bias[col];
+              if (g.accumulate) v += g.C[ci];
+              g.C[ci] = v;
+            } else if (EPI == EPI_ATOMIC) {
+              atomicAdd(&g.C[ci], v);
+            } else if (EPI == EPI_RELU_PE) {
+              v += g.bias[col];
+              g.aux[(size_t)row * g.N + col] = v;
+              v = fmaxf(v, 0.f) + g.pe[(row & 31) * g.N + col];
+              g.C[ci] = v * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
+            } else if (EPI == EPI_RELU_DROP) {
+              v = fmaxf(v + g.bias[col], 0.f);
+              g.C[ci] = v * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
+            } else if (EPI == EPI_HEADS) {
+              v += g.bias[col];
+              if (col >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
+              else if (col >= GT_VOICES) v = gt_sigmoid(v);
+              g.C[ci] = v;
+            } else if (EPI == EPI_MASK_NZ) {
+              g.C[ci] = (g.res[(size_t)row * g.ldres + col] != 0.f) ? v * g.mask_scale : 0.f;
+            } else if (EPI == EPI_ADD_RELUMASK_DROP) {
+              v += g.res[(size_t)row * g.ldres + col];
+              v *= gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
+              g.C[ci] = (g.aux_in[(size_t)row * g.N + col] > 0.f) ? v : 0.f;
+            }
+          }
+        }
+    return;
+  }
+
+  // Row epilogues: stage the BM x N block in LDS (the main loop's final barrier has passed).
+  constexpr int CSTR = Cfg::CSTR;
+  float* sC = smem;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = (wm * TM + a) * 16 + 4 * lg + r;
+        const int cl = (wn * TN + b) * 16 + l16;
+        const int row = m0 + rl;
+        float v = acc[a][b][r];
+        if (row < g.M && cl < g.N) {
+          if (EPI == EPI_RES_LN) {
+            v += g.bias[cl];
+            v *= gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + cl));
+            v += g.res[(size_t)row * g.ldres + cl];
+          } else {
+            if (g.res) v += g.res[(size_t)row * g.ldres + cl];
+          }
+        }
+        sC[rl * CSTR + cl] = v;
+      }
+  __syncthreads();
+
+  constexpr int NW = WM * WN;
+  constexpr int CPL = (BN + 63) / 64;     // columns per lane
+  const float invN = 1.0f / (float)g.N;
+  float dg[CPL], db[CPL];
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+
+  for (int rl = wave; rl < BM; rl += NW) {
+    const int row = m0 + rl;
+    if (row >= g.M) break;                 // wave-uniform
+    const float* zr = sC + rl * CSTR;
+    if (EPI == EPI_RES_LN) {
+      float s = 0.f;
+      for (int c = lane; c < g.N; c += 64) s += zr[c];
+      const float mean = gt_wave_sum(s) * invN;
+      float q = 0.f;
+      for (int c = lane; c < g.N; c += 64) { float d = zr[c] - mean; q += d * d; }
+      const float rstd = 1.0f / sqrtf(gt_wave_sum(q) * invN + GT_LN_EPS);
+      for (int c = lane; c < g.N; c += 64) {
+        const float xh = (zr[c] - mean) * rstd;
+        g.aux[(size_t)row * g.N + c] = xh;
+        g.C[(size_t)row * g.ldc + c] = xh * g.gamma[c] + g.beta[c];
+      }
+      if (lane == 0) g.aux2[row] = rstd;
+    } else {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < g.N) {
+          const float dy = zr[c], xh = g.xhat[(size_t)row * g.N + c];
+          const float gdy = dy * g.gamma[c];
+          s1 += gdy; s2 += gdy * xh;
+          dg[i] += dy * xh; db[i] += dy;
+        }
+      }
+      const float m1 = gt_wave_sum(s1) * invN, m2 = gt_wave_sum(s2) * invN;
+      const float rs = g.rstd[row];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < g.N) {
+          const float xh = g.xhat[(size_t)row * g.N + c];
+          const float dz = rs * (zr[c] * g.gamma[c] - m1 - xh * m2);
+          g.C[(size_t)row * g.ldc + c] = dz;
+          if (g.C2) g.C2[(size_t)row * g.ldc + c] = dz * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + c));
+        }
+      }
+    }
+  }
+  if (EPI == EPI_RES_LNBWD) {
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < g.N) { atomicAdd(&g.dgamma[c], dg[i]); atomicAdd(&g.dbeta[c], db[i]); }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------- host dispatch
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI>
+static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s) {
+  typedef GemmCfg<WM, WN, TM, TN, AKM, BKM, EPI> Cfg;
+  dim3 grid((g.N + Cfg::BN - 1) / Cfg::BN, (g.M + Cfg::BM - 1) / Cfg::BM, splitk);
+  gt_launch(gemm_kernel<WM, WN, TM, TN, AKM, BKM, EPI>, grid, dim3(Cfg::NT), s, g);
+}
+
+// standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
+template <bool AKM, bool BKM, int EPI>
+static inline void gemm_launch(GemmArgs g, hipStream_t s) {
+  int splitk = 1;
+  g.k_chunk = (g.K + 15) / 16 * 16;
+  const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  if (EPI == EPI_ATOMIC) {
+    // wgrad: output is small (N_w x K_w), the contraction (tokens) is long -> split it over z
+    const long tiles = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+    long want = (1024 + tiles - 1) / tiles;
+    long maxs = (g.K + 63) / 64;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    int chunk = (int)((g.K + want - 1) / want);
+    chunk = (chunk + 15) / 16 * 16;
+    splitk = (g.K + chunk - 1) / chunk;
+    g.k_chunk = chunk;
+    gemm_launch_cfg<2, 2, 1, 1, AKM, BKM, EPI>(g, splitk, s);
+    return;
+  }
+  if (t64 >= 512) gemm_launch_cfg<2, 2, 2, 2, AKM, BKM, EPI>(g, splitk, s);
+  else            gemm_launch_cfg<2, 2, 1, 1, AKM, BKM, EPI>(g, splitk, s);
+}
+
+// row epilogues: BN = padded d_model, BM = 32
+template <bool AKM, bool BKM, int EPI>
+static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
+  g.k_chunk = (g.K + 15) / 16 * 16;
+  if (g.N <= 32)       gemm_launch_cfg<2, 2, 1, 1, AKM, BKM, EPI>(g, 1, s);
+  else if (g.N <= 64)  gemm_launch_cfg<2, 2, 1, 2, AKM, BKM, EPI>(g, 1, s);
+  else if (g.N <= 128) gemm_launch_cfg<2, 2, 1, 4, AKM, BKM, EPI>(g, 1, s);
+  else if (g.N <= 256) gemm_launch_cfg<1, 4, 2, 4, AKM, BKM, EPI>(g, 1, s);
+  else if (g.N <= 512) gemm_launch_cfg<1, 4, 2, 8, AKM, BKM, EPI>(g, 1, s);
+  else return -1;
+  return 0;
+}

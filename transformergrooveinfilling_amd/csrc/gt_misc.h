@@ -1,0 +1,191 @@
+// Row-wise / elementwise kernels of the step: standalone LayerNorm fwd/bwd (final encoder/decoder
+// norms), the fused BCE+MSE loss with its hit_loss_penalty mask, head-activation backward,
+// the flat multi-tensor SGD/Adam update, teacher-forcing shift and the predict threshold.
+// All are HBM-bound streaming kernels; every (M,d) pass is one coalesced read + one write.
+#pragma once
+#include "gt_common.h"
+
+// ---- LayerNorm forward: one wave per row -------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ xhat, float* __restrict__ rstd_out, int M, int N) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * N;
+  const float invN = 1.0f / (float)N;
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += xr[c];
+  const float mean = gt_wave_sum(s) * invN;
+  float q = 0.f;
+  for (int c = lane; c < N; c += 64) { const float d = xr[c] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(gt_wave_sum(q) * invN + GT_LN_EPS);
+  for (int c = lane; c < N; c += 64) {
+    const float xh = (xr[c] - mean) * rstd;
+    xhat[(size_t)row * N + c] = xh;
+    y[(size_t)row * N + c] = xh * gamma[c] + beta[c];
+  }
+  if (lane == 0) rstd_out[row] = rstd;
+}
+
+// ---- LayerNorm backward: one wave walks ROWS_PER_WAVE rows, then one atomic per column ----------
+#define GT_LNB_ROWS 8
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     float* __restrict__ dz, float* __restrict__ dz_masked, DropArgs drop,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int N) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GT_LNB_ROWS;
+  const float invN = 1.0f / (float)N;
+  const uint32_t dkey = gt_drop_key(drop);
+  float dg[GT_MAX_D / 64], db[GT_MAX_D / 64];
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+  for (int rr = 0; rr < GT_LNB_ROWS; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      if (c < N) {
+        const float d = dy[(size_t)row * N + c], xh = xhat[(size_t)row * N + c], gd = d * gamma[c];
+        s1 += gd; s2 += gd * xh; dg[i] += d * xh; db[i] += d;
+      }
+    }
+    const float m1 = gt_wave_sum(s1) * invN, m2 = gt_wave_sum(s2) * invN, rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      if (c < N) {
+        const size_t e = (size_t)row * N + c;
+        const float v = rs * (dy[e] * gamma[c] - m1 - xhat[e] * m2);
+        dz[e] = v;
+        if (dz_masked) dz_masked[e] = v * gt_drop_mul(drop, dkey, (uint32_t)e);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) {
+    const int c = lane + 64 * i;
+    if (c < N && row0 < M) { atomicAdd(&dgamma[c], dg[i]); atomicAdd(&dbeta[c], db[i]); }
+  }
+}
+
+// ---- loss: BCEWithLogits(h)*pen + MSE(v)*pen + MSE(o)*pen, summed over voices, mean over (B,T) ---
+// One thread per (row, voice).  stats: [0] loss [1] hit accuracy [3] bce [4] mse_v [5] mse_o.
+// d_hvo = d loss / d (h, v, o)  (w.r.t. the ACTIVATED outputs, like autograd hands them over).
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ hvo, const float* __restrict__ y, float penalty,
+                                                   float* __restrict__ stats, float* __restrict__ d_hvo, int M) {
+  __shared__ float red[4][4];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const float invM = 1.0f / (float)M;
+  float bce = 0.f, mv = 0.f, mo = 0.f, ok = 0.f;
+  if (e < M * GT_VOICES) {
+    const int m = e / GT_VOICES, j = e % GT_VOICES;
+    const size_t base = (size_t)m * GT_TGT + j;
+    const float h = hvo[base], v = hvo[base + GT_VOICES], o = hvo[base + 2 * GT_VOICES];
+    const float yh = y[base], yv = y[base + GT_VOICES], yo = y[base + 2 * GT_VOICES];
+    const float pen = (yh == 1.0f) ? 1.0f : penalty;
+    bce = (fmaxf(h, 0.f) - h * yh + log1pf(expf(-fabsf(h)))) * pen;
+    mv = (v - yv) * (v - yv) * pen;
+    mo = (o - yo) * (o - yo) * pen;
+    ok = (((h > 0.f) ? 1.0f : 0.0f) == yh) ? 1.0f : 0.0f;      // sigmoid(h) > 0.5  <=>  h > 0
+    if (d_hvo) {
+      d_hvo[base] = (gt_sigmoid(h) - yh) * pen * invM;
+      d_hvo[base + GT_VOICES] = 2.0f * (v - yv) * pen * invM;
+      d_hvo[base + 2 * GT_VOICES] = 2.0f * (o - yo) * pen * invM;
+    }
+  }
+  bce = gt_wave_sum(bce); mv = gt_wave_sum(mv); mo = gt_wave_sum(mo); ok = gt_wave_sum(ok);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = bce; red[w][1] = mv; red[w][2] = mo; red[w][3] = ok; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b_ = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * invM;
+    const float v_ = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * invM;
+    const float o_ = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) * invM;
+    const float k_ = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) * invM * (1.0f / GT_VOICES);
+    atomicAdd(&stats[0], b_ + v_ + o_);
+    atomicAdd(&stats[1], k_);
+    atomicAdd(&stats[3], b_);
+    atomicAdd(&stats[4], v_);
+    atomicAdd(&stats[5], o_);
+  }
+}
+
+// d logits = d (h,v,o) * activation'  (v = sigmoid -> v(1-v);  o = 0.5 tanh -> 0.5 - 2 o^2)
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ d_hvo, const float* __restrict__ hvo,
+                                                        float* __restrict__ dlogits, int n) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int c = e % GT_TGT;
+  const float a = hvo[e];
+  float g = d_hvo[e];
+  if (c >= 2 * GT_VOICES) g *= (0.5f - 2.0f * a * a);
+  else if (c >= GT_VOICES) g *= a * (1.0f - a);
+  dlogits[e] = g;
+}
+
+// ---- optimizer: flat multi-tensor update (one launch for all 78+ tensors) -----------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n,
+                                                  const gt_step_state* __restrict__ st) {
+  const float k = st->lr * st->grad_scale;
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 pv = *reinterpret_cast<float4*>(p + i);
+    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    pv.x -= k * gv.x; pv.y -= k * gv.y; pv.z -= k * gv.z; pv.w -= k * gv.w;
+    *reinterpret_cast<float4*>(p + i) = pv;
+  } else {
+    for (int64_t j = i; j < n; ++j) p[j] -= k * g[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, const gt_step_state* __restrict__ st) {
+  const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->step + 1u);
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const float step_size = st->lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = i0 + u;
+    if (i < n) {
+      const float gi = g[i] * st->grad_scale;
+      const float mi = b1 * m[i] + (1.0f - b1) * gi;
+      const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + st->eps);
+    }
+  }
+}
+
+__global__ void step_inc_kernel(gt_step_state* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) st->step += 1u;
+}
+
+// teacher forcing: tgt_in[b,t] = y[b,t-1], row 0 = zeros
+__global__ __launch_bounds__(256) void shift_right_kernel(const float* __restrict__ y, float* __restrict__ tgt, int n) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int m = e / GT_TGT;
+  tgt[e] = ((m & 31) == 0) ? 0.f : y[e - GT_TGT];
+}
+
+// predict: h = sigmoid(logit) > thres ? 1 : 0 (or the probability).  t < 0: all rows (encoder-only);
+// t >= 0: only row t of every sequence, and the thresholded step is fed to tgt row t+1 (greedy decode).
+__global__ __launch_bounds__(256) void predict_head_kernel(const float* __restrict__ hvo_in, float* __restrict__ hvo_out,
+                                                           float* __restrict__ tgt, float thres, int use_thres, int t, int B) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int rows = (t < 0) ? B * 32 : B;
+  if (e >= rows * GT_TGT) return;
+  const int r = e / GT_TGT, c = e % GT_TGT;
+  const int m = (t < 0) ? r : r * 32 + t;
+  float a = hvo_in[(size_t)m * GT_TGT + c];
+  if (c < GT_VOICES) {
+    const float pr = gt_sigmoid(a);
+    a = use_thres ? ((pr > thres) ? 1.0f : 0.0f) : pr;
+  }
+  hvo_out[(size_t)m * GT_TGT + c] = a;
+  if (tgt != nullptr && t >= 0 && t + 1 < 32) tgt[(size_t)(m + 1) * GT_TGT + c] = a;
+}
