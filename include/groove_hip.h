@@ -135,6 +135,12 @@ int gt_predict(const gt_config* cfg, const float* params, const float* pe, const
                float* hvo_out, float thres, int use_thres, float* tgt_scratch, float* ws,
                gt_stream_t stream);
 
+/* Measurement aid (no reference counterpart): with profiling on, every kernel launch is bracketed by
+ * HIP events on its own stream.  gt_profile_report synchronises and writes one text row per kernel
+ * class: "label launches total_ms total_flops total_bytes".  Not graph-capturable while on. */
+int gt_profile_enable(int on);
+int gt_profile_report(char* buf, size_t buf_len, int max_rows);
+
 #ifdef __cplusplus
 }
 #endif

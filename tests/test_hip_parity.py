@@ -1,0 +1,105 @@
+"""Parity of the real HIP path (libgroove_hip.so on an MI355X) against the oracle, the committed
+golden vectors and the reference's demo checkpoint; then size-independent properties at
+BASELINE.json's full sizes.  All calls go through the C ABI."""
+import numpy as np
+import pytest
+
+import parity
+from harness import Runner, cfg_dict
+from oracle import numpy_groove as ng
+
+pytestmark = pytest.mark.gpu
+
+ENC = cfg_dict(32, 4, 16, 2)
+ENCDEC = cfg_dict(32, 4, 16, 2, 2)
+C1 = cfg_dict(32, 4, 16, 6)                       # InfillingClosedHH_testing_training.yaml
+YAML_HH = cfg_dict(32, 16, 512, 6)                # InfillingClosedHH_training.yaml (head_dim 2)
+C2 = cfg_dict(128, 4, 512, 3)                     # BASELINE configs[1]
+YAML_KS = cfg_dict(256, 2, 512, 6)                # InfillingKicksAndSnares / InfillingRandom YAML (head_dim 128)
+C3 = cfg_dict(256, 2, 512, 2, 2)                  # encoder-decoder (layers reduced for oracle time)
+C4 = cfg_dict(512, 8, 512, 2)                     # d_model 512 / 8 heads (layers reduced for oracle time)
+SYM = cfg_dict(64, 16, 64, 2, embedding_size_src=27)
+
+
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 2, 0.0), (ENC, 5, 0.25), (ENCDEC, 3, 0.0), (ENCDEC, 2, 0.25), (C1, 32, 0.18),
+                                     (YAML_HH, 16, 0.24), (SYM, 3, 0.1), (cfg_dict(16, 16, 16, 1), 1, 0.0),
+                                     (C2, 8, 0.0), (C2, 64, 0.24), (YAML_KS, 4, 0.3), (C3, 4, 0.0), (C3, 3, 0.3),
+                                     (C4, 4, 0.0), (C4, 3, 0.15), (cfg_dict(64, 4, 2048, 1), 2, 0.16)])
+def test_step_parity(cfg, B, p):
+    parity.check_step("hip", cfg, B, p)
+
+
+@pytest.mark.parametrize("path", parity.golden_files())
+def test_golden_vectors(path):
+    parity.check_golden("hip", path)
+
+
+def test_demo_checkpoint():
+    parity.check_demo_ckpt("hip")
+
+
+def test_optimizers():
+    parity.check_optimizers("hip", ENC, 4)
+    parity.check_optimizers("hip", C2, 2)
+
+
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 4, 0.2), (ENCDEC, 2, 0.1), (C2, 16, 0.24)])
+def test_train_step(cfg, B, p):
+    parity.check_train_step("hip", cfg, B, p)
+
+
+@pytest.mark.parametrize("cfg,B,use_thres", [(ENC, 8, True), (ENC, 3, False), (ENCDEC, 4, True), (C2, 32, True)])
+def test_predict(cfg, B, use_thres):
+    parity.check_predict("hip", cfg, B, use_thres)
+
+
+# ---- properties at full size (BASELINE configs[1]: d128/H4/F512/L3, bs 64, dropout 0.24) ---------------
+def test_full_size_properties():
+    cfg = dict(C2, dropout=0.24)
+    B = 64
+    P = ng.init_params(cfg, seed=0)
+    x, y = ng.synthetic_batch(B, 16, seed=1234)
+    r = Runner(cfg, B, "hip", rng=(5, 6, 0), lr=0.07)
+    r.set_params(P)
+    # (1) eval forward is a pure function of (weights, inputs): bitwise repeatable
+    a = r.forward(x)
+    b = r.forward(x)
+    assert np.array_equal(a, b)
+    # (2) sequences are independent: permuting the batch permutes the outputs bit for bit
+    perm = np.random.default_rng(0).permutation(B)
+    c = r.forward(x[perm])
+    assert np.array_equal(c, a[perm])
+    # (3) v in (0,1), o in (-0.5,0.5)
+    assert (a[..., 9:18] > 0).all() and (a[..., 9:18] < 1).all() and (np.abs(a[..., 18:]) < 0.5).all()
+    # (4) loss is linear in the penalty mask: stats(pen) = stats(0) + pen*(stats(1)-stats(0))
+    s0, _ = r.loss(y, 0.0)
+    s1, _ = r.loss(y, 1.0)
+    sp, _ = r.loss(y, 0.38)
+    assert abs(sp[0] - (s0[0] + 0.38 * (s1[0] - s0[0]))) < 1e-5 * abs(sp[0])
+    # (5) gradient of a scaled loss scales: backward is linear in d_hvo
+    _, d = r.loss(y, 0.38)
+    g1 = r.backward(d_hvo=d)
+    g2 = r.backward(d_hvo=2.0 * d)
+    for k in g1:
+        assert parity.rel_err(g2[k], 2.0 * g1[k]) < 1e-5, k
+    # (6) train-mode dropout: same (seed, step) -> same masks; next step -> different masks, same keep rate
+    t0 = r.forward(x, train=True)
+    h0 = r.ws_get("hact", 0)
+    t1 = r.forward(x, train=True)
+    assert np.array_equal(t0, t1)
+    r.train_step(x, y, 0.38)
+    assert r.step_state().step == 1
+    r.forward(x, train=True)
+    h1 = r.ws_get("hact", 0)
+    assert not np.array_equal(h0 == 0, h1 == 0)
+    # (7) a few SGD steps on a fixed batch reduce the loss
+    losses = [r.train_step(x, y, 0.38)[0] for _ in range(20)]
+    assert losses[-1] < losses[0]
+    assert np.isfinite(r.params.numpy()).all()
+
+
+def test_errors_are_reported():
+    from transformergrooveinfilling_amd import _lib
+    r = Runner(ENC, 2, "hip")
+    with pytest.raises(_lib.GrooveLibError):
+        r.forward(np.zeros((2, 32, 16), np.float32))      # params not set -> NULL

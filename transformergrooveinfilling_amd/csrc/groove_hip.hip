@@ -29,6 +29,65 @@ static int gt_fail(const char* fmt, ...) {
   return -1;
 }
 extern "C" const char* gt_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------ launch timing
+GtProfile g_prof;
+#ifndef GT_EMU
+struct ProfRec { const char* label; double flops, bytes; hipEvent_t a, b; };
+static std::vector<ProfRec> g_recs;
+void gt_prof_before(hipStream_t s) {
+  ProfRec r{g_prof.label, g_prof.flops, g_prof.bytes, nullptr, nullptr};
+  (void)hipEventCreate(&r.a);
+  (void)hipEventCreate(&r.b);
+  (void)hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+}
+void gt_prof_after(hipStream_t s) {
+  (void)hipEventRecord(g_recs.back().b, s);
+  g_prof.label = "other"; g_prof.flops = 0; g_prof.bytes = 0;
+}
+#else
+void gt_prof_before(hipStream_t) {}
+void gt_prof_after(hipStream_t) {}
+#endif
+extern "C" int gt_profile_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.label = "other";
+  return 0;
+}
+// Synchronises, then writes up to max_rows rows "label count total_ms total_flops total_bytes" (one per
+// kernel class, '\n'-separated) into buf and clears the records.  Returns the number of classes.
+extern "C" int gt_profile_report(char* buf, size_t buf_len, int max_rows) {
+  int n = 0;
+#ifndef GT_EMU
+  struct Acc { std::string label; long count; double ms, flops, bytes; };
+  std::vector<Acc> acc;
+  for (auto& r : g_recs) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+    size_t i = 0;
+    for (; i < acc.size(); ++i) if (acc[i].label == r.label) break;
+    if (i == acc.size()) acc.push_back(Acc{r.label, 0, 0, 0, 0});
+    acc[i].count++; acc[i].ms += ms; acc[i].flops += r.flops; acc[i].bytes += r.bytes;
+  }
+  g_recs.clear();
+  std::string out;
+  for (auto& a : acc) {
+    if (n >= max_rows) break;
+    char line[256];
+    snprintf(line, sizeof(line), "%s %ld %.6f %.6e %.6e\n", a.label.c_str(), a.count, a.ms, a.flops, a.bytes);
+    out += line;
+    ++n;
+  }
+  if (buf && buf_len) { strncpy(buf, out.c_str(), buf_len - 1); buf[buf_len - 1] = 0; }
+#else
+  if (buf && buf_len) buf[0] = 0;
+#endif
+  return n;
+}
 extern "C" int gt_version(void) { return 1; }
 
 static int check_cfg(const gt_config* c) {
@@ -249,6 +308,7 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
 static void ln_bwd(const Ctx& x, const float* dy, const float* xhat, const float* rstd, int64_t gamma_off, float* dz, float* dzm,
                    int site) {
   const int rows_per_block = 4 * GT_LNB_ROWS;
+  gt_prof_tag("ln_bwd", 0, 12.0 * x.M * x.d);
   gt_launch(ln_bwd_kernel, dim3((x.M + rows_per_block - 1) / rows_per_block), dim3(256), x.s, dy, xhat, rstd,
             x.prm + gamma_off, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
             x.grd + gamma_off + (x.d + 63) / 64 * 64, x.M, x.d);
@@ -270,6 +330,7 @@ static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k,
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = P; a.ctx = ctx; a.ldc = x.d;
   a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.causal = causal; a.drop = mk_drop(x, site);
+  gt_prof_tag("attn_fwd", 4.0 * x.M * 32 * x.d, 4.0 * (4.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   gt_launch(attn_fwd_kernel, dim3(x.c.batch * x.H), dim3(256), x.s, a);
 }
 static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* P,
@@ -279,6 +340,7 @@ static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k,
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = const_cast<float*>(P);
   a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.drop = mk_drop(x, site);
   a.dctx = dctx; a.lddc = x.d; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddkv; a.lddv = lddkv;
+  gt_prof_tag("attn_bwd", 10.0 * x.M * 32 * x.d, 4.0 * (7.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   gt_launch(attn_bwd_kernel, dim3(x.c.batch * x.H), dim3(256), x.s, a);
 }
 
@@ -339,6 +401,7 @@ static int encoder_fwd(const Ctx& x, const float* pe, const float* src) {
     if (ffn_fwd(x, p, w, ws + w.x1, p.n2w, l)) return -1;
     cur = ws + w.xout;
   }
+  gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
   gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, x.prm + x.P.encn_w, x.prm + x.P.encn_b, ws + x.W.memory,
             ws + x.W.enc_xhat, ws + x.W.enc_rstd, x.M, x.d);
   return 0;
@@ -362,6 +425,7 @@ static int decoder_fwd(const Ctx& x, const float* pe, const float* tgt_in) {
     if (ffn_fwd(x, p, w, ws + w.x2, p.n3w, gl)) return -1;
     cur = ws + w.xout;
   }
+  gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
   gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, x.prm + x.P.decn_w, x.prm + x.P.decn_b, ws + x.W.dec_final,
             ws + x.W.dec_xhat, ws + x.W.dec_rstd, x.M, x.d);
   return 0;
@@ -393,6 +457,7 @@ extern "C" int gt_loss(const gt_config* cfg, const float* hvo, const float* y, f
   const int M = cfg->batch * 32;
   hipStream_t s = (hipStream_t)stream;
   hipMemsetAsync(stats, 0, 8 * sizeof(float), s);
+  gt_prof_tag("loss", 0, 12.0 * M * GT_TGT);
   gt_launch(loss_kernel, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, hvo, y, hit_loss_penalty, stats, d_hvo, M);
   return launch_status("gt_loss");
 }
@@ -447,6 +512,7 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
   float* dzB = ws + W.dzB; float* dzBm = x.drop ? ws + W.dzBm : dzB;
 
   // OutputLayer: dlogits, dW_out, then d(final) fused with the final norm's backward
+  gt_prof_tag("heads_bwd", 0, 12.0 * M * GT_TGT);
   gt_launch(heads_bwd_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, d_hvo, hvo, ws + W.dlogits, M * GT_TGT);
   const float* fin = ws + (Ld > 0 ? W.dec_final : W.memory);
   wgrad(x, ws + W.dlogits, GT_TGT, fin, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
@@ -528,9 +594,11 @@ extern "C" int gt_optimizer_step(int algo, float* params, const float* grads, fl
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 1023) / 1024);
   if (algo == 0) {
+    gt_prof_tag("optimizer", 0, 12.0 * n);
     gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, (const gt_step_state*)state);
   } else if (algo == 1) {
     if (!m || !v) return gt_fail("gt_optimizer_step: adam needs m and v");
+    gt_prof_tag("optimizer", 0, 28.0 * n);
     gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state);
   } else {
     return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);

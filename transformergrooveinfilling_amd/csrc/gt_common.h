@@ -18,13 +18,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define GT_LN_EPS 1e-5f
 
+// ---- optional per-launch timing (gt_profile_*): HIP events around every launch, by kernel class ----
+// Off by default (zero overhead beyond one branch).  bench.py switches it on for a separate eager pass
+// to measure the dominant kernel's average duration live (events are recorded on the launch stream).
+struct GtProfile {
+  bool on = false;
+  const char* label = "";      // set by the caller just before a launch
+  double flops = 0, bytes = 0; // algorithmic work of the next launch
+};
+extern GtProfile g_prof;
+void gt_prof_before(hipStream_t s);
+void gt_prof_after(hipStream_t s);
+static inline void gt_prof_tag(const char* label, double flops, double bytes) {
+  if (g_prof.on) { g_prof.label = label; g_prof.flops = flops; g_prof.bytes = bytes; }
+}
+
 template <typename... KArgs, typename... Args>
 static inline void gt_launch(void (*kern)(KArgs...), dim3 grid, dim3 block, hipStream_t s, Args... args) {
 #ifdef GT_EMU
   (void)s;
   emu::launch(grid, block, 0, [=]() { kern(args...); });
 #else
+  if (g_prof.on) gt_prof_before(s);
   kern<<<grid, block, 0, s>>>(args...);
+  if (g_prof.on) gt_prof_after(s);
 #endif
 }
 

@@ -338,9 +338,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 }
 
 // --------------------------------------------------------------------------------- host dispatch
+template <bool BKM, int EPI>
+static inline const char* gemm_label() {
+  return EPI == EPI_ATOMIC ? "gemm_wgrad" : EPI == EPI_RES_LN ? "gemm_fwd_res_ln" : EPI == EPI_RES_LNBWD ? "gemm_dgrad_lnbwd"
+       : EPI == EPI_RELU_PE ? "gemm_fwd_input" : EPI == EPI_RELU_DROP ? "gemm_fwd_ffn1" : EPI == EPI_HEADS ? "gemm_fwd_heads"
+       : EPI == EPI_MASK_NZ ? "gemm_dgrad_ffn2" : EPI == EPI_ADD_RELUMASK_DROP ? "gemm_dgrad_input"
+       : BKM ? "gemm_dgrad" : "gemm_fwd_bias";
+}
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI>
 static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s) {
   typedef GemmCfg<WM, WN, TM, TN, AKM, BKM, EPI> Cfg;
+  gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
   dim3 grid((g.N + Cfg::BN - 1) / Cfg::BN, (g.M + Cfg::BM - 1) / Cfg::BM, splitk);
   gt_launch(gemm_kernel<WM, WN, TM, TN, AKM, BKM, EPI>, grid, dim3(Cfg::NT), s, g);
 }
