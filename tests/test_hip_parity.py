@@ -100,6 +100,10 @@ def test_full_size_properties():
 
 def test_errors_are_reported():
     from transformergrooveinfilling_amd import _lib
+    import ctypes
     r = Runner(ENC, 2, "hip")
-    with pytest.raises(_lib.GrooveLibError):
-        r.forward(np.zeros((2, 32, 16), np.float32))      # params not set -> NULL
+    with pytest.raises(_lib.GrooveLibError, match="NULL"):
+        r.lib.call("gt_forward", ctypes.byref(r.c), None, r.pe.ptr, r.hvo.ptr, None, r.hvo.ptr, r.ws.ptr, None, 0, r.stream)
+    bad = _lib.make_config(2, 16, 48, 5, 16, 2)            # 48 % 5 != 0
+    with pytest.raises(_lib.GrooveLibError, match="divisible"):
+        r.lib.call("gt_forward", ctypes.byref(bad), r.pe.ptr, r.pe.ptr, r.hvo.ptr, None, r.hvo.ptr, r.ws.ptr, None, 0, r.stream)

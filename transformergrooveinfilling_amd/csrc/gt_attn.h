@@ -28,7 +28,9 @@ __device__ static inline void attn_load_slab(float (*s)[33], const float* src, i
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = tid + 256 * u, r = e >> 5, c = e & 31;
-    s[r][c] = (c0 + c < hd) ? src[(size_t)(b * 32 + r) * ld + h * hd + c0 + c] : 0.f;
+    const bool ok = c0 + c < hd;                       // branch-free: clamped address, select after the load
+    const float val = src[(size_t)(b * 32 + r) * ld + h * hd + (ok ? c0 + c : 0)];
+    s[r][c] = ok ? val : 0.f;
   }
 }
 

@@ -10,10 +10,11 @@
 //
 // Workgroup = WM x WN waves; each wave owns TM x TN tiles of v_mfma_f32_16x16x4_f32 (exact fp32;
 // 64 FLOP/clk/SIMD = the chip's 157.3 TF fp32 matrix peak, MI355X_MICROARCH.md "Matrix cores").
-// K is walked in BK=16 slabs, double-buffered in LDS with register staging (global loads of slab
+// K is walked in BK-wide slabs (64 by default: few, long slabs keep the latency-exposed
+// load->barrier hand-offs rare on these short-K GEMMs), double-buffered in LDS with register staging (global loads of slab
 // t+1 are in flight while slab t is multiplied; one barrier per slab).  Tiles are kept in LDS in
 // SOURCE orientation so both global->LDS copies are 16-byte vector moves:
-//   k-contiguous source : s[row][16+4]  -> fragment for 4 MFMA k-steps = ONE ds_read_b128
+//   k-contiguous source : s[row][BK+4]  -> fragment for 4 MFMA k-steps = ONE ds_read_b128
 //                         (lane (r=l&15, g=l>>4) reads k = 4g..4g+3; A and B use the same
 //                         k permutation, so the products pair up correctly)
 //   row-contiguous source: s[k][rows+4] -> fragment = 4 ds_read_b32 (stride%8==4: conflict-free)
@@ -63,28 +64,36 @@ struct TileStage {
   static constexpr int CH = ROWS * CPR;
   static constexpr int PER = (CH + NT - 1) / NT;
   float4 v[PER];
+  // Branch-free staging: every lane ALWAYS issues its loads (out-of-range chunks read a clamped, valid
+  // address and are zeroed afterwards).  A guarded `if (ok) t = load` makes hipcc branch around each load
+  // and wait vmcnt(0) per element -- one serialized L2 round trip per chunk (cdna_hip_programming.md 5,
+  // trap (c)); measured here as ~3.7 us per 64-wide slab before this form.
   __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int r0, int c0, int rmax,
                                        int cmax, bool vec, int tid) {
+    if (vec && (cmax & 3) == 0) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      int ch = tid + i * NT;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (CH % NT == 0 || ch < CH) {
-        int r = ch / CPR, c = (ch % CPR) * 4;
-        int gr = r0 + r, gc = c0 + c;
-        if (gr < rmax && gc < cmax) {
-          const float* p = src + (size_t)gr * ld + gc;
-          if (vec && gc + 3 < cmax) {
-            t = *reinterpret_cast<const float4*>(p);
-          } else {
-            t.x = p[0];
-            if (gc + 1 < cmax) t.y = p[1];
-            if (gc + 2 < cmax) t.z = p[2];
-            if (gc + 3 < cmax) t.w = p[3];
-          }
-        }
+      for (int i = 0; i < PER; ++i) {
+        const int ch = tid + i * NT;
+        const int r = ch / CPR, c = (ch % CPR) * 4;
+        const int gr = r0 + r, gc = c0 + c;
+        const bool ok = (CH % NT == 0 || ch < CH) && gr < rmax && gc < cmax;
+        const size_t off = ok ? (size_t)gr * ld + gc : 0;
+        float4 t = *reinterpret_cast<const float4*>(src + off);
+        if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = t;
       }
-      v[i] = t;
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int ch = tid + i * NT;
+        const int r = ch / CPR, c = (ch % CPR) * 4;
+        const int gr = r0 + r, gc = c0 + c;
+        const bool okr = (CH % NT == 0 || ch < CH) && gr < rmax;
+        const size_t base = (size_t)gr * ld + gc;
+        const bool k0 = okr && gc < cmax, k1 = okr && gc + 1 < cmax, k2 = okr && gc + 2 < cmax, k3 = okr && gc + 3 < cmax;
+        const float x0 = src[k0 ? base : 0], x1 = src[k1 ? base + 1 : 0], x2 = src[k2 ? base + 2 : 0], x3 = src[k3 ? base + 3 : 0];
+        v[i] = make_float4(k0 ? x0 : 0.f, k1 ? x1 : 0.f, k2 ? x2 : 0.f, k3 ? x3 : 0.f);
+      }
     }
   }
   __device__ __forceinline__ void store(float* s, int str, int tid) const {
@@ -99,22 +108,30 @@ struct TileStage {
   }
 };
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI>
+template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
 struct GemmCfg {
-  static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 16, NT = WM * WN * 64;
+  static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = BK_, NT = WM * WN * 64;
   static constexpr int SA_STR = AKM ? BM + 4 : BK + 4, SA_ROWS = AKM ? BK : BM;
   static constexpr int SB_STR = BKM ? BN + 4 : BK + 4, SB_ROWS = BKM ? BK : BN;
   static constexpr int SA_SZ = SA_ROWS * SA_STR, SB_SZ = SB_ROWS * SB_STR;
   static constexpr bool ROW = (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD);
   static constexpr int CSTR = BN + 4;
+  static constexpr int NG = WM * WN * 4;                       // 16-lane row groups per workgroup
   static constexpr int MAIN_SZ = 2 * (SA_SZ + SB_SZ);
-  static constexpr int EPI_SZ = ROW ? BM * CSTR : 0;
+  // row epilogue: BM x CSTR staging; LN backward re-uses it for the [NG][CSTR] x 2 dgamma/dbeta partials
+  static constexpr int EPI_ROWS = EPI == EPI_RES_LNBWD ? (BM > 2 * NG ? BM : 2 * NG) : BM;
+  static constexpr int EPI_SZ = ROW ? EPI_ROWS * CSTR : 0;
   static constexpr int SMEM = MAIN_SZ > EPI_SZ ? MAIN_SZ : EPI_SZ;
 };
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI>
+__device__ static inline float gt_red16(float v) {
+  v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+  return v;
+}
+
+template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
-  typedef GemmCfg<WM, WN, TM, TN, AKM, BKM, EPI> Cfg;
+  typedef GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI> Cfg;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::NT;
   constexpr int SA_STR = Cfg::SA_STR, SB_STR = Cfg::SB_STR, SA_SZ = Cfg::SA_SZ, SB_SZ = Cfg::SB_SZ;
   __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM];
@@ -159,40 +176,46 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     const float* sA = smem + cur * SA_SZ;
     const float* sB = smem + 2 * SA_SZ + cur * SB_SZ;
     if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+    const int klen = kend - (kbeg + kt * BK);        // valid k in this slab (tail slabs skip zero work)
 
-    float af[TM][4], bf[TN][4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row = (wm * TM + i) * 16 + l16;
-      if (!AKM) {
-        float4 t = *reinterpret_cast<const float4*>(&sA[row * SA_STR + 4 * lg]);
-        af[i][0] = t.x; af[i][1] = t.y; af[i][2] = t.z; af[i][3] = t.w;
-      } else {
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      if (kk * 16 < klen) {
+        float af[TM][4], bf[TN][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) af[i][j] = sA[(4 * lg + j) * SA_STR + row];
+        for (int i = 0; i < TM; ++i) {
+          const int row = (wm * TM + i) * 16 + l16;
+          if (!AKM) {
+            float4 t = *reinterpret_cast<const float4*>(&sA[row * SA_STR + kk * 16 + 4 * lg]);
+            af[i][0] = t.x; af[i][1] = t.y; af[i][2] = t.z; af[i][3] = t.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[i][j] = sA[(kk * 16 + 4 * lg + j) * SA_STR + row];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int col = (wn * TN + i) * 16 + l16;
+          if (!BKM) {
+            float4 t = *reinterpret_cast<const float4*>(&sB[col * SB_STR + kk * 16 + 4 * lg]);
+            bf[i][0] = t.x; bf[i][1] = t.y; bf[i][2] = t.z; bf[i][3] = t.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[i][j] = sB[(kk * 16 + 4 * lg + j) * SB_STR + col];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = GT_MFMA16(af[a][j], bf[b][j], acc[a][b]);
       }
     }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int col = (wn * TN + i) * 16 + l16;
-      if (!BKM) {
-        float4 t = *reinterpret_cast<const float4*>(&sB[col * SB_STR + 4 * lg]);
-        bf[i][0] = t.x; bf[i][1] = t.y; bf[i][2] = t.z; bf[i][3] = t.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[i][j] = sB[(4 * lg + j) * SB_STR + col];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = GT_MFMA16(af[a][j], bf[b][j], acc[a][b]);
 
     if (EPI == EPI_ATOMIC && AKM) {
       if (g.dbias != nullptr && blockIdx.x == 0 && tid < BM) {
-#pragma unroll
+#pragma unroll 8
         for (int kk = 0; kk < BK; ++kk) bsum += sA[kk * SA_STR + tid];
       }
     }
@@ -252,8 +275,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     return;
   }
 
-  // Row epilogues: stage the BM x N block in LDS (the main loop's final barrier has passed).
-  constexpr int CSTR = Cfg::CSTR;
+  // Row epilogues: stage the BM x N block in LDS (the main loop's final barrier has passed), then
+  // every 16-lane group owns one row at a time: LayerNorm statistics are 16-lane xor-shuffle sums.
+  constexpr int CSTR = Cfg::CSTR, NG = Cfg::NG;
   float* sC = smem;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -278,61 +302,88 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
       }
   __syncthreads();
 
-  constexpr int NW = WM * WN;
-  constexpr int CPL = (BN + 63) / 64;     // columns per lane
+  constexpr int CPL = BN / 16;            // columns per lane of a 16-lane row group
+  const int grp = wave * 4 + lg;
   const float invN = 1.0f / (float)g.N;
-  float dg[CPL], db[CPL];
+  float dg[EPI == EPI_RES_LNBWD ? CPL : 1], db[EPI == EPI_RES_LNBWD ? CPL : 1];
+  if (EPI == EPI_RES_LNBWD) {
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int i = 0; i < CPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+  }
 
-  for (int rl = wave; rl < BM; rl += NW) {
+  for (int rl = grp; rl < BM; rl += NG) {           // BM % NG == 0: the trip count is wave-uniform
     const int row = m0 + rl;
-    if (row >= g.M) break;                 // wave-uniform
+    const bool live = row < g.M;
     const float* zr = sC + rl * CSTR;
     if (EPI == EPI_RES_LN) {
       float s = 0.f;
-      for (int c = lane; c < g.N; c += 64) s += zr[c];
-      const float mean = gt_wave_sum(s) * invN;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) { const int c = l16 + 16 * i; if (c < g.N) s += zr[c]; }
+      const float mean = gt_red16(s) * invN;
       float q = 0.f;
-      for (int c = lane; c < g.N; c += 64) { float d = zr[c] - mean; q += d * d; }
-      const float rstd = 1.0f / sqrtf(gt_wave_sum(q) * invN + GT_LN_EPS);
-      for (int c = lane; c < g.N; c += 64) {
-        const float xh = (zr[c] - mean) * rstd;
-        g.aux[(size_t)row * g.N + c] = xh;
-        g.C[(size_t)row * g.ldc + c] = xh * g.gamma[c] + g.beta[c];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) { const int c = l16 + 16 * i; if (c < g.N) { const float d = zr[c] - mean; q += d * d; } }
+      const float rstd = 1.0f / sqrtf(gt_red16(q) * invN + GT_LN_EPS);
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int c = l16 + 16 * i;
+          if (c < g.N) {
+            const float xh = (zr[c] - mean) * rstd;
+            g.aux[(size_t)row * g.N + c] = xh;
+            g.C[(size_t)row * g.ldc + c] = xh * g.gamma[c] + g.beta[c];
+          }
+        }
+        if (l16 == 0) g.aux2[row] = rstd;
       }
-      if (lane == 0) g.aux2[row] = rstd;
     } else {
       float s1 = 0.f, s2 = 0.f;
+      float xh[CPL];
 #pragma unroll
       for (int i = 0; i < CPL; ++i) {
-        const int c = lane + 64 * i;
-        if (c < g.N) {
-          const float dy = zr[c], xh = g.xhat[(size_t)row * g.N + c];
+        const int c = l16 + 16 * i;
+        xh[i] = 0.f;
+        if (live && c < g.N) {
+          const float dy = zr[c];
+          xh[i] = g.xhat[(size_t)row * g.N + c];
           const float gdy = dy * g.gamma[c];
-          s1 += gdy; s2 += gdy * xh;
-          dg[i] += dy * xh; db[i] += dy;
+          s1 += gdy; s2 += gdy * xh[i];
+          dg[i] += dy * xh[i]; db[i] += dy;
         }
       }
-      const float m1 = gt_wave_sum(s1) * invN, m2 = gt_wave_sum(s2) * invN;
-      const float rs = g.rstd[row];
+      const float m1 = gt_red16(s1) * invN, m2 = gt_red16(s2) * invN;
+      if (live) {
+        const float rs = g.rstd[row];
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int c = lane + 64 * i;
-        if (c < g.N) {
-          const float xh = g.xhat[(size_t)row * g.N + c];
-          const float dz = rs * (zr[c] * g.gamma[c] - m1 - xh * m2);
-          g.C[(size_t)row * g.ldc + c] = dz;
-          if (g.C2) g.C2[(size_t)row * g.ldc + c] = dz * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + c));
+        for (int i = 0; i < CPL; ++i) {
+          const int c = l16 + 16 * i;
+          if (c < g.N) {
+            const float dz = rs * (zr[c] * g.gamma[c] - m1 - xh[i] * m2);
+            g.C[(size_t)row * g.ldc + c] = dz;
+            if (g.C2) g.C2[(size_t)row * g.ldc + c] = dz * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + c));
+          }
         }
       }
     }
   }
   if (EPI == EPI_RES_LNBWD) {
+    // dgamma/dbeta: reduce the NG row groups through LDS, then ONE atomic per column per workgroup
+    __syncthreads();
+    float* sG = smem;
+    float* sBt = smem + NG * CSTR;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
-      const int c = lane + 64 * i;
-      if (c < g.N) { atomicAdd(&g.dgamma[c], dg[i]); atomicAdd(&g.dbeta[c], db[i]); }
+      const int c = l16 + 16 * i;
+      sG[grp * CSTR + c] = dg[i];
+      sBt[grp * CSTR + c] = db[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < g.N; c += NT) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) { a += sG[q * CSTR + c]; b += sBt[q * CSTR + c]; }
+      atomicAdd(&g.dgamma[c], a);
+      atomicAdd(&g.dbeta[c], b);
     }
   }
 }
@@ -345,47 +396,63 @@ static inline const char* gemm_label() {
        : EPI == EPI_MASK_NZ ? "gemm_dgrad_ffn2" : EPI == EPI_ADD_RELUMASK_DROP ? "gemm_dgrad_input"
        : BKM ? "gemm_dgrad" : "gemm_fwd_bias";
 }
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI>
+template <int WM, int WN, int TM, int TN, int BK, bool AKM, bool BKM, int EPI>
 static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s) {
-  typedef GemmCfg<WM, WN, TM, TN, AKM, BKM, EPI> Cfg;
+  typedef GemmCfg<WM, WN, TM, TN, BK, AKM, BKM, EPI> Cfg;
+  static_assert(!Cfg::ROW || (Cfg::BM % Cfg::NG) == 0, "row epilogue: BM must be a multiple of the row-group count");
   gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
   dim3 grid((g.N + Cfg::BN - 1) / Cfg::BN, (g.M + Cfg::BM - 1) / Cfg::BM, splitk);
-  gt_launch(gemm_kernel<WM, WN, TM, TN, AKM, BKM, EPI>, grid, dim3(Cfg::NT), s, g);
+  gt_launch(gemm_kernel<WM, WN, TM, TN, BK, AKM, BKM, EPI>, grid, dim3(Cfg::NT), s, g);
 }
 
 // standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
 template <bool AKM, bool BKM, int EPI>
 static inline void gemm_launch(GemmArgs g, hipStream_t s) {
-  int splitk = 1;
-  g.k_chunk = (g.K + 15) / 16 * 16;
-  const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  g.k_chunk = (g.K + 63) / 64 * 64;
   if (EPI == EPI_ATOMIC) {
-    // wgrad: output is small (N_w x K_w), the contraction (tokens) is long -> split it over z
+    // wgrad: the output (N_w x K_w) is small, the contraction (tokens) is long -> split it over z
     const long tiles = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
     long want = (1024 + tiles - 1) / tiles;
-    long maxs = (g.K + 63) / 64;
+    const long maxs = (g.K + 127) / 128;
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     int chunk = (int)((g.K + want - 1) / want);
-    chunk = (chunk + 15) / 16 * 16;
-    splitk = (g.K + chunk - 1) / chunk;
+    chunk = (chunk + 63) / 64 * 64;
     g.k_chunk = chunk;
-    gemm_launch_cfg<2, 2, 1, 1, AKM, BKM, EPI>(g, splitk, s);
+    gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, (g.K + chunk - 1) / chunk, s);
     return;
   }
-  if (t64 >= 512) gemm_launch_cfg<2, 2, 2, 2, AKM, BKM, EPI>(g, splitk, s);
-  else            gemm_launch_cfg<2, 2, 1, 1, AKM, BKM, EPI>(g, splitk, s);
+  const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  if (t64 >= 256) gemm_launch_cfg<2, 2, 2, 2, 64, AKM, BKM, EPI>(g, 1, s);
+  else            gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
 }
 
-// row epilogues: BN = padded d_model, BM = 32
+// row epilogues: BN = padded d_model; 16-row tiles while they still give <= 1024 workgroups, else 32
 template <bool AKM, bool BKM, int EPI>
 static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
-  g.k_chunk = (g.K + 15) / 16 * 16;
-  if (g.N <= 32)       gemm_launch_cfg<2, 2, 1, 1, AKM, BKM, EPI>(g, 1, s);
-  else if (g.N <= 64)  gemm_launch_cfg<2, 2, 1, 2, AKM, BKM, EPI>(g, 1, s);
-  else if (g.N <= 128) gemm_launch_cfg<2, 2, 1, 4, AKM, BKM, EPI>(g, 1, s);
-  else if (g.N <= 256) gemm_launch_cfg<1, 4, 2, 4, AKM, BKM, EPI>(g, 1, s);
-  else if (g.N <= 512) gemm_launch_cfg<1, 4, 2, 8, AKM, BKM, EPI>(g, 1, s);
-  else return -1;
+  const bool small = g.M <= 16384;
+  if (g.N <= 32) {
+    g.k_chunk = (g.K + 63) / 64 * 64;
+    if (small) gemm_launch_cfg<1, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
+    else       gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
+  } else if (g.N <= 64) {
+    g.k_chunk = (g.K + 63) / 64 * 64;
+    if (small) gemm_launch_cfg<1, 4, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
+    else       gemm_launch_cfg<2, 2, 1, 2, 64, AKM, BKM, EPI>(g, 1, s);
+  } else if (g.N <= 128) {
+    g.k_chunk = (g.K + 63) / 64 * 64;
+    if (small) gemm_launch_cfg<1, 4, 1, 2, 64, AKM, BKM, EPI>(g, 1, s);
+    else       gemm_launch_cfg<2, 2, 1, 4, 64, AKM, BKM, EPI>(g, 1, s);
+  } else if (g.N <= 256) {
+    g.k_chunk = (g.K + 31) / 32 * 32;
+    if (small) gemm_launch_cfg<1, 4, 1, 4, 32, AKM, BKM, EPI>(g, 1, s);
+    else       gemm_launch_cfg<1, 4, 2, 4, 32, AKM, BKM, EPI>(g, 1, s);
+  } else if (g.N <= 512) {
+    g.k_chunk = (g.K + 15) / 16 * 16;
+    if (small) gemm_launch_cfg<1, 4, 1, 8, 16, AKM, BKM, EPI>(g, 1, s);
+    else       gemm_launch_cfg<1, 4, 2, 8, 16, AKM, BKM, EPI>(g, 1, s);
+  } else {
+    return -1;
+  }
   return 0;
 }
