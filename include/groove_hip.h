@@ -53,8 +53,8 @@ typedef struct gt_config {
  * Adam bias correction and learning rate without host-side kernel-argument changes */
 typedef struct gt_step_state {
   uint32_t seed_lo, seed_hi;   /* dropout RNG seed */
-  uint32_t step;               /* incremented by gt_optimizer_step (dropout stream id, Adam t-1) */
-  uint32_t pad;
+  uint32_t step;               /* dropout stream id; incremented by gt_optimizer_step (a host may overwrite it) */
+  uint32_t opt_step;           /* optimizer updates applied so far (Adam t-1); incremented by gt_optimizer_step */
   float lr;                    /* ref:train.py:136 learning_rate */
   float grad_scale;            /* 1/world_size for data-parallel averaging, else 1 */
   float beta1, beta2, eps;     /* Adam (torch defaults 0.9 / 0.999 / 1e-8) */

@@ -1,0 +1,72 @@
+"""Data-parallel path on CPU: world_size 2 over gloo.  Each rank runs forward+loss+backward of ITS shard through the
+C ABI (host-emulator build of the kernels), gradients are summed with ONE all-reduce of the flat buffer and
+averaged by grad_scale in the optimizer kernel -> identical replicas that match a single process on the full batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from harness import Runner, cfg_dict
+    from oracle import numpy_groove as ng
+    from transformergrooveinfilling_amd import parallel
+    r_, l_, w_ = parallel.init_distributed("gloo")
+    assert (r_, w_) == (rank, world)
+    cfg = cfg_dict(32, 4, 16, 2)
+    B = 4
+    P = ng.init_params(cfg, seed=5 + rank, perturb=0.05)                   # deliberately different per rank ...
+    x, y = ng.synthetic_batch(B, 16, seed=9)
+    run = Runner(cfg, B // world, "emu", lr=0.05)
+    run.set_params(P)
+    flat = torch.from_numpy(run.params.numpy())                            # shares memory with the runner's buffer
+    parallel.broadcast_parameters(flat, src=0)                             # ... then made identical
+    sl = slice(rank * (B // world), (rank + 1) * (B // world))
+    run.train_step(x[sl], y[sl], 0.47, algo=0, skip_update=True)
+    g = torch.from_numpy(run.grads.numpy())
+    parallel.allreduce_gradients(g)                                        # ONE collective, SUM
+    st = run.step_state()
+    st.grad_scale = 1.0 / world
+    run.state.numpy()[:] = np.frombuffer(bytes(st), dtype=np.uint8)
+    new = run.optimizer_step(0)
+    torch.save({"params": new, "rank": rank}, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_matches_single_process(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "rank%d.pt")
+    mp.start_processes(_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from harness import Runner, cfg_dict
+    from oracle import numpy_groove as ng
+    a = torch.load(out % 0, weights_only=False)["params"]
+    b = torch.load(out % 1, weights_only=False)["params"]
+    cfg = cfg_dict(32, 4, 16, 2)
+    P = ng.init_params(cfg, seed=5, perturb=0.05)
+    x, y = ng.synthetic_batch(4, 16, seed=9)
+    single = Runner(cfg, 4, "emu", lr=0.05)
+    single.set_params(P)
+    single.train_step(x, y, 0.47, algo=0)
+    ref = single.unflatten(single.params.numpy())
+    for k in ref:
+        assert np.array_equal(a[k], b[k]), k                                # replicas stay identical
+        assert np.abs(a[k] - ref[k]).max() < 1e-6, k                         # == one process on the whole batch

@@ -1,0 +1,102 @@
+"""Host-side logic that needs no GPU: the train.py CLI / YAML contract, the checkpoint finder, the save
+schedule and the data-parallel sampler."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import train as train_cli
+from transformergrooveinfilling_amd import parallel, training
+
+# hyper-parameters of the reference's shipped YAMLs (ref:configs/*_training.yaml)
+REF_YAMLS = {
+    "InfillingClosedHH_training": dict(experiment="InfillingClosedHH", batch_size=16, d_model=32, dim_feedforward=512, dropout=0.24,
+                                       optimizer_algorithm="sgd", learning_rate=0.07, n_heads=16, num_encoder_decoder_layers=6,
+                                       epochs=400, encoder_only=1, hit_loss_penalty=0.38, load_model=None),
+    "InfillingKicksAndSnares_training": dict(experiment="InfillingKicksAndSnares", batch_size=32, d_model=256, dim_feedforward=512,
+                                             dropout=0.3, optimizer_algorithm="sgd", learning_rate=0.089, n_heads=2,
+                                             num_encoder_decoder_layers=6, epochs=400, encoder_only=1, hit_loss_penalty=0.73, load_model=None),
+    "InfillingClosedHH_Symbolic_training": dict(experiment="InfillingClosedHH_Symbolic", batch_size=16, d_model=32, dim_feedforward=512,
+                                                dropout=0.24, optimizer_algorithm="sgd", learning_rate=0.07, n_heads=16,
+                                                num_encoder_decoder_layers=6, epochs=400, encoder_only=1, hit_loss_penalty=0.38, load_model=None),
+    "InfillingRandom_test_large": dict(experiment="InfillingRandom", batch_size=16, d_model=256, dim_feedforward=64, dropout=0.15,
+                                       optimizer_algorithm="sgd", learning_rate=0.04, n_heads=16, num_encoder_decoder_layers=11,
+                                       epochs=100, encoder_only=1, hit_loss_penalty=1),           # no load_model key
+}
+
+
+@pytest.mark.parametrize("name", sorted(REF_YAMLS))
+def test_reference_yaml_keys_load_unchanged(tmp_path, name):
+    f = tmp_path / (name + ".yaml")
+    f.write_text(yaml.safe_dump(REF_YAMLS[name]))
+    args = train_cli.build_parser().parse_args(["--config", str(f), "--d_model", "999"])      # CLI hparams ignored with --config
+    hp = train_cli.load_hyperparameters(args)
+    assert hp["d_model"] == REF_YAMLS[name]["d_model"] and hp["load_model"] is None
+    p = train_cli.model_params(hp, "cuda")
+    assert p["model"]["max_len"] == 32 and p["model"]["embedding_size_tgt"] == 27
+    assert p["model"]["embedding_size_src"] == (27 if "Symbolic" in name else 16)
+    assert p["model"]["num_decoder_layers"] == 0
+    assert p["training"] == {"learning_rate": hp["learning_rate"], "batch_size": hp["batch_size"], "hit_loss_penalty": hp["hit_loss_penalty"]}
+
+
+def test_cli_without_config_and_overrides(tmp_path):
+    args = train_cli.build_parser().parse_args(["--experiment", "InfillingRandom", "--encoder_only", "0", "--d_model", "128",
+                                                "--testing", "1", "--override", "n_heads=4"])
+    hp = train_cli.load_hyperparameters(args)
+    assert hp["epochs"] == 1 and hp["n_heads"] == 4 and hp["d_model"] == 128
+    p = train_cli.model_params(hp, "cuda")
+    assert p["model"]["num_decoder_layers"] == p["model"]["num_encoder_layers"] == 7
+    with pytest.raises(AssertionError):
+        train_cli.load_hyperparameters(train_cli.build_parser().parse_args([]))                  # experiment not specified
+
+
+def test_save_schedule_matches_reference_rule():
+    part, full = training.save_schedule(400)
+    assert set(range(10)) <= part and {10, 20, 390, 399} <= part and 15 not in part
+    assert {0, 9, 10, 30, 399} <= full and 20 not in full
+    assert training.save_schedule(5) == (set(range(5)), set(range(5)))
+    assert training.save_schedule(100, only_final=True) == ({99}, set())
+
+
+def test_find_checkpoint_latest_epoch(tmp_path):
+    for ep in (0, 3, 12):
+        (tmp_path / training.FILE_PATTERN.format("171tyqit", ep)).write_bytes(b"x")
+    (tmp_path / training.FILE_PATTERN.format("other", 40)).write_bytes(b"x")
+    lm = {"location": "local", "dir": str(tmp_path), "file_pattern": "transformer_run_{}_Epoch_{}.Model", "run": "171tyqit"}
+    assert training.find_checkpoint(lm).endswith("transformer_run_171tyqit_Epoch_12.Model")
+    assert training.find_checkpoint(dict(lm, epoch=3)).endswith("Epoch_3.Model")
+    with pytest.raises(FileNotFoundError):
+        training.find_checkpoint(dict(lm, epoch=7))
+
+
+def test_sharded_sampler_partitions_every_epoch():
+    n, bs, world = 1000, 16, 4
+    seen = []
+    for r in range(world):
+        s = parallel.ShardedBatchSampler(n, bs, r, world, seed=3)
+        s.set_epoch(5)
+        batches = list(s)
+        assert len(batches) == len(s) == (n // world) // bs and all(len(b) == bs for b in batches)
+        seen.append(np.concatenate(batches))
+    allidx = np.concatenate(seen)
+    assert len(np.unique(allidx)) == len(allidx)                     # disjoint shards
+    s0 = parallel.ShardedBatchSampler(n, bs, 0, world, seed=3)
+    s0.set_epoch(6)
+    assert not np.array_equal(np.concatenate(list(s0)), seen[0])     # reshuffled per epoch
+
+
+def test_synthetic_generator_ranges():
+    x, y = train_cli.synthetic_tensors(64, 16, 1)
+    assert x.shape == (64, 32, 16) and y.shape == (64, 32, 27)
+    h, v, o = y[..., :9], y[..., 9:18], y[..., 18:]
+    assert set(h.unique().tolist()) <= {0.0, 1.0} and (v[h == 0] == 0).all() and (o.abs() <= 0.5).all()
+
+
+def test_model_needs_gpu_and_has_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from transformergrooveinfilling_amd.model import GrooveTransformerEncoder
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GrooveTransformerEncoder(d_model=32, nhead=4, num_encoder_layers=1, dim_feedforward=16)

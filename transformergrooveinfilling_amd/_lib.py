@@ -23,7 +23,7 @@ class GtConfig(ctypes.Structure):
 
 class GtStepState(ctypes.Structure):
     _fields_ = [("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32), ("step", ctypes.c_uint32),
-                ("pad", ctypes.c_uint32), ("lr", ctypes.c_float), ("grad_scale", ctypes.c_float),
+                ("opt_step", ctypes.c_uint32), ("lr", ctypes.c_float), ("grad_scale", ctypes.c_float),
                 ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
                 ("pad2", ctypes.c_float * 3)]
 

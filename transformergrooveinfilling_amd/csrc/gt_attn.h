@@ -28,9 +28,8 @@ __device__ static inline void attn_load_slab(float (*s)[33], const float* src, i
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = tid + 256 * u, r = e >> 5, c = e & 31;
-    const bool ok = c0 + c < hd;                       // branch-free: clamped address, select after the load
-    const float val = src[(size_t)(b * 32 + r) * ld + h * hd + (ok ? c0 + c : 0)];
-    s[r][c] = ok ? val : 0.f;
+    const float* p = (c0 + c < hd) ? src + ((size_t)(b * 32 + r) * ld + h * hd + c0 + c) : gt_zero_page;   // branch-free
+    s[r][c] = *p;
   }
 }
 

@@ -18,6 +18,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define GT_LN_EPS 1e-5f
 
+// A 16-byte zero page.  Out-of-range staging loads select THIS ADDRESS instead of zero-selecting the
+// loaded value: a select after the load makes the compiler wait (vmcnt) right behind the load and
+// kills the prefetch/compute overlap; a select before it costs one v_cndmask on the address.
+// Deliberately non-const so the loads cannot be folded back into a value select.
+__device__ __attribute__((aligned(16))) static float gt_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
 // ---- optional per-launch timing (gt_profile_*): HIP events around every launch, by kernel class ----
 // Off by default (zero overhead beyond one branch).  bench.py switches it on for a separate eager pass
 // to measure the dominant kernel's average duration live (events are recorded on the launch stream).

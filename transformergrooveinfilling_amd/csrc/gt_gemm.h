@@ -64,8 +64,7 @@ struct TileStage {
   static constexpr int CH = ROWS * CPR;
   static constexpr int PER = (CH + NT - 1) / NT;
   float4 v[PER];
-  // Branch-free staging: every lane ALWAYS issues its loads (out-of-range chunks read a clamped, valid
-  // address and are zeroed afterwards).  A guarded `if (ok) t = load` makes hipcc branch around each load
+  // Branch-free staging: every lane ALWAYS issues its loads (out-of-range chunks read gt_zero_page).  A guarded `if (ok) t = load` makes hipcc branch around each load
   // and wait vmcnt(0) per element -- one serialized L2 round trip per chunk (cdna_hip_programming.md 5,
   // trap (c)); measured here as ~3.7 us per 64-wide slab before this form.
   __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int r0, int c0, int rmax,
@@ -77,10 +76,8 @@ struct TileStage {
         const int r = ch / CPR, c = (ch % CPR) * 4;
         const int gr = r0 + r, gc = c0 + c;
         const bool ok = (CH % NT == 0 || ch < CH) && gr < rmax && gc < cmax;
-        const size_t off = ok ? (size_t)gr * ld + gc : 0;
-        float4 t = *reinterpret_cast<const float4*>(src + off);
-        if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
-        v[i] = t;
+        const float* p = ok ? src + ((size_t)gr * ld + gc) : gt_zero_page;
+        v[i] = *reinterpret_cast<const float4*>(p);
       }
     } else {
 #pragma unroll
@@ -89,10 +86,12 @@ struct TileStage {
         const int r = ch / CPR, c = (ch % CPR) * 4;
         const int gr = r0 + r, gc = c0 + c;
         const bool okr = (CH % NT == 0 || ch < CH) && gr < rmax;
-        const size_t base = (size_t)gr * ld + gc;
-        const bool k0 = okr && gc < cmax, k1 = okr && gc + 1 < cmax, k2 = okr && gc + 2 < cmax, k3 = okr && gc + 3 < cmax;
-        const float x0 = src[k0 ? base : 0], x1 = src[k1 ? base + 1 : 0], x2 = src[k2 ? base + 2 : 0], x3 = src[k3 ? base + 3 : 0];
-        v[i] = make_float4(k0 ? x0 : 0.f, k1 ? x1 : 0.f, k2 ? x2 : 0.f, k3 ? x3 : 0.f);
+        const float* base = src + ((size_t)gr * ld + gc);
+        const float* p0 = (okr && gc < cmax) ? base : gt_zero_page;
+        const float* p1 = (okr && gc + 1 < cmax) ? base + 1 : gt_zero_page;
+        const float* p2 = (okr && gc + 2 < cmax) ? base + 2 : gt_zero_page;
+        const float* p3 = (okr && gc + 3 < cmax) ? base + 3 : gt_zero_page;
+        v[i] = make_float4(*p0, *p1, *p2, *p3);
       }
     }
   }
@@ -227,11 +226,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
   }
 
   // ------------------------------------------------------------------------------- epilogues
+  // Two-phase everywhere: (1) every global input of the epilogue is loaded UNCONDITIONALLY (address-select
+  // against gt_zero_page for out-of-range elements) into registers, so all loads are in flight together;
+  // (2) compute + predicated stores.  Guarded per-element loads would serialise one L2 round trip each.
   const uint32_t dkey = gt_drop_key(g.drop);
+  auto ldg = [](const float* p, size_t idx, bool ok) -> float { return *(ok ? p + idx : gt_zero_page); };
 
   if (!Cfg::ROW) {
     if (EPI == EPI_ATOMIC && AKM) {
       if (g.dbias != nullptr && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) atomicAdd(&g.dbias[m0 + tid], bsum);
+    }
+    constexpr bool NEED_R1 = (EPI == EPI_STORE || EPI == EPI_RELU_PE || EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP);
+    constexpr bool NEED_R2 = (EPI == EPI_ADD_RELUMASK_DROP);
+    constexpr bool NEED_BIAS = (EPI == EPI_STORE || EPI == EPI_RELU_PE || EPI == EPI_RELU_DROP || EPI == EPI_HEADS);
+    float bia[TN], r1[NEED_R1 ? TM : 1][NEED_R1 ? TN : 1][4], r2[NEED_R2 ? TM : 1][NEED_R2 ? TN : 1][4];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + (wn * TN + b) * 16 + l16;
+      bia[b] = NEED_BIAS ? ldg(g.bias, col, g.bias != nullptr && col < g.N) : 0.f;
+    }
+    if (NEED_R1) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + (wm * TM + a) * 16 + 4 * lg + r;
+            const int col = n0 + (wn * TN + b) * 16 + l16;
+            const bool ok = row < g.M && col < g.N;
+            if (EPI == EPI_STORE) r1[a][b][r] = ldg(g.C, (size_t)row * g.ldc + col, ok && g.accumulate);
+            else if (EPI == EPI_RELU_PE) r1[a][b][r] = ldg(g.pe, (size_t)(row & 31) * g.N + col, ok);
+            else r1[a][b][r] = ldg(g.res, (size_t)row * g.ldres + col, ok);
+            if (NEED_R2) r2[a][b][r] = ldg(g.aux_in, (size_t)row * g.N + col, ok);
+          }
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -245,38 +273,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
             float v = acc[a][b][r];
             const size_t ci = (size_t)row * g.ldc + col;
             if (EPI == EPI_STORE) {
-              if (g.bias) v += g.bias[col];
-              if (g.accumulate) v += g.C[ci];
-              g.C[ci] = v;
+              g.C[ci] = v + bia[b] + r1[a][b][r];
             } else if (EPI == EPI_ATOMIC) {
               atomicAdd(&g.C[ci], v);
             } else if (EPI == EPI_RELU_PE) {
-              v += g.bias[col];
+              v += bia[b];
               g.aux[(size_t)row * g.N + col] = v;
-              v = fmaxf(v, 0.f) + g.pe[(row & 31) * g.N + col];
+              v = fmaxf(v, 0.f) + r1[a][b][r];
               g.C[ci] = v * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
             } else if (EPI == EPI_RELU_DROP) {
-              v = fmaxf(v + g.bias[col], 0.f);
+              v = fmaxf(v + bia[b], 0.f);
               g.C[ci] = v * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
             } else if (EPI == EPI_HEADS) {
-              v += g.bias[col];
+              v += bia[b];
               if (col >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
               else if (col >= GT_VOICES) v = gt_sigmoid(v);
               g.C[ci] = v;
             } else if (EPI == EPI_MASK_NZ) {
-              g.C[ci] = (g.res[(size_t)row * g.ldres + col] != 0.f) ? v * g.mask_scale : 0.f;
+              g.C[ci] = (r1[a][b][r] != 0.f) ? v * g.mask_scale : 0.f;
             } else if (EPI == EPI_ADD_RELUMASK_DROP) {
-              v += g.res[(size_t)row * g.ldres + col];
+              v += r1[a][b][r];
               v *= gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
-              g.C[ci] = (g.aux_in[(size_t)row * g.N + col] > 0.f) ? v : 0.f;
+              g.C[ci] = (r2[a][b][r] > 0.f) ? v : 0.f;
             }
           }
         }
     return;
   }
 
-  // Row epilogues: stage the BM x N block in LDS (the main loop's final barrier has passed), then
-  // every 16-lane group owns one row at a time: LayerNorm statistics are 16-lane xor-shuffle sums.
+  // Row epilogues: stage the raw BM x BN accumulators in LDS (the main loop's final barrier has passed),
+  // then every 16-lane group owns one row at a time: lane l16 holds columns l16 + 16 i in registers and the
+  // LayerNorm statistics are 16-lane xor-shuffle sums.
   constexpr int CSTR = Cfg::CSTR, NG = Cfg::NG;
   float* sC = smem;
 #pragma unroll
@@ -284,22 +311,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rl = (wm * TM + a) * 16 + 4 * lg + r;
-        const int cl = (wn * TN + b) * 16 + l16;
-        const int row = m0 + rl;
-        float v = acc[a][b][r];
-        if (row < g.M && cl < g.N) {
-          if (EPI == EPI_RES_LN) {
-            v += g.bias[cl];
-            v *= gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + cl));
-            v += g.res[(size_t)row * g.ldres + cl];
-          } else {
-            if (g.res) v += g.res[(size_t)row * g.ldres + cl];
-          }
-        }
-        sC[rl * CSTR + cl] = v;
-      }
+      for (int r = 0; r < 4; ++r)
+        sC[((wm * TM + a) * 16 + 4 * lg + r) * CSTR + (wn * TN + b) * 16 + l16] = acc[a][b][r];
   __syncthreads();
 
   constexpr int CPL = BN / 16;            // columns per lane of a 16-lane row group
@@ -314,51 +327,73 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
   for (int rl = grp; rl < BM; rl += NG) {           // BM % NG == 0: the trip count is wave-uniform
     const int row = m0 + rl;
     const bool live = row < g.M;
+    const size_t rowc = live ? row : 0;               // clamped row for the unconditional loads
     const float* zr = sC + rl * CSTR;
+    float z[CPL], e1[CPL], e2[CPL], e3[CPL];
     if (EPI == EPI_RES_LN) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {                 // phase 1: all loads
+        const int c = l16 + 16 * i;
+        const bool okc = c < g.N;
+        z[i] = zr[c];
+        e1[i] = ldg(g.bias, c, okc);
+        e2[i] = ldg(g.res, rowc * g.ldres + c, okc);
+        e3[i] = ldg(g.gamma, c, okc);
+      }
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) { const int c = l16 + 16 * i; if (c < g.N) s += zr[c]; }
+      for (int i = 0; i < CPL; ++i) {
+        const int c = l16 + 16 * i;
+        z[i] = (c < g.N) ? (z[i] + e1[i]) * gt_drop_mul(g.drop, dkey, (uint32_t)(rowc * g.N + c)) + e2[i] : 0.f;
+        s += z[i];
+      }
       const float mean = gt_red16(s) * invN;
       float q = 0.f;
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) { const int c = l16 + 16 * i; if (c < g.N) { const float d = zr[c] - mean; q += d * d; } }
+      for (int i = 0; i < CPL; ++i) { const int c = l16 + 16 * i; if (c < g.N) { const float d = z[i] - mean; q += d * d; } }
       const float rstd = 1.0f / sqrtf(gt_red16(q) * invN + GT_LN_EPS);
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) e1[i] = ldg(g.beta, l16 + 16 * i, l16 + 16 * i < g.N);
       if (live) {
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
           const int c = l16 + 16 * i;
           if (c < g.N) {
-            const float xh = (zr[c] - mean) * rstd;
+            const float xh = (z[i] - mean) * rstd;
             g.aux[(size_t)row * g.N + c] = xh;
-            g.C[(size_t)row * g.ldc + c] = xh * g.gamma[c] + g.beta[c];
+            g.C[(size_t)row * g.ldc + c] = xh * e3[i] + e1[i];
           }
         }
         if (l16 == 0) g.aux2[row] = rstd;
       }
     } else {
+      const float rs = g.rstd[rowc];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {                 // phase 1: all loads
+        const int c = l16 + 16 * i;
+        const bool okc = live && c < g.N;
+        z[i] = zr[c];
+        e1[i] = ldg(g.res, rowc * g.ldres + c, okc && g.res != nullptr);
+        e2[i] = ldg(g.xhat, rowc * g.N + c, okc);
+        e3[i] = ldg(g.gamma, c, okc);
+      }
       float s1 = 0.f, s2 = 0.f;
-      float xh[CPL];
 #pragma unroll
       for (int i = 0; i < CPL; ++i) {
         const int c = l16 + 16 * i;
-        xh[i] = 0.f;
-        if (live && c < g.N) {
-          const float dy = zr[c];
-          xh[i] = g.xhat[(size_t)row * g.N + c];
-          const float gdy = dy * g.gamma[c];
-          s1 += gdy; s2 += gdy * xh[i];
-          dg[i] += dy * xh[i]; db[i] += dy;
-        }
+        const float dy = (live && c < g.N) ? z[i] + e1[i] : 0.f;
+        z[i] = dy;
+        const float gdy = dy * e3[i];
+        s1 += gdy; s2 += gdy * e2[i];
+        dg[i] += dy * e2[i]; db[i] += dy;
       }
       const float m1 = gt_red16(s1) * invN, m2 = gt_red16(s2) * invN;
       if (live) {
-        const float rs = g.rstd[row];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
           const int c = l16 + 16 * i;
           if (c < g.N) {
-            const float dz = rs * (zr[c] * g.gamma[c] - m1 - xh[i] * m2);
+            const float dz = rs * (z[i] * e3[i] - m1 - e2[i] * m2);
             g.C[(size_t)row * g.ldc + c] = dz;
             if (g.C2) g.C2[(size_t)row * g.ldc + c] = dz * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + c));
           }

@@ -43,14 +43,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int rr = 0; rr < GT_LNB_ROWS; ++rr) {
     const int row = row0 + rr;
     if (row >= M) break;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, d[GT_MAX_D / 64], xh[GT_MAX_D / 64], ga[GT_MAX_D / 64];
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {          // all loads first, branch-free (address select)
+      const int c = lane + 64 * i;
+      const bool ok = c < N;
+      d[i] = *(ok ? dy + (size_t)row * N + c : gt_zero_page);
+      xh[i] = *(ok ? xhat + (size_t)row * N + c : gt_zero_page);
+      ga[i] = *(ok ? gamma + c : gt_zero_page);
+    }
 #pragma unroll
     for (int i = 0; i < GT_MAX_D / 64; ++i) {
-      const int c = lane + 64 * i;
-      if (c < N) {
-        const float d = dy[(size_t)row * N + c], xh = xhat[(size_t)row * N + c], gd = d * gamma[c];
-        s1 += gd; s2 += gd * xh; dg[i] += d * xh; db[i] += d;
-      }
+      const float gd = d[i] * ga[i];
+      s1 += gd; s2 += gd * xh[i]; dg[i] += d[i] * xh[i]; db[i] += d[i];
     }
     const float m1 = gt_wave_sum(s1) * invN, m2 = gt_wave_sum(s2) * invN, rs = rstd[row];
 #pragma unroll
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       const int c = lane + 64 * i;
       if (c < N) {
         const size_t e = (size_t)row * N + c;
-        const float v = rs * (dy[e] * gamma[c] - m1 - xhat[e] * m2);
+        const float v = rs * (d[i] * ga[i] - m1 - xh[i] * m2);
         dz[e] = v;
         if (dz_masked) dz_masked[e] = v * gt_drop_mul(drop, dkey, (uint32_t)e);
       }
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const gt_step_state* __restrict__ st) {
-  const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->step + 1u);
+  const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->opt_step + 1u);
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = st->lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
   const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 __global__ void step_inc_kernel(gt_step_state* st) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) st->step += 1u;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1u; st->opt_step += 1u; }
 }
 
 // teacher forcing: tgt_in[b,t] = y[b,t-1], row 0 = zeros

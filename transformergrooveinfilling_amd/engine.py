@@ -2,10 +2,10 @@
 
 Everything a train step touches lives in HBM for the life of the engine: ONE flat fp32 parameter
 buffer (state-dict order, gt_param_layout), one flat gradient buffer of the same layout (a single RCCL
-all-reduce and a single fused optimizer launch), optimizer moments, the activation workspace, the
-positional-encoding buffer, the 48-byte device step state (dropout seed/step, lr, Adam betas) and
-static input/output buffers.  A whole step (forward, loss, backward, update) is one call into
-libgroove_hip.so and is captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed.
+all-reduce and a single fused optimizer launch), optimizer moments, the positional-encoding buffer and
+the 48-byte device step state (dropout seed/step, lr, Adam betas).  Per batch size there is a "slot":
+activation workspace, static input/output buffers and the captured hipGraph of the whole step
+(forward, loss, backward, update = one call into libgroove_hip.so, captured once, replayed).
 
 Replaces, for the hot path only, the body of the reference's train_loop batch iteration
 (ref:train.py:195-215: zero_grad / forward / calculate_loss / backward / opt.step) and
@@ -26,55 +26,80 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _Slot:
+    """Buffers and captured graph for one batch size."""
+
+    def __init__(self, eng, B):
+        f32 = dict(dtype=torch.float32, device=eng.device)
+        d = eng.dims
+        self.B = B
+        self.cfg = _lib.make_config(B, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
+                                    d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"])
+        self.ws = torch.empty(eng.lib.workspace_floats(self.cfg), **f32)
+        self.x = torch.zeros(B, 32, d["embedding_size_src"], **f32)
+        self.y = torch.zeros(B, 32, 27, **f32)
+        self.hvo = torch.zeros(B, 32, 27, **f32)
+        self.tgt = torch.zeros(B, 32, 27, **f32)
+        self.stats = torch.zeros(8, **f32)
+        self.graph = None
+        self.graph_key = None
+
+
 class StepEngine:
     def __init__(self, d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_layers=0,
-                 dropout=0.0, embedding_size_src=16, batch_size=64, optimizer="sgd", learning_rate=0.05,
+                 dropout=0.0, embedding_size_src=16, batch_size=None, optimizer="sgd", learning_rate=0.05,
                  hit_loss_penalty=1.0, seed=0, device="cuda", world_size=1, use_graph=True, lib=None):
         if not torch.cuda.is_available():
             raise RuntimeError("StepEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback for the hot path")
         self.lib = lib or _lib.get_lib()
         self.device = torch.device(device)
-        self.B, self.M = int(batch_size), int(batch_size) * 32
-        self.S = int(embedding_size_src)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.encoder_only = num_decoder_layers == 0
         self.algo = ALGO[optimizer.lower()]
         self.penalty = float(hit_loss_penalty)
         self.world_size = int(world_size)
         self.use_graph = use_graph
-        self.dims = dict(d_model=d_model, n_heads=n_heads, dim_feedforward=dim_feedforward,
-                         num_encoder_layers=num_encoder_layers, num_decoder_layers=num_decoder_layers,
-                         dropout=dropout, embedding_size_src=embedding_size_src)
-        self.cfg = _lib.make_config(self.B, self.S, d_model, n_heads, dim_feedforward, num_encoder_layers,
-                                    num_decoder_layers, dropout)
-        self.total, self.entries = self.lib.param_layout(self.cfg)
-        self.names = layout.param_names(d_model, dim_feedforward, self.S, num_encoder_layers, num_decoder_layers)
+        self.dims = dict(d_model=int(d_model), n_heads=int(n_heads), dim_feedforward=int(dim_feedforward),
+                         num_encoder_layers=int(num_encoder_layers), num_decoder_layers=int(num_decoder_layers),
+                         dropout=float(dropout), embedding_size_src=int(embedding_size_src))
+        probe = _lib.make_config(1, embedding_size_src, d_model, n_heads, dim_feedforward, num_encoder_layers,
+                                 num_decoder_layers, dropout)
+        self.total, self.entries = self.lib.param_layout(probe)
+        self.names = layout.param_names(d_model, dim_feedforward, embedding_size_src, num_encoder_layers, num_decoder_layers)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(self.total, **f32)
         self.grads = torch.zeros(self.total, **f32)
         self.m = torch.zeros(self.total, **f32) if self.algo == 1 else None
         self.v = torch.zeros(self.total, **f32) if self.algo == 1 else None
         self.pe = torch.from_numpy(layout.positional_encoding(d_model)).to(self.device)
-        self.x = torch.zeros(self.B, 32, self.S, **f32)
-        self.y = torch.zeros(self.B, 32, 27, **f32)
-        self.hvo = torch.zeros(self.B, 32, 27, **f32)
-        self.tgt = torch.zeros(self.B, 32, 27, **f32)
-        self.stats = torch.zeros(8, **f32)
-        self._ws = {}            # batch -> workspace (predict may run other batch sizes)
-        self.ws = self._workspace(self.cfg)
         st = _lib.GtStepState(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, 0, 0, learning_rate,
                               1.0 / self.world_size, 0.9, 0.999, 1e-8)
         self.state = torch.from_numpy(np.frombuffer(bytes(st), dtype=np.uint8).copy()).to(self.device)
-        self._graph = None
-        self._graph_key = None
+        self._slots = {}
+        self.B = int(batch_size) if batch_size else None
+        if self.B:
+            self.slot(self.B)
 
     # ---- buffers ---------------------------------------------------------------------------------
-    def _workspace(self, cfg):
-        n = self.lib.workspace_floats(cfg)
-        key = cfg.batch
-        if key not in self._ws or self._ws[key].numel() < n:
-            self._ws[key] = torch.empty(n, dtype=torch.float32, device=self.device)
-        return self._ws[key]
+    def slot(self, B):
+        B = int(B)
+        if B not in self._slots:
+            self._slots[B] = _Slot(self, B)
+        return self._slots[B]
+
+    # convenience views of the default slot (bench / tests)
+    x = property(lambda self: self.slot(self.B).x)
+    y = property(lambda self: self.slot(self.B).y)
+    hvo = property(lambda self: self.slot(self.B).hvo)
+    stats = property(lambda self: self.slot(self.B).stats)
+    cfg = property(lambda self: self.slot(self.B).cfg)
+
+    def ensure_adam(self):
+        if self.m is None:
+            self.m = torch.zeros_like(self.params)
+            self.v = torch.zeros_like(self.params)
 
     def views(self, flat=None):
         """name -> view into the flat parameter (or gradient/moment) buffer, state-dict order."""
@@ -89,7 +114,8 @@ class StepEngine:
                 continue
             if n not in v:
                 raise KeyError("unexpected parameter %r" % n)
-            v[n].copy_(torch.as_tensor(np.asarray(t) if not torch.is_tensor(t) else t).to(self.device).view_as(v[n]))
+            src = t if torch.is_tensor(t) else torch.from_numpy(np.asarray(t, np.float32))
+            v[n].copy_(src.to(self.device).view_as(v[n]))
 
     def state_struct(self):
         return _lib.GtStepState.from_buffer_copy(self.state.cpu().numpy().tobytes())
@@ -98,35 +124,40 @@ class StepEngine:
         st = self.state_struct()
         for k, val in kw.items():
             setattr(st, k, val)
-        self.state.copy_(torch.from_numpy(np.frombuffer(bytes(st), dtype=np.uint8).copy()))
+        self.state.copy_(torch.from_numpy(np.frombuffer(bytes(st), dtype=np.uint8).copy()))   # graphs stay valid
+
+    def set_step_async(self, step):
+        """Overwrite only the dropout step counter (bytes 8..11 of the device state), stream-ordered."""
+        t = torch.tensor([step & 0x7FFFFFFF], dtype=torch.int32).view(torch.uint8)
+        self.state[8:12].copy_(t, non_blocking=True)
 
     @property
     def stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- the hot path ----------------------------------------------------------------------------
-    def _enqueue_step(self, skip_update):
-        self.lib.call("gt_train_step", ctypes.byref(self.cfg), self.algo, _ptr(self.params), _ptr(self.grads),
-                      _ptr(self.m), _ptr(self.v), _ptr(self.pe), _ptr(self.x), _ptr(self.y),
-                      ctypes.c_float(self.penalty), _ptr(self.hvo), _ptr(self.stats), _ptr(self.tgt), _ptr(self.ws),
+    def _enqueue_step(self, s, skip_update):
+        self.lib.call("gt_train_step", ctypes.byref(s.cfg), self.algo, _ptr(self.params), _ptr(self.grads),
+                      _ptr(self.m), _ptr(self.v), _ptr(self.pe), _ptr(s.x), _ptr(s.y),
+                      ctypes.c_float(self.penalty), _ptr(s.hvo), _ptr(s.stats), _ptr(s.tgt), _ptr(s.ws),
                       _ptr(self.state), int(skip_update), self.stream)
 
-    def _enqueue_update(self):
+    def enqueue_update(self):
         self.lib.call("gt_optimizer_step", self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v),
                       ctypes.c_int64(self.total), _ptr(self.state), self.stream)
 
-    def _replay(self, key, fn):
+    def _replay(self, s, key, fn):
         if not self.use_graph:
             fn()
             return
-        if self._graph_key != key:
-            # warm-up launch outside capture (module load), then capture once
-            s = torch.cuda.Stream(self.device)
-            s.wait_stream(torch.cuda.current_stream(self.device))
+        if s.graph_key != key:
+            # one launch outside capture (code-object load), state restored, then capture once
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
             snap = (self.params.clone(), self.state.clone(), None if self.m is None else (self.m.clone(), self.v.clone()))
-            with torch.cuda.stream(s):
+            with torch.cuda.stream(side):
                 fn()
-            torch.cuda.current_stream(self.device).wait_stream(s)
+            torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             self.params.copy_(snap[0]); self.state.copy_(snap[1])
             if snap[2] is not None:
@@ -134,43 +165,59 @@ class StepEngine:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fn()
-            self._graph, self._graph_key = g, key
-        self._graph.replay()
+            s.graph, s.graph_key = g, key
+        s.graph.replay()
 
     def train_step(self, x=None, y=None):
         """One optimisation step on (x, y) (device or host tensors; None = reuse the static buffers).
         Returns the device stats tensor [loss, hit_acc, -, bce, mse_v, mse_o, -, -] without syncing."""
+        s = self.slot(x.shape[0] if x is not None else self.B)
         if x is not None:
-            self.x.copy_(x, non_blocking=True)
+            s.x.copy_(x, non_blocking=True)
         if y is not None:
-            self.y.copy_(y, non_blocking=True)
+            s.y.copy_(y, non_blocking=True)
         if self.world_size == 1:
-            self._replay("fused", lambda: self._enqueue_step(0))
+            self._replay(s, ("fused", self.algo, self.penalty), lambda: self._enqueue_step(s, 0))
         else:
             import torch.distributed as dist
-            self._replay("fwdbwd", lambda: self._enqueue_step(1))
+            self._replay(s, ("fwdbwd", self.algo, self.penalty), lambda: self._enqueue_step(s, 1))
             dist.all_reduce(self.grads)                      # RCCL sum over xGMI; averaged by grad_scale
-            self._enqueue_update()
-        return self.stats
+            self.enqueue_update()
+        return s.stats
 
     def forward(self, x, tgt_in=None, train=False):
-        """(h_logits, v, o) views of the (B,32,27) HVO buffer for a batch of the engine's size."""
-        self.x.copy_(x)
+        """Eval/train forward for any batch size -> (B,32,27) [h logits | v | o] buffer of that slot."""
+        s = self.slot(x.shape[0])
+        s.x.copy_(x)
         if tgt_in is not None:
-            self.tgt.copy_(tgt_in)
-        self.lib.call("gt_forward", ctypes.byref(self.cfg), _ptr(self.params), _ptr(self.pe), _ptr(self.x),
-                      None if self.encoder_only else _ptr(self.tgt), _ptr(self.hvo), _ptr(self.ws), _ptr(self.state),
+            s.tgt.copy_(tgt_in)
+        self.lib.call("gt_forward", ctypes.byref(s.cfg), _ptr(self.params), _ptr(self.pe), _ptr(s.x),
+                      None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(s.ws), _ptr(self.state),
                       int(train), self.stream)
-        return self.hvo
+        return s.hvo
+
+    def loss(self, s, y, penalty, want_grad=True):
+        """calculate_loss on slot s's current hvo.  -> (stats, d_hvo) device tensors."""
+        s.y.copy_(y)
+        d_hvo = torch.empty_like(s.hvo) if want_grad else None
+        self.lib.call("gt_loss", ctypes.byref(s.cfg), _ptr(s.hvo), _ptr(s.y), ctypes.c_float(penalty), _ptr(s.stats),
+                      _ptr(d_hvo), self.stream)
+        return s.stats, d_hvo
+
+    def backward(self, s, d_hvo, train, accumulate=True):
+        self.lib.call("gt_backward", ctypes.byref(s.cfg), _ptr(self.params), _ptr(self.grads), _ptr(s.x),
+                      None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(d_hvo), _ptr(s.ws), _ptr(self.state),
+                      int(train), int(accumulate), self.stream)
 
     def predict(self, x, use_thres=True, thres=0.5):
         """model.predict for ANY batch size (ref:evaluator.py:173 passes the whole evaluation set at once):
         returns a (N,32,27) HVO tensor on the device ([h | v | o], one D2H for the evaluator)."""
         x = torch.as_tensor(x, dtype=torch.float32).to(self.device).contiguous()
         n = x.shape[0]
-        cfg = _lib.make_config(n, self.S, self.cfg.d_model, self.cfg.n_heads, self.cfg.dim_ff, self.cfg.n_enc_layers,
-                               self.cfg.n_dec_layers, self.cfg.dropout)
-        ws = self._workspace(cfg)
+        d = self.dims
+        cfg = _lib.make_config(n, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
+                               d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"])
+        ws = torch.empty(self.lib.workspace_floats(cfg), dtype=torch.float32, device=self.device)
         out = torch.empty(n, 32, 27, dtype=torch.float32, device=self.device)
         tgt = torch.empty(n, 32, 27, dtype=torch.float32, device=self.device) if not self.encoder_only else None
         self.lib.call("gt_predict", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x), _ptr(out),
@@ -180,12 +227,13 @@ class StepEngine:
     def profile(self, steps):
         """Eager (no graph) pass of `steps` train steps with HIP events around every launch.
         -> {kernel class: (launches, total_ms, total_flops, total_bytes)}.  Measurement aid for bench.py."""
+        s = self.slot(self.B)
         snap = (self.params.clone(), self.state.clone())
         torch.cuda.synchronize(self.device)
         self.lib.cdll.gt_profile_enable(1)
         try:
             for _ in range(steps):
-                self._enqueue_step(0)
+                self._enqueue_step(s, 0)
             buf = ctypes.create_string_buffer(1 << 16)
             self.lib.cdll.gt_profile_report(buf, len(buf), 256)
         finally:

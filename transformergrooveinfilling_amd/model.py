@@ -1,0 +1,161 @@
+"""GrooveTransformerEncoder / GrooveTransformer: the reference's model interface over the HIP hot path.
+
+Mirrors what the reference imports from its un-vendored submodule (ref:train.py:12,149; ref:evaluator.py:173):
+``forward(src[, tgt]) -> (h_logits, v, o)`` and ``predict(src, use_thres=True, thres=0.5) -> (h, v, o)``,
+an ``nn.Module`` whose ``state_dict()`` carries exactly the checkpoint's key names (so
+ref:demo/transformer_run_171tyqit_Epoch_1.Model strict-loads) including the ``pe`` buffer.
+
+Every parameter is a VIEW into the engine's flat HBM buffer (and ``.grad`` a view into the flat gradient
+buffer), so the fused kernels, the single RCCL all-reduce and ``wandb.watch``/``state_dict`` all see the same
+memory.  There is no CPU implementation: constructing a model without a ROCm GPU raises.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import layout
+from .engine import StepEngine
+
+
+class _Node(nn.Module):
+    """Name-only container so that parameter paths equal the reference's state-dict keys."""
+
+
+def _attach(root, dotted, tensor, buffer=False):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    if buffer:
+        m.register_buffer(parts[-1], tensor)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor))
+    return m
+
+
+class _GrooveFn(torch.autograd.Function):
+    """autograd bridge: forward = gt_forward, backward = gt_backward accumulating into the flat .grad buffer."""
+
+    @staticmethod
+    def forward(ctx, hook, model, src, tgt):
+        eng = model.engine
+        train = model.training
+        if train:
+            model._train_forwards += 1
+            eng.set_step_async(model._train_forwards)      # fresh dropout masks per training forward
+        hvo = eng.forward(src, tgt, train)
+        ctx.model, ctx.slot, ctx.train = model, eng.slot(src.shape[0]), train
+        return hvo.clone()
+
+    @staticmethod
+    def backward(ctx, d_hvo):
+        ctx.model.engine.backward(ctx.slot, d_hvo.contiguous(), ctx.train, accumulate=True)
+        return None, None, None, None
+
+
+class _GrooveBase(nn.Module):
+    def __init__(self, d_model, nhead, num_encoder_layers, num_decoder_layers, dim_feedforward, dropout,
+                 embedding_size_src, embedding_size_tgt, max_len, device):
+        super().__init__()
+        if max_len != 32 or embedding_size_tgt != 27:
+            raise ValueError("the HIP path is built for max_len=32 / embedding_size_tgt=27 (ref:train.py:128,132)")
+        self.d_model, self.nhead, self.dim_feedforward, self.dropout = d_model, nhead, dim_feedforward, dropout
+        self.num_encoder_layers, self.num_decoder_layers = num_encoder_layers, num_decoder_layers
+        self.embedding_size_src, self.embedding_size_tgt, self.max_len = embedding_size_src, embedding_size_tgt, max_len
+        self.device = device if device is not None else "cuda"
+        self.engine = StepEngine(d_model, nhead, dim_feedforward, num_encoder_layers, num_decoder_layers, dropout,
+                                 embedding_size_src, device=self.device)
+        eng = self.engine
+        grads = eng.views(eng.grads)
+        for name, view in eng.views().items():
+            _attach(self, name, view)
+        for name, p in self.named_parameters():
+            p.grad = grads[name]
+        pe = eng.pe.view(1, max_len, d_model)
+        _attach(self, "InputLayerEncoder.PositionalEncoding.pe", pe, buffer=True)
+        if num_decoder_layers:
+            _attach(self, "InputLayerDecoder.PositionalEncoding.pe", pe, buffer=True)
+        self._hook = torch.zeros(1, device=eng.device, requires_grad=True)   # ties outputs into autograd
+        self._train_forwards = 0
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """torch defaults for the Transformer stack (xavier-uniform packed in-proj, zero attention biases,
+        kaiming-uniform(a=sqrt 5) linears, LayerNorm 1/0); IO layers U(-0.1, 0.1) with zero bias
+        (ckpt: InputLayer weight range +-0.0995)."""
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("in_proj_weight"):
+                    nn.init.xavier_uniform_(p)
+                elif name.endswith(("in_proj_bias", "out_proj.bias")):
+                    p.zero_()
+                elif name.startswith(("InputLayer", "OutputLayer")):
+                    p.uniform_(-0.1, 0.1) if name.endswith("weight") else p.zero_()
+                elif "norm" in name:
+                    p.fill_(1.0) if name.endswith("weight") else p.zero_()
+                elif name.endswith("weight"):
+                    nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                else:
+                    fan_in = self.d_model if "linear1" in name else self.dim_feedforward
+                    p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+
+    def zero_grad(self, set_to_none=False):
+        self.engine.grads.zero_()        # grads stay views of the flat buffer; never set to None
+
+    def _run(self, src, tgt):
+        src = src.to(self.engine.device, torch.float32)
+        if src.dim() != 3 or src.shape[1] != self.max_len or src.shape[2] != self.embedding_size_src:
+            raise ValueError("src must be (B, %d, %d), got %s" % (self.max_len, self.embedding_size_src, tuple(src.shape)))
+        if tgt is not None:
+            tgt = tgt.to(self.engine.device, torch.float32)
+        hvo = _GrooveFn.apply(self._hook, self, src, tgt)
+        n = self.embedding_size_tgt // 3
+        return hvo[..., :n], hvo[..., n:2 * n], hvo[..., 2 * n:]
+
+    def predict(self, src, use_thres=True, thres=0.5, use_pd=False):
+        """eval-mode, no-grad inference (ref:evaluator.py:173): h thresholded to {0,1} (or probabilities)."""
+        if use_pd:
+            raise NotImplementedError("use_pd (sampling hits from the probability) is not part of the HIP path")
+        self.eval()
+        with torch.no_grad():
+            hvo = self.engine.predict(src, use_thres=use_thres, thres=thres)
+        n = self.embedding_size_tgt // 3
+        return hvo[..., :n], hvo[..., n:2 * n], hvo[..., 2 * n:]
+
+    def predict_hvo(self, src, use_thres=True, thres=0.5):
+        """Same, but returns the concatenated (N,32,27) HVO tensor (one D2H for the evaluator)."""
+        self.eval()
+        with torch.no_grad():
+            return self.engine.predict(src, use_thres=use_thres, thres=thres)
+
+
+class GrooveTransformerEncoder(_GrooveBase):
+    """encoder_only = 1 (every shipped YAML: ref:configs/*_training.yaml:11)."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, dim_feedforward=2048, dropout=0.1,
+                 embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None):
+        super().__init__(d_model, nhead, num_encoder_layers, 0, dim_feedforward, dropout, embedding_size_src,
+                         embedding_size_tgt, max_len, device)
+
+    def forward(self, src):
+        return self._run(src, None)
+
+
+class GrooveTransformer(_GrooveBase):
+    """encoder-decoder (encoder_only = 0, ref:train.py:125-127); tgt = y shifted right by one step."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None):
+        super().__init__(d_model, nhead, num_encoder_layers, num_decoder_layers, dim_feedforward, dropout,
+                         embedding_size_src, embedding_size_tgt, max_len, device)
+
+    def forward(self, src, tgt):
+        return self._run(src, tgt)
+
+
+def parameter_names(model):
+    return [n for n, _ in layout.param_names(model.d_model, model.dim_feedforward, model.embedding_size_src,
+                                             model.num_encoder_layers, model.num_decoder_layers)]
