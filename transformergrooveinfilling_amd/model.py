@@ -112,6 +112,8 @@ class _GrooveBase(nn.Module):
         if tgt is not None:
             tgt = tgt.to(self.engine.device, torch.float32)
         hvo = _GrooveFn.apply(self._hook, self, src, tgt)
+        from . import training
+        training.calculate_loss._engine = self.engine          # the loss of these predictions runs on this engine
         n = self.embedding_size_tgt // 3
         return hvo[..., :n], hvo[..., n:2 * n], hvo[..., 2 * n:]
 

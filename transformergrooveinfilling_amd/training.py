@@ -157,6 +157,7 @@ def initialize_model(params):
         optimizer = GrooveSGD(model.parameters(), lr, model.engine)
     else:
         raise ValueError("optimizer_algorithm must be 'sgd' or 'adam' (ref:train.py:40-42), got %r" % algo)
+    _bind_engine(model)
     model.engine.set_state(lr=float(lr))
     model.engine.penalty = float(tp.get("hit_loss_penalty", 1.0))
     initial_epoch = 0
