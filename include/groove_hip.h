@@ -58,7 +58,7 @@ typedef struct gt_step_state {
   float lr;                    /* ref:train.py:136 learning_rate */
   float grad_scale;            /* 1/world_size for data-parallel averaging, else 1 */
   float beta1, beta2, eps;     /* Adam (torch defaults 0.9 / 0.999 / 1e-8) */
-  float pad2[3];
+  float pad2[3];               /* [0],[1]: ticket words of the loss / optimizer reductions (must start as 0) */
 } gt_step_state;
 
 /* ---- dropout RNG (shared with oracle/numpy_groove.py) ------------------------------------------
@@ -116,13 +116,16 @@ int gt_backward(const gt_config* cfg, const float* params, float* grads, const f
 
 /* Replaces optimizer.step() of torch.optim.SGD(lr, momentum=0) (ckpt: optimizer param_groups) /
  * torch.optim.Adam(lr) (ref:train.py:40-42).  algo 0 = sgd, 1 = adam (m, v: flat moment buffers).
- * Reads lr/grad_scale/betas from *state and increments state->step. */
-int gt_optimizer_step(int algo, float* params, const float* grads, float* m, float* v, int64_t n,
-                      gt_step_state* state, gt_stream_t stream);
+ * Reads lr/grad_scale/betas from *state and increments state->step / opt_step.  zero_grads != 0 also
+ * zeroes the consumed gradient buffer (what opt.zero_grad() does before the next batch). */
+int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n,
+                      gt_step_state* state, int zero_grads, gt_stream_t stream);
 
 /* One whole train step of train_loop's batch body (ref:train.py:195-215): [shift y for the decoder]
  * forward, loss, backward, optimizer update.  tgt_scratch (M,27) is only used when n_dec_layers>0.
- * With skip_update != 0 the optimizer is left to the caller (data-parallel: all-reduce grads first). */
+ * With skip_update != 0 the optimizer is left to the caller (data-parallel: all-reduce grads first).
+ * PRECONDITION: grads is all zeros on entry (zero it once after allocation; the update this call -- or the
+ * caller's gt_optimizer_step(zero_grads=1) -- leaves it zeroed again, so no per-step memset is enqueued). */
 int gt_train_step(const gt_config* cfg, int algo, float* params, float* grads, float* m, float* v,
                   const float* pe, const float* x, const float* y, float hit_loss_penalty,
                   float* hvo_out, float* stats, float* tgt_scratch, float* ws, gt_step_state* state,

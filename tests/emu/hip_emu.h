@@ -66,6 +66,7 @@ static inline float __shfl_xor(float v, int m) {
 static inline float __shfl(float v, int src) { return emu::wave_shfl(v, src & 63); }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline void __threadfence() {}
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #define GT_MFMA16(a, b, c) emu::mfma16((a), (b), (c))
 

@@ -114,13 +114,14 @@ class Runner:
         self.lib.call("gt_backward", ctypes.byref(self.c), self.params.ptr, self.grads.ptr, self.x.ptr,
                       self.tgt_in.ptr if self.tgt_in else None, self.hvo.ptr, self.d_hvo.ptr, self.ws.ptr, self.state.ptr,
                       int(train), 0, self.stream)
+        self._grads_dirty = True
         return self.unflatten(self.grads.numpy())
 
     def optimizer_step(self, algo=0):
         if algo == 1 and not hasattr(self, "m"):
             self.m, self.v = self.Buf(np.zeros(self.total, np.float32)), self.Buf(np.zeros(self.total, np.float32))
         self.lib.call("gt_optimizer_step", algo, self.params.ptr, self.grads.ptr, self.m.ptr if algo == 1 else None,
-                      self.v.ptr if algo == 1 else None, ctypes.c_int64(self.total), self.state.ptr, self.stream)
+                      self.v.ptr if algo == 1 else None, ctypes.c_int64(self.total), self.state.ptr, 0, self.stream)
         return self.unflatten(self.params.numpy())
 
     def train_step(self, x, y, penalty, algo=0, skip_update=False):
@@ -128,6 +129,9 @@ class Runner:
         self.y = self.Buf(np.asarray(y, np.float32).reshape(self.M, 27))
         if algo == 1 and not hasattr(self, "m"):
             self.m, self.v = self.Buf(np.zeros(self.total, np.float32)), self.Buf(np.zeros(self.total, np.float32))
+        if getattr(self, "_grads_dirty", False):           # gt_train_step precondition: grads are zero on entry
+            self.grads = self.Buf(np.zeros(self.total, np.float32))
+            self._grads_dirty = False
         self.lib.call("gt_train_step", ctypes.byref(self.c), algo, self.params.ptr, self.grads.ptr,
                       self.m.ptr if algo == 1 else None, self.v.ptr if algo == 1 else None, self.pe.ptr, self.x.ptr, self.y.ptr,
                       ctypes.c_float(penalty), self.hvo.ptr, self.stats.ptr, self.tgt.ptr, self.ws.ptr, self.state.ptr,

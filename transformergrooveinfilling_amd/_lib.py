@@ -46,8 +46,8 @@ _SIGS = {
     "gt_loss": (ctypes.c_int, [_cfgp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp]),
     # cfg, params, grads, x, tgt_in, hvo, d_hvo, ws, state, train, accumulate, stream
     "gt_backward": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
-    # algo, params, grads, m, v, n, state, stream
-    "gt_optimizer_step": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    # algo, params, grads, m, v, n, state, zero_grads, stream
+    "gt_optimizer_step": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int, _vp]),
     # cfg, algo, params, grads, m, v, pe, x, y, penalty, hvo_out, stats, tgt_scratch, ws, state, skip_update, stream
     "gt_train_step": (ctypes.c_int, [_cfgp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp,
                                      _vp, _vp, _vp, ctypes.c_int, _vp]),

@@ -178,7 +178,7 @@ struct LayerW {
 struct WLayout {
   int64_t x0, a0, enc_xhat, enc_rstd, memory, y0, b0, dec_xhat, dec_rstd, dec_final;
   std::vector<LayerW> layers;                        // encoder layers then decoder layers
-  int64_t hvo_tmp, dlogits, dzA, dzAm, dzB, dzBm, dhid, dctx, dqkv, dmem, total;
+  int64_t hvo_tmp, dlogits, loss_part, dzA, dzAm, dzB, dzBm, dhid, dctx, dqkv, dmem, total;
 };
 static WLayout ws_layout(const gt_config& c) {
   WLayout W;
@@ -208,6 +208,7 @@ static WLayout ws_layout(const gt_config& c) {
     W.y0 = W.b0 = W.dec_xhat = W.dec_rstd = W.dec_final = W.dmem = W.hvo_tmp = -1;
   }
   W.dlogits = add(M * GT_TGT);
+  W.loss_part = add(((M * GT_VOICES + 255) / 256) * 4);
   W.dzA = add(M * d); W.dzAm = add(M * d); W.dzB = add(M * d); W.dzBm = add(M * d);
   W.dhid = add(M * F); W.dctx = add(M * d); W.dqkv = add(M * 3 * d);
   W.total = cur;
@@ -257,6 +258,7 @@ struct Ctx {
   const gt_step_state* st;
   bool drop;                 // train mode with p > 0
   hipStream_t s;
+  WgradBatch* wb;            // weight gradients queue up here and leave as grouped dispatches
 };
 static DropArgs mk_drop(const Ctx& x, int site) {
   DropArgs da;
@@ -286,8 +288,11 @@ static void linear_fwd(const Ctx& x, const float* in, int ldin, const float* W, 
 static void wgrad(const Ctx& x, const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, int Nw, int Kw) {
   GemmArgs g = mk_gemm(dY, ldy, X, ldx, dW, Kw, Nw, Kw, x.M);
   g.dbias = db;
-  gemm_launch<true, true, EPI_ATOMIC>(g, x.s);
+  if (x.wb) wgrad_queue(*x.wb, g, x.s);
+  else gemm_launch<true, true, EPI_ATOMIC>(g, x.s);
 }
+// launch everything queued so far (call before any buffer a queued wgrad reads gets overwritten)
+static void wgrad_sync(const Ctx& x) { if (x.wb) wgrad_flush(*x.wb, x.s); }
 // dX = dY W   ("NN")
 static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, int ldw, float* dX, int N, int K, int accumulate) {
   GemmArgs g = mk_gemm(dY, ldy, W, ldw, dX, N, x.M, N, K);
@@ -355,6 +360,7 @@ static int make_ctx(Ctx& x, const gt_config* cfg, const float* params, float* gr
   x.prm = params; x.grd = grads; x.ws = ws; x.st = st;
   x.drop = train && st != nullptr && cfg->dropout > 0.f;
   x.s = (hipStream_t)stream;
+  x.wb = nullptr;
   return 0;
 }
 static int launch_status(const char* what) {
@@ -456,9 +462,10 @@ extern "C" int gt_loss(const gt_config* cfg, const float* hvo, const float* y, f
   if (!hvo || !y || !stats) return gt_fail("gt_loss: hvo / y / stats must not be NULL");
   const int M = cfg->batch * 32;
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(stats, 0, 8 * sizeof(float), s);
+  (void)hipMemsetAsync(stats, 0, 8 * sizeof(float), s);
   gt_prof_tag("loss", 0, 12.0 * M * GT_TGT);
-  gt_launch(loss_kernel, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, hvo, y, hit_loss_penalty, stats, d_hvo, M);
+  gt_launch(loss_kernel<false, false>, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, hvo, y, hit_loss_penalty, stats, d_hvo, M,
+            (float*)nullptr, (unsigned*)nullptr);
   return launch_status("gt_loss");
 }
 
@@ -497,23 +504,30 @@ static void input_layer_bwd(const Ctx& x, const LayerP& first, const float* dz1,
   wgrad(x, ws + x.W.dctx, x.d, in, S, x.grd + w, x.grd + b, x.d, S);
 }
 
-extern "C" int gt_backward(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
-                           const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
-                           gt_stream_t stream) {
+// d_hvo == nullptr: ws.dlogits already holds d loss / d logits (the fused loss kernel wrote it)
+static int backward_impl(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
+                         const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
+                         gt_stream_t stream) {
   Ctx x;
   if (make_ctx(x, cfg, params, grads, ws, state, train, stream)) return -1;
-  if (!grads || !xin || !hvo || !d_hvo) return gt_fail("gt_backward: grads / x / hvo / d_hvo must not be NULL");
+  if (!grads || !xin) return gt_fail("gt_backward: grads / x must not be NULL");
   const int L = cfg->n_enc_layers, Ld = cfg->n_dec_layers, d = x.d, M = x.M;
   if (Ld > 0 && !tgt_in) return gt_fail("gt_backward: encoder-decoder model needs tgt_in");
   const WLayout& W = x.W;
   const PLayout& P = x.P;
-  if (!accumulate) hipMemsetAsync(grads, 0, (size_t)P.total * sizeof(float), x.s);
+  if (!accumulate) (void)hipMemsetAsync(grads, 0, (size_t)P.total * sizeof(float), x.s);
+  // Weight gradients are queued and leave as ONE grouped dispatch per layer (wgrad_sync), placed just before
+  // the first kernel that overwrites a buffer a queued wgrad still reads (dzA/dzAm, dhid, dqkv, ws.dctx).
+  WgradBatch wbatch;
+  x.wb = &wbatch;
   float* dzA = ws + W.dzA; float* dzAm = x.drop ? ws + W.dzAm : dzA;
   float* dzB = ws + W.dzB; float* dzBm = x.drop ? ws + W.dzBm : dzB;
 
   // OutputLayer: dlogits, dW_out, then d(final) fused with the final norm's backward
-  gt_prof_tag("heads_bwd", 0, 12.0 * M * GT_TGT);
-  gt_launch(heads_bwd_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, d_hvo, hvo, ws + W.dlogits, M * GT_TGT);
+  if (d_hvo != nullptr) {
+    gt_prof_tag("heads_bwd", 0, 12.0 * M * GT_TGT);
+    gt_launch(heads_bwd_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, d_hvo, hvo, ws + W.dlogits, M * GT_TGT);
+  }
   const float* fin = ws + (Ld > 0 ? W.dec_final : W.memory);
   wgrad(x, ws + W.dlogits, GT_TGT, fin, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
   {
@@ -546,6 +560,7 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
       wgrad(x, dqx, d, ws + w.x1, d, grads + p.xa.in_w, grads + p.xa.in_b, d, d);
       wgrad(x, dkvx, 2 * d, ws + W.memory, d, grads + p.xa.in_w + (int64_t)d * d, grads + p.xa.in_b + d, 2 * d, d);
       dgrad_store(x, dkvx, 2 * d, params + p.xa.in_w + (int64_t)d * d, d, ws + W.dmem, d, 2 * d, 1);
+      wgrad_sync(x);       // the next kernel overwrites dzA/dzAm (read by the queued linear2 wgrad)
       // dz1 = LNbwd_norm1(dqx Wq + dz2) -> (dzA, dzAm) masked for the self-attn out-proj
       if (dgrad_lnbwd(x, dqx, d, params + p.xa.in_w, d, dzB, ws + w.xhat1, ws + w.rstd1, p.n1w, dzA, dzAm, lsite(gl, GT_SITE_DROP1)))
         return -1;
@@ -561,6 +576,7 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
       } else {
         input_layer_bwd(x, p, dzA, ws + W.b0, tgt_in, GT_TGT, P.din_w, P.din_b, GT_SITE_PE_DEC);
       }
+      wgrad_sync(x);       // next layer (or the encoder) overwrites dzAm / dqkv / ws.dctx
     }
     // encoder final norm backward (input: accumulated dmem) -> grad w.r.t. the last encoder layer's output
     ln_bwd(x, ws + W.dmem, ws + W.enc_xhat, ws + W.enc_rstd, P.encn_w, ws + W.dctx, nullptr, 0);
@@ -576,6 +592,7 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
     if (ffn_bwd(x, p, w, ws + w.x1, dzA, dzAm, ws + w.xhat1, ws + w.rstd1, p.n1w, dzB, dzBm, lsite(l, GT_SITE_DROP1), l)) return -1;
     self_attn_bwd(x, p, w, lin, dzBm, l);
     if (l > 0) {
+      wgrad_sync(x);       // the next kernel overwrites dzA/dzAm (read by the queued linear2 wgrad)
       const LayerW& wp = W.layers[l - 1];
       if (dgrad_lnbwd(x, ws + W.dqkv, 3 * d, params + p.sa.in_w, 3 * d, dzB, ws + wp.xhat2, ws + wp.rstd2, P.enc[l - 1].n2w, dzA, dzAm,
                       lsite(l - 1, GT_SITE_DROPF)))
@@ -584,26 +601,33 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
       input_layer_bwd(x, p, dzB, ws + W.a0, xin, cfg->src_dim, P.in_w, P.in_b, GT_SITE_PE_ENC);
     }
   }
+  wgrad_sync(x);
   return launch_status("gt_backward");
 }
 
+extern "C" int gt_backward(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
+                           const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
+                           gt_stream_t stream) {
+  if (!hvo || !d_hvo) return gt_fail("gt_backward: hvo / d_hvo must not be NULL");
+  return backward_impl(cfg, params, grads, xin, tgt_in, hvo, d_hvo, ws, state, train, accumulate, stream);
+}
+
 // ------------------------------------------------------------------------------------ optimizer
-extern "C" int gt_optimizer_step(int algo, float* params, const float* grads, float* m, float* v, int64_t n, gt_step_state* state,
-                                 gt_stream_t stream) {
+extern "C" int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n, gt_step_state* state,
+                                 int zero_grads, gt_stream_t stream) {
   if (!params || !grads || !state || n <= 0) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 1023) / 1024);
   if (algo == 0) {
     gt_prof_tag("optimizer", 0, 12.0 * n);
-    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, (const gt_step_state*)state);
+    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, state, zero_grads);
   } else if (algo == 1) {
     if (!m || !v) return gt_fail("gt_optimizer_step: adam needs m and v");
     gt_prof_tag("optimizer", 0, 28.0 * n);
-    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state);
+    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, state, zero_grads);
   } else {
     return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
   }
-  gt_launch(step_inc_kernel, dim3(1), dim3(64), s, state);
   return launch_status("gt_optimizer_step");
 }
 
@@ -622,14 +646,18 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
     tgt_in = tgt_scratch;
   }
   if (gt_forward(cfg, params, pe, xin, tgt_in, hvo_out, ws, state, 1, stream)) return -1;
-  // d_hvo lives in the (not yet used) dqkv temporary
+  // loss + head-activation backward in one kernel: d loss / d logits straight into ws.dlogits; workgroup partials are
+  // combined by the last-arriving workgroup (ticket in the step state), so there is no memset node and the stats are
+  // bitwise reproducible.  grads: zero on entry (precondition), re-zeroed by the optimizer kernel.
   WLayout W = ws_layout(*cfg);
-  float* d_hvo = ws + W.dqkv;
-  if (gt_loss(cfg, hvo_out, y, hit_loss_penalty, stats, d_hvo, stream)) return -1;
-  if (gt_backward(cfg, params, grads, xin, tgt_in, hvo_out, d_hvo, ws, state, 1, 0, stream)) return -1;
+  if (!stats || !hvo_out) return gt_fail("gt_train_step: hvo_out / stats must not be NULL");
+  gt_prof_tag("loss", 0, 12.0 * M * GT_TGT);
+  gt_launch(loss_kernel<true, true>, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, (const float*)hvo_out, y, hit_loss_penalty, stats,
+            ws + W.dlogits, M, ws + W.loss_part, reinterpret_cast<unsigned*>(&state->pad2[0]));
+  if (backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream)) return -1;
   if (!skip_update) {
     PLayout P = param_layout(*cfg);
-    if (gt_optimizer_step(algo, params, grads, m, v, P.total, state, stream)) return -1;
+    if (gt_optimizer_step(algo, params, grads, m, v, P.total, state, 1, stream)) return -1;
   }
   return 0;
 }

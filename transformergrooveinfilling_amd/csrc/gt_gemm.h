@@ -129,7 +129,7 @@ __device__ static inline float gt_red16(float v) {
 }
 
 template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
   typedef GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI> Cfg;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::NT;
   constexpr int SA_STR = Cfg::SA_STR, SB_STR = Cfg::SB_STR, SA_SZ = Cfg::SA_SZ, SB_SZ = Cfg::SB_SZ;
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l16 = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * g.k_chunk;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * g.k_chunk;
   const int kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
   const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     }
 
     if (EPI == EPI_ATOMIC && AKM) {
-      if (g.dbias != nullptr && blockIdx.x == 0 && tid < BM) {
+      if (g.dbias != nullptr && bx == 0 && tid < BM) {
 #pragma unroll 8
         for (int kk = 0; kk < BK; ++kk) bsum += sA[kk * SA_STR + tid];
       }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 
   if (!Cfg::ROW) {
     if (EPI == EPI_ATOMIC && AKM) {
-      if (g.dbias != nullptr && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) atomicAdd(&g.dbias[m0 + tid], bsum);
+      if (g.dbias != nullptr && bx == 0 && tid < BM && m0 + tid < g.M) atomicAdd(&g.dbias[m0 + tid], bsum);
     }
     constexpr bool NEED_R1 = (EPI == EPI_STORE || EPI == EPI_RELU_PE || EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP);
     constexpr bool NEED_R2 = (EPI == EPI_ADD_RELUMASK_DROP);
@@ -423,6 +423,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
   }
 }
 
+template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+  gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: up to GT_GROUP_MAX independent GEMMs of one kind in ONE dispatch (all weight gradients of a
+// layer).  A kernel boundary costs ~4 us on this machine whatever the kernel does, and each wgrad alone is too
+// small to fill 256 CUs; together they do.  Workgroup b serves problem i with start[i] <= b < start[i+1].
+#define GT_GROUP_MAX 8
+struct GemmGroup {
+  int n;
+  int start[GT_GROUP_MAX + 1];
+  int gx[GT_GROUP_MAX], gy[GT_GROUP_MAX];
+  GemmArgs p[GT_GROUP_MAX];
+};
+template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(GemmGroup grp) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < grp.n && b >= grp.start[i + 1]) ++i;
+  const int local = b - grp.start[i];
+  const int bx = local % grp.gx[i], t = local / grp.gx[i];
+  gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i]);
+}
+
 // --------------------------------------------------------------------------------- host dispatch
 template <bool BKM, int EPI>
 static inline const char* gemm_label() {
@@ -440,21 +465,51 @@ static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s)
   gt_launch(gemm_kernel<WM, WN, TM, TN, BK, AKM, BKM, EPI>, grid, dim3(Cfg::NT), s, g);
 }
 
+// wgrad: the output (N_w x K_w) is small, the contraction (tokens) is long -> split it over z so that the
+// problem yields about `target` 32x32-tile workgroups.  Sets g.k_chunk, returns the split count.
+static inline int wgrad_split(GemmArgs& g, long target) {
+  const long tiles = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+  long want = (target + tiles - 1) / tiles;
+  const long maxs = (g.K + 127) / 128;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  int chunk = (int)((g.K + want - 1) / want);
+  chunk = (chunk + 63) / 64 * 64;
+  g.k_chunk = chunk;
+  return (g.K + chunk - 1) / chunk;
+}
+
+// all weight gradients queued since the last flush go out as ONE grouped dispatch
+struct WgradBatch {
+  GemmGroup grp;
+  double flops, bytes;
+  WgradBatch() { grp.n = 0; grp.start[0] = 0; flops = bytes = 0; }
+};
+static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) {
+  if (wb.grp.n == 0) return;
+  gt_prof_tag("gemm_wgrad", wb.flops, wb.bytes);
+  gt_launch(gemm_group_kernel<2, 2, 1, 1, 64, true, true, EPI_ATOMIC>, dim3(wb.grp.start[wb.grp.n]), dim3(256), s, wb.grp);
+  wb.grp.n = 0; wb.flops = wb.bytes = 0;
+}
+static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
+  if (wb.grp.n == GT_GROUP_MAX) wgrad_flush(wb, s);
+  const int splitk = wgrad_split(g, 512);
+  const int i = wb.grp.n++;
+  wb.grp.p[i] = g;
+  wb.grp.gx[i] = (g.N + 31) / 32;
+  wb.grp.gy[i] = (g.M + 31) / 32;
+  wb.grp.start[i + 1] = wb.grp.start[i] + wb.grp.gx[i] * wb.grp.gy[i] * splitk;
+  wb.flops += 2.0 * g.M * g.N * g.K;
+  wb.bytes += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+}
+
 // standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
 template <bool AKM, bool BKM, int EPI>
 static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   g.k_chunk = (g.K + 63) / 64 * 64;
   if (EPI == EPI_ATOMIC) {
-    // wgrad: the output (N_w x K_w) is small, the contraction (tokens) is long -> split it over z
-    const long tiles = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
-    long want = (1024 + tiles - 1) / tiles;
-    const long maxs = (g.K + 127) / 128;
-    if (want > maxs) want = maxs;
-    if (want < 1) want = 1;
-    int chunk = (int)((g.K + want - 1) / want);
-    chunk = (chunk + 63) / 64 * 64;
-    g.k_chunk = chunk;
-    gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, (g.K + chunk - 1) / chunk, s);
+    const int splitk = wgrad_split(g, 1024);
+    gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, splitk, s);
     return;
   }
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);

@@ -78,10 +78,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // ---- loss: BCEWithLogits(h)*pen + MSE(v)*pen + MSE(o)*pen, summed over voices, mean over (B,T) ---
 // One thread per (row, voice).  stats: [0] loss [1] hit accuracy [3] bce [4] mse_v [5] mse_o.
-// d_hvo = d loss / d (h, v, o)  (w.r.t. the ACTIVATED outputs, like autograd hands them over).
+// d_out = d loss / d (h, v, o)  (w.r.t. the ACTIVATED outputs, like autograd hands them over), or -- with
+// WRT_LOGITS -- already multiplied by the head activations' derivative (heads_bwd fused; the train step).
+// Reduction across workgroups:
+//   TICKET=false: atomicAdd into stats (zeroed by the caller with a memset node);
+//   TICKET=true : every workgroup stores its 4 partial sums, the last one to arrive (agent-scope release /
+//                 acquire around a ticket counter, cdna_hip_programming.md G16) adds them in a FIXED order ->
+//                 bitwise-reproducible stats and no memset node.  The ticket word re-arms itself.
+template <bool TICKET, bool WRT_LOGITS>
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ hvo, const float* __restrict__ y, float penalty,
-                                                   float* __restrict__ stats, float* __restrict__ d_hvo, int M) {
+                                                   float* __restrict__ stats, float* __restrict__ d_out, int M,
+                                                   float* __restrict__ partials, unsigned* __restrict__ ticket) {
   __shared__ float red[4][4];
+  __shared__ int is_last;
   const int e = blockIdx.x * 256 + threadIdx.x;
   const float invM = 1.0f / (float)M;
   float bce = 0.f, mv = 0.f, mo = 0.f, ok = 0.f;
@@ -95,26 +104,56 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ hvo
     mv = (v - yv) * (v - yv) * pen;
     mo = (o - yo) * (o - yo) * pen;
     ok = (((h > 0.f) ? 1.0f : 0.0f) == yh) ? 1.0f : 0.0f;      // sigmoid(h) > 0.5  <=>  h > 0
-    if (d_hvo) {
-      d_hvo[base] = (gt_sigmoid(h) - yh) * pen * invM;
-      d_hvo[base + GT_VOICES] = 2.0f * (v - yv) * pen * invM;
-      d_hvo[base + 2 * GT_VOICES] = 2.0f * (o - yo) * pen * invM;
+    if (d_out) {
+      float gv = 2.0f * (v - yv) * pen * invM, go = 2.0f * (o - yo) * pen * invM;
+      if (WRT_LOGITS) { gv *= v * (1.0f - v); go *= (0.5f - 2.0f * o * o); }
+      d_out[base] = (gt_sigmoid(h) - yh) * pen * invM;
+      d_out[base + GT_VOICES] = gv;
+      d_out[base + 2 * GT_VOICES] = go;
     }
   }
   bce = gt_wave_sum(bce); mv = gt_wave_sum(mv); mo = gt_wave_sum(mo); ok = gt_wave_sum(ok);
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[w][0] = bce; red[w][1] = mv; red[w][2] = mo; red[w][3] = ok; }
   __syncthreads();
+  if (!TICKET) {
+    if (threadIdx.x == 0) {
+      const float b_ = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * invM;
+      const float v_ = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * invM;
+      const float o_ = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) * invM;
+      const float k_ = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) * invM * (1.0f / GT_VOICES);
+      atomicAdd(&stats[0], b_ + v_ + o_);
+      atomicAdd(&stats[1], k_);
+      atomicAdd(&stats[3], b_);
+      atomicAdd(&stats[4], v_);
+      atomicAdd(&stats[5], o_);
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
-    const float b_ = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * invM;
-    const float v_ = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * invM;
-    const float o_ = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) * invM;
-    const float k_ = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) * invM * (1.0f / GT_VOICES);
-    atomicAdd(&stats[0], b_ + v_ + o_);
-    atomicAdd(&stats[1], k_);
-    atomicAdd(&stats[3], b_);
-    atomicAdd(&stats[4], v_);
-    atomicAdd(&stats[5], o_);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) partials[blockIdx.x * 4 + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+    __threadfence();                                        // release: partials before the ticket
+    const unsigned t = atomicAdd(ticket, 1u);
+    is_last = (t == gridDim.x - 1) ? 1 : 0;
+    if (is_last) __threadfence();                           // acquire: the other workgroups' partials
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // fixed-order sum: thread q (q < 4) walks all workgroups for quantity q
+  if (threadIdx.x < 4) {
+    float acc = 0.f;
+    for (unsigned bk = 0; bk < gridDim.x; ++bk) acc += partials[bk * 4 + threadIdx.x];
+    red[0][threadIdx.x] = acc * invM;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b_ = red[0][0], v_ = red[0][1], o_ = red[0][2];
+    stats[0] = b_ + v_ + o_;
+    stats[1] = red[0][3] * (1.0f / GT_VOICES);
+    stats[2] = 0.f;
+    stats[3] = b_; stats[4] = v_; stats[5] = o_; stats[6] = 0.f; stats[7] = 0.f;
+    *ticket = 0u;                                           // re-arm for the next step
   }
 }
 
@@ -132,8 +171,20 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
 }
 
 // ---- optimizer: flat multi-tensor update (one launch for all 78+ tensors) -----------------------
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n,
-                                                  const gt_step_state* __restrict__ st) {
+// zero_grads: the gradient is consumed and left zeroed (the next backward accumulates into it: no memset node).
+// The LAST workgroup to finish (ticket counter in the step state) advances step / opt_step: every workgroup
+// has read the state before it takes its ticket, so there is no separate increment launch and no race.
+__device__ static inline void gt_opt_finish(gt_step_state* st) {
+  __syncthreads();                                   // all threads of this workgroup are past their state reads
+  if (threadIdx.x == 0) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(&st->pad2[1]);
+    const unsigned t = atomicAdd(ticket, 1u);
+    if (t == gridDim.x - 1) { st->step += 1u; st->opt_step += 1u; *ticket = 0u; }
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n, gt_step_state* st,
+                                                  int zero_grads) {
   const float k = st->lr * st->grad_scale;
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -141,32 +192,33 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     const float4 gv = *reinterpret_cast<const float4*>(g + i);
     pv.x -= k * gv.x; pv.y -= k * gv.y; pv.z -= k * gv.z; pv.w -= k * gv.w;
     *reinterpret_cast<float4*>(p + i) = pv;
+    if (zero_grads) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    for (int64_t j = i; j < n; ++j) p[j] -= k * g[j];
+    for (int64_t j = i; j < n; ++j) { p[j] -= k * g[j]; if (zero_grads) g[j] = 0.f; }
   }
+  gt_opt_finish(st);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, const gt_step_state* __restrict__ st) {
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, gt_step_state* st, int zero_grads) {
   const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->opt_step + 1u);
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = st->lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  const float gs = st->grad_scale, eps = st->eps;
   const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int64_t i = i0 + u;
     if (i < n) {
-      const float gi = g[i] * st->grad_scale;
+      const float gi = g[i] * gs;
       const float mi = b1 * m[i] + (1.0f - b1) * gi;
       const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
       m[i] = mi; v[i] = vi;
-      p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + st->eps);
+      p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+      if (zero_grads) g[i] = 0.f;
     }
   }
-}
-
-__global__ void step_inc_kernel(gt_step_state* st) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1u; st->opt_step += 1u; }
+  gt_opt_finish(st);
 }
 
 // teacher forcing: tgt_in[b,t] = y[b,t-1], row 0 = zeros

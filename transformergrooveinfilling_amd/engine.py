@@ -142,9 +142,11 @@ class StepEngine:
                       ctypes.c_float(self.penalty), _ptr(s.hvo), _ptr(s.stats), _ptr(s.tgt), _ptr(s.ws),
                       _ptr(self.state), int(skip_update), self.stream)
 
-    def enqueue_update(self):
+    def enqueue_update(self, zero_grads=True):
+        """Fused update over the flat buffers.  zero_grads=True also clears the consumed gradients (fused step path);
+        the torch.optim-style front keeps them until zero_grad() like torch does."""
         self.lib.call("gt_optimizer_step", self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v),
-                      ctypes.c_int64(self.total), _ptr(self.state), self.stream)
+                      ctypes.c_int64(self.total), _ptr(self.state), int(zero_grads), self.stream)
 
     def _replay(self, s, key, fn):
         if not self.use_graph:
@@ -162,6 +164,7 @@ class StepEngine:
             self.params.copy_(snap[0]); self.state.copy_(snap[1])
             if snap[2] is not None:
                 self.m.copy_(snap[2][0]); self.v.copy_(snap[2][1])
+            self.grads.zero_()                    # gt_train_step's precondition (the update re-zeroes it every step)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fn()
@@ -238,7 +241,7 @@ class StepEngine:
             self.lib.cdll.gt_profile_report(buf, len(buf), 256)
         finally:
             self.lib.cdll.gt_profile_enable(0)
-        self.params.copy_(snap[0]); self.state.copy_(snap[1])
+        self.params.copy_(snap[0]); self.state.copy_(snap[1]); self.grads.zero_()
         out = {}
         for line in buf.value.decode().splitlines():
             lab, cnt, ms, fl, by = line.split()

@@ -50,7 +50,7 @@ class _FusedMixin:
         loss = closure() if closure is not None else None
         self._push_lr()
         self.engine.algo = self._algo
-        self.engine.enqueue_update()
+        self.engine.enqueue_update(zero_grads=False)
         return loss
 
 
@@ -258,6 +258,7 @@ def train_loop(dataloader, groove_transformer, encoder_only, opt, epoch, loss_fn
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         world = torch.distributed.get_world_size()
     if fast:
+        eng.grads.zero_()                      # gt_train_step precondition; every fused update re-zeroes them
         eng.penalty = float(hit_loss_penalty)
         eng.algo = opt._algo
         opt._push_lr()
