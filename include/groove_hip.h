@@ -142,6 +142,10 @@ int gt_predict(const gt_config* cfg, const float* params, const float* pe, const
  * HIP events on its own stream.  gt_profile_report synchronises and writes one text row per kernel
  * class: "label launches total_ms total_flops total_bytes".  Not graph-capturable while on. */
 int gt_profile_enable(int on);
+/* on: grouped weight-gradient dispatches run on an internal side stream (created once, on first use) and may overlap
+ * the backward chain; recorded as fork/join edges when the call is being captured into a hipGraph.  off (default;
+ * env GT_OVERLAP=1 switches the default): a single stream -- measured faster on ROCm 7.2, see DESIGN.md. */
+int gt_set_overlap(int on);
 int gt_profile_report(char* buf, size_t buf_len, int max_rows);
 
 #ifdef __cplusplus

@@ -34,6 +34,7 @@ typedef float f32x4 __attribute__((vector_size(16)));
 typedef int hipStream_t_dummy;
 typedef void* hipStream_t;
 typedef int hipError_t;
+typedef void* hipEvent_t;
 #define hipSuccess 0
 
 #define __global__

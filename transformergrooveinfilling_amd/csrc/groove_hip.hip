@@ -9,6 +9,7 @@
 // reference's demo checkpoint (ref:demo/transformer_run_171tyqit_Epoch_1.Model).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -178,7 +179,8 @@ struct LayerW {
 struct WLayout {
   int64_t x0, a0, enc_xhat, enc_rstd, memory, y0, b0, dec_xhat, dec_rstd, dec_final;
   std::vector<LayerW> layers;                        // encoder layers then decoder layers
-  int64_t hvo_tmp, dlogits, loss_part, dzA, dzAm, dzB, dzBm, dhid, dctx, dqkv, dmem, total;
+  int64_t hvo_tmp, dlogits, loss_part, dctx, dmem, da0_dec, ln_part, ln_part_stride, total;
+  struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; } set[2];
 };
 static WLayout ws_layout(const gt_config& c) {
   WLayout W;
@@ -209,8 +211,21 @@ static WLayout ws_layout(const gt_config& c) {
   }
   W.dlogits = add(M * GT_TGT);
   W.loss_part = add(((M * GT_VOICES + 255) / 256) * 4);
-  W.dzA = add(M * d); W.dzAm = add(M * d); W.dzB = add(M * d); W.dzBm = add(M * d);
-  W.dhid = add(M * F); W.dctx = add(M * d); W.dqkv = add(M * 3 * d);
+  // dgamma/dbeta partials: one [row_tiles][2][d] block per LayerNorm instance (2 per encoder layer, 3 per decoder
+  // layer, the final norms)
+  W.ln_part_stride = ((M + 15) / 16) * 2 * d;
+  W.ln_part = add(W.ln_part_stride * (2 * c.n_enc_layers + 3 * c.n_dec_layers + 2));
+  W.dctx = add(M * d);
+  W.da0_dec = c.n_dec_layers > 0 ? add(M * d) : -1;
+  // Backward temporaries exist twice: layer l works in set l&1, so the grouped weight-gradient dispatch of layer l
+  // (side stream) can still read its inputs while the dgrad chain of layer l-1 already runs in the other set.
+  for (int k = 0; k < 2; ++k) {
+    WLayout::TmpSet& t = W.set[k];
+    t.dzA = add(M * d); t.dzAm = add(M * d); t.dzB = add(M * d); t.dzBm = add(M * d);
+    t.dhid = add(M * F); t.dqkv = add(M * 3 * d);
+    if (c.n_dec_layers > 0) { t.dzC = add(M * d); t.dzCm = add(M * d); t.dqkvx = add(M * 3 * d); }
+    else { t.dzC = t.dzCm = t.dqkvx = -1; }
+  }
   W.total = cur;
   return W;
 }
@@ -259,7 +274,29 @@ struct Ctx {
   bool drop;                 // train mode with p > 0
   hipStream_t s;
   WgradBatch* wb;            // weight gradients queue up here and leave as grouped dispatches
+  hipStream_t side;          // stream the grouped wgrad dispatches run on (nullptr: the main stream)
+  hipEvent_t pending[2];     // last side-stream event that reads temporaries set 0 / 1 (nullptr: none)
+  LnJobs* ln;                // LayerNorm parameter-gradient partials to be summed at the end of backward
 };
+// next partials block for a LayerNorm backward launched with `nwg` workgroups; registers the reduction job
+static float* ln_job(const Ctx& x, int64_t gamma_off, int nwg) {
+  if (!x.ln || x.ln->n >= GT_LN_JOBS_MAX) return nullptr;          // fall back to atomics
+  float* part = x.ws + x.W.ln_part + x.W.ln_part_stride * x.ln->n;
+  LnJob& j = x.ln->j[x.ln->n++];
+  j.part = part; j.dgamma = x.grd + gamma_off; j.dbeta = x.grd + gamma_off + (x.d + 63) / 64 * 64; j.nwg = nwg;
+  return part;
+}
+struct Tmp { float *dzA, *dzAm, *dzB, *dzBm, *dzC, *dzCm, *dhid, *dqkv, *dqkvx; };
+static Tmp tmp_set(const Ctx& x, int gl) {
+  const WLayout::TmpSet& t = x.W.set[gl & 1];
+  float* ws = x.ws;
+  Tmp r;
+  r.dzA = ws + t.dzA; r.dzAm = x.drop ? ws + t.dzAm : r.dzA;
+  r.dzB = ws + t.dzB; r.dzBm = x.drop ? ws + t.dzBm : r.dzB;
+  r.dzC = t.dzC >= 0 ? ws + t.dzC : nullptr; r.dzCm = t.dzC >= 0 ? (x.drop ? ws + t.dzCm : r.dzC) : nullptr;
+  r.dhid = ws + t.dhid; r.dqkv = ws + t.dqkv; r.dqkvx = t.dqkvx >= 0 ? ws + t.dqkvx : nullptr;
+  return r;
+}
 static DropArgs mk_drop(const Ctx& x, int site) {
   DropArgs da;
   da.st = x.drop ? x.st : nullptr;
@@ -291,8 +328,60 @@ static void wgrad(const Ctx& x, const float* dY, int ldy, const float* X, int ld
   if (x.wb) wgrad_queue(*x.wb, g, x.s);
   else gemm_launch<true, true, EPI_ATOMIC>(g, x.s);
 }
-// launch everything queued so far (call before any buffer a queued wgrad reads gets overwritten)
-static void wgrad_sync(const Ctx& x) { if (x.wb) wgrad_flush(*x.wb, x.s); }
+// ---- side stream for weight gradients ------------------------------------------------------------------------
+// Weight gradients are off the critical path (nothing in the backward chain reads them), so their grouped dispatches
+// run on a second stream and overlap the dgrad chain, which alone cannot fill 256 CUs at these sizes.  The stream and
+// a pool of events are created once, on first use (outside any capture: the engine's warm-up call); under hipGraph
+// capture the record/wait pairs become fork/join edges of the captured graph.
+// Measured on MI355X / ROCm 7.2 (profiles/, r01f): captured into a hipGraph the fork/join did NOT buy concurrency --
+// the sum of kernel durations still equalled the wall time and the step got 7 % slower -- so the default is OFF
+// (GT_OVERLAP=1 or gt_set_overlap(1) turns it on for experiments).
+static int g_overlap = -1;
+#ifndef GT_EMU
+static hipStream_t g_side = nullptr;
+static std::vector<hipEvent_t> g_events;
+static size_t g_event_next = 0;
+static hipStream_t side_stream() {
+  if (g_overlap < 0) { const char* e = getenv("GT_OVERLAP"); g_overlap = (e && e[0] == '1') ? 1 : 0; }
+  if (!g_overlap) return nullptr;
+  if (!g_side) {
+    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; return nullptr; }
+    g_events.resize(512);
+    for (auto& e : g_events) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  }
+  return g_side;
+}
+static hipEvent_t next_event() { return g_events[g_event_next++ % g_events.size()]; }
+#else
+static hipStream_t side_stream() { return nullptr; }
+#endif
+extern "C" int gt_set_overlap(int on) { g_overlap = on != 0; return 0; }
+
+// launch everything queued so far for the layer whose temporaries live in set `set` (call after the last producer of a
+// queued wgrad's inputs has been enqueued)
+static void wgrad_sync(Ctx& x, int set) {
+  if (!x.wb || x.wb->grp.n == 0) return;
+#ifndef GT_EMU
+  if (x.side && !g_prof.on) {
+    hipEvent_t ready = next_event(), done = next_event();
+    (void)hipEventRecord(ready, x.s);
+    (void)hipStreamWaitEvent(x.side, ready, 0);
+    wgrad_flush(*x.wb, x.side);
+    (void)hipEventRecord(done, x.side);
+    x.pending[set & 1] = done;
+    return;
+  }
+#endif
+  wgrad_flush(*x.wb, x.s);
+}
+// before the main stream writes into temporaries set `set`: wait for the side-stream reader of that set
+static void acquire_set(Ctx& x, int set) {
+#ifndef GT_EMU
+  if (x.pending[set & 1]) { (void)hipStreamWaitEvent(x.s, x.pending[set & 1], 0); x.pending[set & 1] = nullptr; }
+#else
+  (void)x; (void)set;
+#endif
+}
 // dX = dY W   ("NN")
 static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, int ldw, float* dX, int N, int K, int accumulate) {
   GemmArgs g = mk_gemm(dY, ldy, W, ldw, dX, N, x.M, N, K);
@@ -308,15 +397,19 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
   g.dgamma = x.grd + gamma_off; g.dbeta = x.grd + gamma_off + (x.d + 63) / 64 * 64;   // bias tensor follows the weight
   g.C2 = x.drop ? dzm : nullptr;
   g.drop = mk_drop(x, site);
+  const int bm = gemm_row_bm(x.M);
+  g.ln_part = ln_job(x, gamma_off, (x.M + bm - 1) / bm);
   return gemm_launch_row<false, true, EPI_RES_LNBWD>(g, x.s);
 }
 static void ln_bwd(const Ctx& x, const float* dy, const float* xhat, const float* rstd, int64_t gamma_off, float* dz, float* dzm,
                    int site) {
   const int rows_per_block = 4 * GT_LNB_ROWS;
+  const int nblk = (x.M + rows_per_block - 1) / rows_per_block;
+  float* part = ln_job(x, gamma_off, nblk);
   gt_prof_tag("ln_bwd", 0, 12.0 * x.M * x.d);
-  gt_launch(ln_bwd_kernel, dim3((x.M + rows_per_block - 1) / rows_per_block), dim3(256), x.s, dy, xhat, rstd,
+  gt_launch(ln_bwd_kernel, dim3(nblk), dim3(256), x.s, dy, xhat, rstd,
             x.prm + gamma_off, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
-            x.grd + gamma_off + (x.d + 63) / 64 * 64, x.M, x.d);
+            x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d);
 }
 // x_out = LN(drop(in W^T + b) + res)
 static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, int64_t b_off, const float* res, int64_t gamma_off,
@@ -361,6 +454,9 @@ static int make_ctx(Ctx& x, const gt_config* cfg, const float* params, float* gr
   x.drop = train && st != nullptr && cfg->dropout > 0.f;
   x.s = (hipStream_t)stream;
   x.wb = nullptr;
+  x.side = nullptr;
+  x.pending[0] = x.pending[1] = nullptr;
+  x.ln = nullptr;
   return 0;
 }
 static int launch_status(const char* what) {
@@ -472,36 +568,34 @@ extern "C" int gt_loss(const gt_config* cfg, const float* hvo, const float* y, f
 // ------------------------------------------------------------------------------------ backward
 // FFN block backward.  In: dz (grad of the pre-norm sum of the layer's last norm) and its dropout-masked
 // copy dzm.  Out: dz_prev = LNbwd_prev(dhid W1 + dz) into (dzo, dzom) for the norm in front of the FFN.
-static int ffn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, const float* dz, const float* dzm,
-                   const float* xhat_prev, const float* rstd_prev, int64_t gamma_prev, float* dzo, float* dzom, int site_prev, int gl) {
+static int ffn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const Tmp& t, const float* xin, const float* dz, const float* dzm,
+                   const float* xhat_prev, const float* rstd_prev, int64_t gamma_prev, float* dzo, float* dzom, int site_prev) {
   float* ws = x.ws;
   wgrad(x, dzm, x.d, ws + w.hact, x.F, x.grd + p.w2, x.grd + p.b2, x.d, x.F);
-  GemmArgs g = mk_gemm(dzm, x.d, x.prm + p.w2, x.F, ws + x.W.dhid, x.F, x.M, x.F, x.d);
+  GemmArgs g = mk_gemm(dzm, x.d, x.prm + p.w2, x.F, t.dhid, x.F, x.M, x.F, x.d);
   g.res = ws + w.hact; g.ldres = x.F;
   g.mask_scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
   gemm_launch<false, true, EPI_MASK_NZ>(g, x.s);
-  wgrad(x, ws + x.W.dhid, x.F, xin, x.d, x.grd + p.w1, x.grd + p.b1, x.F, x.d);
-  (void)gl;
-  return dgrad_lnbwd(x, ws + x.W.dhid, x.F, x.prm + p.w1, x.F, dz, xhat_prev, rstd_prev, gamma_prev, dzo, dzom, site_prev);
+  wgrad(x, t.dhid, x.F, xin, x.d, x.grd + p.w1, x.grd + p.b1, x.F, x.d);
+  return dgrad_lnbwd(x, t.dhid, x.F, x.prm + p.w1, x.F, dz, xhat_prev, rstd_prev, gamma_prev, dzo, dzom, site_prev);
 }
-// self-attention block backward.  In: dz1m (masked grad of the out-proj output).  Leaves dqkv in ws.
-static void self_attn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, const float* dz1m, int gl) {
+// self-attention block backward.  In: dz1m (masked grad of the out-proj output).  Leaves dqkv in the set.
+static void self_attn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const Tmp& t, const float* xin, const float* dz1m, int gl) {
   float* ws = x.ws;
   const int d = x.d;
   wgrad(x, dz1m, d, ws + w.ctx, d, x.grd + p.sa.out_w, x.grd + p.sa.out_b, d, d);
   dgrad_store(x, dz1m, d, x.prm + p.sa.out_w, d, ws + x.W.dctx, d, d, 0);
-  attention_bwd(x, ws + w.qkv, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.P, ws + x.W.dctx, ws + x.W.dqkv, 3 * d,
-                ws + x.W.dqkv + d, ws + x.W.dqkv + 2 * d, 3 * d, lsite(gl, GT_SITE_ATTN));
-  wgrad(x, ws + x.W.dqkv, 3 * d, xin, d, x.grd + p.sa.in_w, x.grd + p.sa.in_b, 3 * d, d);
+  attention_bwd(x, ws + w.qkv, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.P, ws + x.W.dctx, t.dqkv, 3 * d,
+                t.dqkv + d, t.dqkv + 2 * d, 3 * d, lsite(gl, GT_SITE_ATTN));
+  wgrad(x, t.dqkv, 3 * d, xin, d, x.grd + p.sa.in_w, x.grd + p.sa.in_b, 3 * d, d);
 }
-// grad of the InputLayer: da = (dqkv Win + dz1) * dropmask * (a0 > 0); dW = da^T in; db = colsum(da)
-static void input_layer_bwd(const Ctx& x, const LayerP& first, const float* dz1, const float* a0, const float* in, int S, int64_t w,
-                            int64_t b, int site) {
-  float* ws = x.ws;
-  GemmArgs g = mk_gemm(ws + x.W.dqkv, 3 * x.d, x.prm + first.sa.in_w, x.d, ws + x.W.dctx, x.d, x.M, x.d, 3 * x.d);
+// grad of the InputLayer: da = (dqkv Win + dz1) * dropmask * (a0 > 0) -> da_out; dW = da^T in; db = colsum(da)
+static void input_layer_bwd(const Ctx& x, const LayerP& first, const Tmp& t, const float* dz1, const float* a0, const float* in, int S,
+                            int64_t w, int64_t b, int site, float* da_out) {
+  GemmArgs g = mk_gemm(t.dqkv, 3 * x.d, x.prm + first.sa.in_w, x.d, da_out, x.d, x.M, x.d, 3 * x.d);
   g.res = dz1; g.ldres = x.d; g.aux_in = a0; g.drop = mk_drop(x, site);
   gemm_launch<false, true, EPI_ADD_RELUMASK_DROP>(g, x.s);
-  wgrad(x, ws + x.W.dctx, x.d, in, S, x.grd + w, x.grd + b, x.d, S);
+  wgrad(x, da_out, x.d, in, S, x.grd + w, x.grd + b, x.d, S);
 }
 
 // d_hvo == nullptr: ws.dlogits already holds d loss / d logits (the fused loss kernel wrote it)
@@ -516,12 +610,16 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   const WLayout& W = x.W;
   const PLayout& P = x.P;
   if (!accumulate) (void)hipMemsetAsync(grads, 0, (size_t)P.total * sizeof(float), x.s);
-  // Weight gradients are queued and leave as ONE grouped dispatch per layer (wgrad_sync), placed just before
-  // the first kernel that overwrites a buffer a queued wgrad still reads (dzA/dzAm, dhid, dqkv, ws.dctx).
+  // Weight gradients are queued and leave as ONE grouped dispatch per layer (wgrad_sync) on the side stream.  Layer gl
+  // keeps its temporaries in set gl&1; acquire_set() makes the main stream wait for the side-stream reader of a set
+  // right before the first kernel that writes into it again (two layers later).
   WgradBatch wbatch;
   x.wb = &wbatch;
-  float* dzA = ws + W.dzA; float* dzAm = x.drop ? ws + W.dzAm : dzA;
-  float* dzB = ws + W.dzB; float* dzBm = x.drop ? ws + W.dzBm : dzB;
+  x.side = side_stream();
+  LnJobs lnjobs;
+  lnjobs.n = 0; lnjobs.N = d;
+  x.ln = &lnjobs;
+  const int top = L + Ld - 1;                       // global index of the last layer
 
   // OutputLayer: dlogits, dW_out, then d(final) fused with the final norm's backward
   if (d_hvo != nullptr) {
@@ -539,69 +637,81 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   }
   // ws.dctx now holds the grad w.r.t. the last layer's output (the input of the final norm)
   if (Ld > 0) {
-    hipMemsetAsync(ws + W.dmem, 0, (size_t)M * d * sizeof(float), x.s);
+    (void)hipMemsetAsync(ws + W.dmem, 0, (size_t)M * d * sizeof(float), x.s);
     {
-      const LayerW& w = W.layers[L + Ld - 1];
-      ln_bwd(x, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.dec[Ld - 1].n3w, dzA, dzAm, lsite(L + Ld - 1, GT_SITE_DROPF));
+      const LayerW& w = W.layers[top];
+      Tmp t = tmp_set(x, top);
+      ln_bwd(x, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.dec[Ld - 1].n3w, t.dzA, t.dzAm, lsite(top, GT_SITE_DROPF));
     }
     for (int l = Ld - 1; l >= 0; --l) {
       const LayerP& p = P.dec[l];
-      const LayerW& w = W.layers[L + l];
       const int gl = L + l;
-      const float* yin = (l == 0) ? ws + W.y0 : ws + W.layers[L + l - 1].xout;
-      // FFN (+ norm3 handled by the producer of dzA) -> dz2 = LNbwd_norm2(...) in (dzB, dzBm), masked for cross out-proj
-      if (ffn_bwd(x, p, w, ws + w.x2, dzA, dzAm, ws + w.xhatx, ws + w.rstdx, p.n2w, dzB, dzBm, lsite(gl, GT_SITE_DROP2), gl)) return -1;
-      // cross attention
-      wgrad(x, dzBm, d, ws + w.ctxx, d, grads + p.xa.out_w, grads + p.xa.out_b, d, d);
-      dgrad_store(x, dzBm, d, params + p.xa.out_w, d, ws + W.dctx, d, d, 0);
-      float* dqx = ws + W.dqkv; float* dkvx = ws + W.dqkv + (int64_t)M * d;      // dq (M,d) then dkv (M,2d), both dense
+      const LayerW& w = W.layers[gl];
+      const Tmp t = tmp_set(x, gl);
+      const float* yin = (l == 0) ? ws + W.y0 : ws + W.layers[gl - 1].xout;
+      // FFN (norm3's backward was done by the producer of dzA) -> dz2 = LNbwd_norm2(...) in (dzB, dzBm)
+      if (ffn_bwd(x, p, w, t, ws + w.x2, t.dzA, t.dzAm, ws + w.xhatx, ws + w.rstdx, p.n2w, t.dzB, t.dzBm, lsite(gl, GT_SITE_DROP2))) return -1;
+      // cross attention: q from the decoder stream, k/v from the encoder memory
+      wgrad(x, t.dzBm, d, ws + w.ctxx, d, grads + p.xa.out_w, grads + p.xa.out_b, d, d);
+      dgrad_store(x, t.dzBm, d, params + p.xa.out_w, d, ws + W.dctx, d, d, 0);
+      float* dqx = t.dqkvx; float* dkvx = t.dqkvx + (int64_t)M * d;            // dq (M,d) then dkv (M,2d), both dense
       attention_bwd(x, ws + w.qx, d, ws + w.kvx, ws + w.kvx + d, 2 * d, ws + w.Px, ws + W.dctx, dqx, d, dkvx, dkvx + d, 2 * d,
                     lsite(gl, GT_SITE_XATTN));
       wgrad(x, dqx, d, ws + w.x1, d, grads + p.xa.in_w, grads + p.xa.in_b, d, d);
       wgrad(x, dkvx, 2 * d, ws + W.memory, d, grads + p.xa.in_w + (int64_t)d * d, grads + p.xa.in_b + d, 2 * d, d);
       dgrad_store(x, dkvx, 2 * d, params + p.xa.in_w + (int64_t)d * d, d, ws + W.dmem, d, 2 * d, 1);
-      wgrad_sync(x);       // the next kernel overwrites dzA/dzAm (read by the queued linear2 wgrad)
-      // dz1 = LNbwd_norm1(dqx Wq + dz2) -> (dzA, dzAm) masked for the self-attn out-proj
-      if (dgrad_lnbwd(x, dqx, d, params + p.xa.in_w, d, dzB, ws + w.xhat1, ws + w.rstd1, p.n1w, dzA, dzAm, lsite(gl, GT_SITE_DROP1)))
+      // dz1 = LNbwd_norm1(dqx Wq + dz2) -> (dzC, dzCm) masked for the self-attn out-proj
+      if (dgrad_lnbwd(x, dqx, d, params + p.xa.in_w, d, t.dzB, ws + w.xhat1, ws + w.rstd1, p.n1w, t.dzC, t.dzCm, lsite(gl, GT_SITE_DROP1)))
         return -1;
-      self_attn_bwd(x, p, w, yin, dzAm, gl);
+      self_attn_bwd(x, p, w, t, yin, t.dzCm, gl);
       if (l > 0) {
-        const LayerW& wp = W.layers[L + l - 1];
-        // NOTE: result goes to dzB then is swapped into the "A" role for the next (lower) layer
-        if (dgrad_lnbwd(x, ws + W.dqkv, 3 * d, params + p.sa.in_w, 3 * d, dzA, ws + wp.xhat2, ws + wp.rstd2, P.dec[l - 1].n3w, dzB,
-                        dzBm, lsite(gl - 1, GT_SITE_DROPF)))
+        wgrad_sync(x, gl);
+        const LayerW& wp = W.layers[gl - 1];
+        const Tmp tn = tmp_set(x, gl - 1);
+        acquire_set(x, gl - 1);
+        if (dgrad_lnbwd(x, t.dqkv, 3 * d, params + p.sa.in_w, 3 * d, t.dzC, ws + wp.xhat2, ws + wp.rstd2, P.dec[l - 1].n3w, tn.dzA,
+                        tn.dzAm, lsite(gl - 1, GT_SITE_DROPF)))
           return -1;
-        float* t = dzA; dzA = dzB; dzB = t;
-        t = dzAm; dzAm = dzBm; dzBm = t;
       } else {
-        input_layer_bwd(x, p, dzA, ws + W.b0, tgt_in, GT_TGT, P.din_w, P.din_b, GT_SITE_PE_DEC);
+        input_layer_bwd(x, p, t, t.dzC, ws + W.b0, tgt_in, GT_TGT, P.din_w, P.din_b, GT_SITE_PE_DEC, ws + W.da0_dec);
+        wgrad_sync(x, gl);
       }
-      wgrad_sync(x);       // next layer (or the encoder) overwrites dzAm / dqkv / ws.dctx
     }
     // encoder final norm backward (input: accumulated dmem) -> grad w.r.t. the last encoder layer's output
     ln_bwd(x, ws + W.dmem, ws + W.enc_xhat, ws + W.enc_rstd, P.encn_w, ws + W.dctx, nullptr, 0);
   }
   {
     const LayerW& w = W.layers[L - 1];
-    ln_bwd(x, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.enc[L - 1].n2w, dzA, dzAm, lsite(L - 1, GT_SITE_DROPF));
+    const Tmp t = tmp_set(x, L - 1);
+    acquire_set(x, L - 1);
+    ln_bwd(x, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.enc[L - 1].n2w, t.dzA, t.dzAm, lsite(L - 1, GT_SITE_DROPF));
   }
   for (int l = L - 1; l >= 0; --l) {
     const LayerP& p = P.enc[l];
     const LayerW& w = W.layers[l];
+    const Tmp t = tmp_set(x, l);
     const float* lin = (l == 0) ? ws + W.x0 : ws + W.layers[l - 1].xout;
-    if (ffn_bwd(x, p, w, ws + w.x1, dzA, dzAm, ws + w.xhat1, ws + w.rstd1, p.n1w, dzB, dzBm, lsite(l, GT_SITE_DROP1), l)) return -1;
-    self_attn_bwd(x, p, w, lin, dzBm, l);
+    if (ffn_bwd(x, p, w, t, ws + w.x1, t.dzA, t.dzAm, ws + w.xhat1, ws + w.rstd1, p.n1w, t.dzB, t.dzBm, lsite(l, GT_SITE_DROP1))) return -1;
+    self_attn_bwd(x, p, w, t, lin, t.dzBm, l);
     if (l > 0) {
-      wgrad_sync(x);       // the next kernel overwrites dzA/dzAm (read by the queued linear2 wgrad)
+      wgrad_sync(x, l);
       const LayerW& wp = W.layers[l - 1];
-      if (dgrad_lnbwd(x, ws + W.dqkv, 3 * d, params + p.sa.in_w, 3 * d, dzB, ws + wp.xhat2, ws + wp.rstd2, P.enc[l - 1].n2w, dzA, dzAm,
+      const Tmp tn = tmp_set(x, l - 1);
+      acquire_set(x, l - 1);
+      if (dgrad_lnbwd(x, t.dqkv, 3 * d, params + p.sa.in_w, 3 * d, t.dzB, ws + wp.xhat2, ws + wp.rstd2, P.enc[l - 1].n2w, tn.dzA, tn.dzAm,
                       lsite(l - 1, GT_SITE_DROPF)))
         return -1;
     } else {
-      input_layer_bwd(x, p, dzB, ws + W.a0, xin, cfg->src_dim, P.in_w, P.in_b, GT_SITE_PE_ENC);
+      input_layer_bwd(x, p, t, t.dzB, ws + W.a0, xin, cfg->src_dim, P.in_w, P.in_b, GT_SITE_PE_ENC, ws + W.dctx);
+      wgrad_sync(x, l);
     }
   }
-  wgrad_sync(x);
+  acquire_set(x, 0);                                // join: every side-stream dispatch is ordered before what follows
+  acquire_set(x, 1);
+  if (lnjobs.n > 0) {                               // all LayerNorm dgamma/dbeta of the step: one launch, fixed order
+    gt_prof_tag("ln_param_reduce", 0, 4.0 * lnjobs.n * W.ln_part_stride);
+    gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(256), x.s, lnjobs);
+  }
   return launch_status("gt_backward");
 }
 
@@ -620,14 +730,15 @@ extern "C" int gt_optimizer_step(int algo, float* params, float* grads, float* m
   const unsigned blocks = (unsigned)((n + 1023) / 1024);
   if (algo == 0) {
     gt_prof_tag("optimizer", 0, 12.0 * n);
-    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, state, zero_grads);
+    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, (const gt_step_state*)state, zero_grads);
   } else if (algo == 1) {
     if (!m || !v) return gt_fail("gt_optimizer_step: adam needs m and v");
     gt_prof_tag("optimizer", 0, 28.0 * n);
-    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, state, zero_grads);
+    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state, zero_grads);
   } else {
     return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
   }
+  gt_launch(step_inc_kernel, dim3(1), dim3(64), s, state);
   return launch_status("gt_optimizer_step");
 }
 

@@ -52,6 +52,7 @@ struct GemmArgs {
   const float* gamma; const float* beta;
   const float* xhat; const float* rstd;     // LN backward inputs (ld = N)
   float* dgamma; float* dbeta;
+  float* ln_part;            // if set: per-row-tile partials [row_tile][2][N] instead of contended atomics
   const float* pe;           // [32, N]
   float* dbias;              // EPI_ATOMIC: column sums of A over k (grad of the bias), or nullptr
   float mask_scale;
@@ -417,8 +418,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int q = 0; q < NG; ++q) { a += sG[q * CSTR + c]; b += sBt[q * CSTR + c]; }
-      atomicAdd(&g.dgamma[c], a);
-      atomicAdd(&g.dbeta[c], b);
+      if (g.ln_part) {       // 128+ workgroups adding into the same d addresses serialise at the atomic unit (~6 us):
+        g.ln_part[((size_t)by * 2) * g.N + c] = a;             // store partials, ln_param_reduce_kernel sums them later
+        g.ln_part[((size_t)by * 2 + 1) * g.N + c] = b;
+      } else {
+        atomicAdd(&g.dgamma[c], a);
+        atomicAdd(&g.dbeta[c], b);
+      }
     }
   }
 }
@@ -518,9 +524,10 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
 }
 
 // row epilogues: BN = padded d_model; 16-row tiles while they still give <= 1024 workgroups, else 32
+static inline int gemm_row_bm(int M) { return M <= 16384 ? 16 : 32; }
 template <bool AKM, bool BKM, int EPI>
 static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
-  const bool small = g.M <= 16384;
+  const bool small = gemm_row_bm(g.M) == 16;
   if (g.N <= 32) {
     g.k_chunk = (g.K + 63) / 64 * 64;
     if (small) gemm_launch_cfg<1, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
@@ -531,7 +538,8 @@ static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
     else       gemm_launch_cfg<2, 2, 1, 2, 64, AKM, BKM, EPI>(g, 1, s);
   } else if (g.N <= 128) {
     g.k_chunk = (g.K + 63) / 64 * 64;
-    if (small) gemm_launch_cfg<1, 4, 1, 2, 64, AKM, BKM, EPI>(g, 1, s);
+    g.k_chunk = (g.K + 127) / 128 * 128;
+    if (small) gemm_launch_cfg<1, 4, 1, 2, 128, AKM, BKM, EPI>(g, 1, s);
     else       gemm_launch_cfg<2, 2, 1, 4, 64, AKM, BKM, EPI>(g, 1, s);
   } else if (g.N <= 256) {
     g.k_chunk = (g.K + 31) / 32 * 32;

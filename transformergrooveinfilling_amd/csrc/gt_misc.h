@@ -32,7 +32,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      float* __restrict__ dz, float* __restrict__ dz_masked, DropArgs drop,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int N) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part,
+                                                     int M, int N) {
+  __shared__ float sred[4][2][GT_MAX_D];
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GT_LNB_ROWS;
   const float invN = 1.0f / (float)N;
@@ -69,10 +71,55 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       }
     }
   }
+  if (part == nullptr) {
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      if (c < N && row0 < M) { atomicAdd(&dgamma[c], dg[i]); atomicAdd(&dbeta[c], db[i]); }
+    }
+    return;
+  }
+  // partials per workgroup [block][2][N] (summed by ln_param_reduce_kernel): no contended atomics
+  const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < GT_MAX_D / 64; ++i) {
     const int c = lane + 64 * i;
-    if (c < N && row0 < M) { atomicAdd(&dgamma[c], dg[i]); atomicAdd(&dbeta[c], db[i]); }
+    if (c < N) { sred[w][0][c] = dg[i]; sred[w][1][c] = db[i]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < N; c += 256) {
+    part[((size_t)blockIdx.x * 2) * N + c] = sred[0][0][c] + sred[1][0][c] + sred[2][0][c] + sred[3][0][c];
+    part[((size_t)blockIdx.x * 2 + 1) * N + c] = sred[0][1][c] + sred[1][1][c] + sred[2][1][c] + sred[3][1][c];
+  }
+}
+
+// dgamma / dbeta of every LayerNorm of the step in ONE launch: job j sums its workgroup partials [nwg][2][N] in a fixed
+// order (deterministic) and adds them into the gradient buffer.  grid = (ceil(2N/64), jobs); 4 waves split the partials.
+#define GT_LN_JOBS_MAX 96
+struct LnJob { const float* part; float* dgamma; float* dbeta; int nwg; };
+struct LnJobs { int n, N; LnJob j[GT_LN_JOBS_MAX]; };
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnJobs jobs) {
+  __shared__ float s[4][64];
+  const LnJob jb = jobs.j[blockIdx.y];
+  const int N = jobs.N, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c2 = blockIdx.x * 64 + lane;                 // column in [0, 2N): gamma then beta
+  const bool ok = c2 < 2 * N;
+  const int which = (ok && c2 >= N) ? 1 : 0, c = ok ? c2 - which * N : 0;
+  float acc = 0.f;
+  for (int g0 = w; g0 < jb.nwg; g0 += 16) {              // 4 independent loads in flight per lane
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gidx = g0 + 4 * u;
+      v[u] = *((ok && gidx < jb.nwg) ? jb.part + ((size_t)gidx * 2 + which) * N + c : gt_zero_page);
+    }
+    acc += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  s[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && ok) {
+    float* dst = which ? jb.dbeta : jb.dgamma;
+    dst[c] += (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
   }
 }
 
@@ -172,18 +219,13 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
 
 // ---- optimizer: flat multi-tensor update (one launch for all 78+ tensors) -----------------------
 // zero_grads: the gradient is consumed and left zeroed (the next backward accumulates into it: no memset node).
-// The LAST workgroup to finish (ticket counter in the step state) advances step / opt_step: every workgroup
-// has read the state before it takes its ticket, so there is no separate increment launch and no race.
-__device__ static inline void gt_opt_finish(gt_step_state* st) {
-  __syncthreads();                                   // all threads of this workgroup are past their state reads
-  if (threadIdx.x == 0) {
-    unsigned* ticket = reinterpret_cast<unsigned*>(&st->pad2[1]);
-    const unsigned t = atomicAdd(ticket, 1u);
-    if (t == gridDim.x - 1) { st->step += 1u; st->opt_step += 1u; *ticket = 0u; }
-  }
+// (step / opt_step advance in step_inc_kernel: a last-workgroup ticket inside these kernels was measured SLOWER --
+// ~600 arrivals on one counter serialise for longer than the ~4 us a separate launch costs.)
+__global__ void step_inc_kernel(gt_step_state* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1u; st->opt_step += 1u; }
 }
 
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n, gt_step_state* st,
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n, const gt_step_state* st,
                                                   int zero_grads) {
   const float k = st->lr * st->grad_scale;
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -196,11 +238,10 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
   } else {
     for (int64_t j = i; j < n; ++j) { p[j] -= k * g[j]; if (zero_grads) g[j] = 0.f; }
   }
-  gt_opt_finish(st);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, gt_step_state* st, int zero_grads) {
+                                                   float* __restrict__ v, int64_t n, const gt_step_state* st, int zero_grads) {
   const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->opt_step + 1u);
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = st->lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
@@ -218,7 +259,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
       if (zero_grads) g[i] = 0.f;
     }
   }
-  gt_opt_finish(st);
 }
 
 // teacher forcing: tgt_in[b,t] = y[b,t-1], row 0 = zeros
