@@ -55,6 +55,7 @@ _SIGS = {
     "gt_predict": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),
     "gt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_overlap": (ctypes.c_int, [ctypes.c_int]),
+    "gt_set_chain": (ctypes.c_int, [ctypes.c_int]),
     "gt_profile_report": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]),
 }
 EXPORTS = tuple(_SIGS)

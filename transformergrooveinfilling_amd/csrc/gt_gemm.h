@@ -130,11 +130,10 @@ __device__ static inline float gt_red16(float v) {
 }
 
 template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, float* smem) {
   typedef GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI> Cfg;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::NT;
   constexpr int SA_STR = Cfg::SA_STR, SB_STR = Cfg::SB_STR, SA_SZ = Cfg::SA_SZ, SB_SZ = Cfg::SB_SZ;
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -176,11 +175,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     const float* sA = smem + cur * SA_SZ;
     const float* sB = smem + 2 * SA_SZ + cur * SB_SZ;
     if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
-    const int klen = kend - (kbeg + kt * BK);        // valid k in this slab (tail slabs skip zero work)
-
+    // (no tail skip: slabs are zero-filled beyond K; a branch here splits the MFMA block and hipcc then shuttles the
+    //  accumulators VGPR<->AGPR around every few MFMAs, exposing the LDS latency each time)
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      if (kk * 16 < klen) {
+      {
         float af[TM][4], bf[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -431,27 +430,38 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 
 template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
-  gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+  __shared__ __attribute__((aligned(16))) float smem[GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI>::SMEM];
+  gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // Grouped launch: up to GT_GROUP_MAX independent GEMMs of one kind in ONE dispatch (all weight gradients of a
 // layer).  A kernel boundary costs ~4 us on this machine whatever the kernel does, and each wgrad alone is too
 // small to fill 256 CUs; together they do.  Workgroup b serves problem i with start[i] <= b < start[i+1].
-#define GT_GROUP_MAX 8
+#define GT_GROUP_MAX 16
 struct GemmGroup {
   int n;
   int start[GT_GROUP_MAX + 1];
   int gx[GT_GROUP_MAX], gy[GT_GROUP_MAX];
+  int big[GT_GROUP_MAX];       // 1: 64x64 tiles (both output dims >= 64: half the staged bytes and atomics per flop), 0: 32x32
   GemmArgs p[GT_GROUP_MAX];
 };
-template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_group_kernel(GemmGroup grp) {
-  const int b = blockIdx.x;
+// weight-gradient group ("TN", fp32 atomics), 32x32 tiles.  (A 64x64-tile variant sharing the launch was measured
+// slower twice over: fewer workgroups -> longer serial slab chains, and its 70 KB of LDS halved the occupancy of the
+// 32x32 problems in the same launch.)
+__global__ __launch_bounds__(256) void wgrad_group_kernel(GemmGroup grp) {
+  typedef GemmCfg<2, 2, 1, 1, 64, true, true, EPI_ATOMIC> C32;
+  __shared__ __attribute__((aligned(16))) float smem[C32::SMEM];
+  // XCD-aware placement: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one), each with its own
+  // L2.  Give every XCD a CONTIGUOUS range of the logical tile space (tiles of one problem / one token chunk share their
+  // dY and X slabs), so each slab is pulled through the fabric once instead of once per XCD.  Placement only changes
+  // speed, never results.
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+  const int b = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
   int i = 0;
   while (i + 1 < grp.n && b >= grp.start[i + 1]) ++i;
   const int local = b - grp.start[i];
   const int bx = local % grp.gx[i], t = local / grp.gx[i];
-  gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i]);
+  gemm_body<2, 2, 1, 1, 64, true, true, EPI_ATOMIC>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i], smem);
 }
 
 // --------------------------------------------------------------------------------- host dispatch
@@ -473,8 +483,8 @@ static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s)
 
 // wgrad: the output (N_w x K_w) is small, the contraction (tokens) is long -> split it over z so that the
 // problem yields about `target` 32x32-tile workgroups.  Sets g.k_chunk, returns the split count.
-static inline int wgrad_split(GemmArgs& g, long target) {
-  const long tiles = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
+  const long tiles = (long)((g.M + tile - 1) / tile) * ((g.N + tile - 1) / tile);
   long want = (target + tiles - 1) / tiles;
   const long maxs = (g.K + 127) / 128;
   if (want > maxs) want = maxs;
@@ -494,16 +504,19 @@ struct WgradBatch {
 static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) {
   if (wb.grp.n == 0) return;
   gt_prof_tag("gemm_wgrad", wb.flops, wb.bytes);
-  gt_launch(gemm_group_kernel<2, 2, 1, 1, 64, true, true, EPI_ATOMIC>, dim3(wb.grp.start[wb.grp.n]), dim3(256), s, wb.grp);
+  gt_launch(wgrad_group_kernel, dim3(wb.grp.start[wb.grp.n]), dim3(256), s, wb.grp);
   wb.grp.n = 0; wb.flops = wb.bytes = 0;
 }
 static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   if (wb.grp.n == GT_GROUP_MAX) wgrad_flush(wb, s);
-  const int splitk = wgrad_split(g, 512);
+  // 64x64 tiles were measured SLOWER here (r01i: 23.7 vs 20.4 us per group): fewer workgroups -> longer serial slab chains
+  const int big = 0, tile = big ? 64 : 32;
+  const int splitk = wgrad_split(g, big ? 256 : 512, tile);
   const int i = wb.grp.n++;
   wb.grp.p[i] = g;
-  wb.grp.gx[i] = (g.N + 31) / 32;
-  wb.grp.gy[i] = (g.M + 31) / 32;
+  wb.grp.big[i] = big;
+  wb.grp.gx[i] = (g.N + tile - 1) / tile;
+  wb.grp.gy[i] = (g.M + tile - 1) / tile;
   wb.grp.start[i + 1] = wb.grp.start[i] + wb.grp.gx[i] * wb.grp.gy[i] * splitk;
   wb.flops += 2.0 * g.M * g.N * g.K;
   wb.bytes += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
