@@ -146,8 +146,9 @@ int gt_profile_enable(int on);
  * the backward chain; recorded as fork/join edges when the call is being captured into a hipGraph.  off (default;
  * env GT_OVERLAP=1 switches the default): a single stream -- measured faster on ROCm 7.2, see DESIGN.md. */
 int gt_set_overlap(int on);
-/* on (default): encoder-only models with d_model <= 256 and dim_feedforward <= 512 run on the fused row-chain kernels
- * (one launch per layer and direction besides attention); off: one kernel per op (the path every other shape takes). */
+/* on: encoder-only models with d_model <= 256 and dim_feedforward <= 512 run on the fused row-chain kernels (one launch
+ * per layer and direction besides attention; wave-specialised loader / MFMA waves).  off (default; env GT_CHAIN=1
+ * switches the default): one kernel per op -- currently the faster path at the headline size, see DESIGN.md. */
 int gt_set_chain(int on);
 int gt_profile_report(char* buf, size_t buf_len, int max_rows);
 

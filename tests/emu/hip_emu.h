@@ -52,6 +52,11 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
 void block_sync();
 float wave_shfl(float v, int src_lane);
 f32x4 mfma16(float a, float b, f32x4 c);
+// global_load_lds_dwordx4: lane i of the wave writes its 16 bytes at (wave-uniform LDS base) + i*16
+static inline void glds16(const void* g, void* lds_base) {
+  int lane = (threadIdx_.x + threadIdx_.y * blockDim_.x) & 63;
+  memcpy((char*)lds_base + lane * 16, g, 16);
+}
 }  // namespace emu
 
 #define threadIdx emu::threadIdx_
@@ -84,7 +89,7 @@ unsigned char* dyn_smem_ = nullptr;
 
 namespace {
 enum { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
-struct Fiber { ucontext_t ctx; char* stack; int state; };
+struct Fiber { ucontext_t ctx; char* stack; int state; long nbar; };
 constexpr size_t kStack = 256 * 1024;
 std::vector<Fiber> fibers;
 ucontext_t sched_ctx;
@@ -111,6 +116,7 @@ void run_block() {
     f.ctx.uc_stack.ss_size = kStack;
     f.ctx.uc_link = &sched_ctx;
     f.state = RUN;
+    f.nbar = 0;
     makecontext(&f.ctx, trampoline, 0);
   }
   int nwaves = (nthreads + 63) / 64;
@@ -124,7 +130,16 @@ void run_block() {
       swapcontext(&sched_ctx, &fibers[t].ctx);
       ++progressed;
     }
-    if (done == nthreads) break;
+    if (done == nthreads) {
+      // hardware counts exited waves out of a barrier, so a mismatch would not hang -- it would silently mis-synchronise
+      for (int t = 1; t < nthreads; ++t)
+        if (fibers[t].nbar != fibers[0].nbar) {
+          fprintf(stderr, "hip_emu: threads of one workgroup executed different numbers of barriers (%ld vs %ld, thread %d)\n",
+                  fibers[0].nbar, fibers[t].nbar, t);
+          abort();
+        }
+      break;
+    }
     // release barriers whose participants have all arrived
     int wb = 0, live = 0;
     for (int t = 0; t < nthreads; ++t) {
@@ -156,7 +171,7 @@ void run_block() {
 void wave_sync() { fibers[cur].state = WAIT_WAVE; yield_to_sched(); }
 }  // namespace
 
-void block_sync() { fibers[cur].state = WAIT_BLOCK; yield_to_sched(); }
+void block_sync() { fibers[cur].state = WAIT_BLOCK; ++fibers[cur].nbar; yield_to_sched(); }
 
 float wave_shfl(float v, int src_lane) {
   int w = cur / 64, l = cur % 64;

@@ -55,9 +55,10 @@ def cfg_dict(d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_
 class Runner:
     """One model instance behind the C ABI.  backend = 'emu' | 'hip'."""
 
-    def __init__(self, cfg, B, backend="emu", rng=(1234, 99, 0), lr=0.094):
+    def __init__(self, cfg, B, backend="emu", rng=(1234, 99, 0), lr=0.094, chain=False):
         self.cfgd, self.B, self.backend = cfg, B, backend
         self.lib = emu_lib() if backend == "emu" else _lib.get_lib()
+        self.lib.cdll.gt_set_chain(int(chain))          # process-global switch: fused row-chain kernels on / off
         self.Buf = NpBuf if backend == "emu" else CudaBuf
         self.c = _lib.make_config(B, cfg["embedding_size_src"], cfg["d_model"], cfg["n_heads"], cfg["dim_feedforward"],
                                   cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0), cfg.get("dropout", 0.0))

@@ -29,6 +29,17 @@ def test_step_parity(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 
 
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 5, 0.25), (C1, 32, 0.18), (YAML_HH, 16, 0.24), (SYM, 3, 0.1), (C2, 64, 0.24), (YAML_KS, 4, 0.3),
+                                     (cfg_dict(16, 16, 16, 1), 1, 0.0)])
+def test_step_parity_row_chain_kernels(cfg, B, p):
+    """the opt-in fused row-chain kernels (GT_CHAIN=1): same parity bar as the default one-kernel-per-op path"""
+    parity.check_step("hip", cfg, B, p, chain=True)
+
+
+def test_train_step_row_chain_kernels():
+    parity.check_train_step("hip", C2, 16, 0.24, chain=True)
+
+
 @pytest.mark.parametrize("path", parity.golden_files())
 def test_golden_vectors(path):
     parity.check_golden("hip", path)

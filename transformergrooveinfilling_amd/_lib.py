@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "lib", "libgroove_hip.so")
+DEFAULT_LIB = os.environ.get("GT_LIB_PATH") or os.path.join(_HERE, "lib", "libgroove_hip.so")   # GT_LIB_PATH: experiments only
 
 GT_T = 32
 GT_TGT = 27

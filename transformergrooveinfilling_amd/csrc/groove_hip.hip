@@ -268,12 +268,15 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   return 0;
 }
 
-// Row-chain kernels (gt_chain.h) serve encoder-only models with d_model <= 256 and dim_feedforward <= 512 (every
-// shipped YAML and BASELINE configs[0..1]); GT_CHAIN=0 / gt_set_chain(0) forces the one-kernel-per-op path.
+// Row-chain kernels (gt_chain.h) can serve encoder-only models with d_model <= 256 and dim_feedforward <= 512 (every
+// shipped YAML and BASELINE configs[0..1]).  They are OPT-IN (GT_CHAIN=1 / gt_set_chain(1)): parity-green, but at the
+// headline size (128 row tiles on 256 CUs, 768 KB of weights streamed per workgroup) still slower than one kernel per op
+// -- 476 vs ~430 us per step, r01s in profiles/ -- because a CU's global->LDS rate (~140 cycles per 1 KB load
+// instruction) bounds a 16-row tile well below its MFMA rate.
 static int g_chain = -1;
 extern "C" int gt_set_chain(int on) { g_chain = on != 0; return 0; }
 static int chain_enabled() {
-  if (g_chain < 0) { const char* e = getenv("GT_CHAIN"); g_chain = (e && e[0] == '0') ? 0 : 1; }
+  if (g_chain < 0) { const char* e = getenv("GT_CHAIN"); g_chain = (e && e[0] == '1') ? 1 : 0; }
   return g_chain;
 }
 
@@ -512,7 +515,7 @@ static bool use_chain(const Ctx& x) { return x.c.n_dec_layers == 0 && chain_supp
 
 template <typename Args>
 static void chain_launch(void (*k64)(Args), void (*k128)(Args), void (*k256)(Args), const Ctx& x, const Args& a) {
-  const dim3 grid((x.M + 15) / 16), block(256);
+  const dim3 grid((x.M + 15) / 16), block(512);       // 4 compute + 4 loader waves
   const int dp = chain_dpad(x.d);
   if (dp == 64) gt_launch(k64, grid, block, x.s, a);
   else if (dp == 128) gt_launch(k128, grid, block, x.s, a);
@@ -920,3 +923,4 @@ extern "C" int gt_predict(const gt_config* cfg, const float* params, const float
   }
   return launch_status("gt_predict");
 }
+

@@ -24,11 +24,11 @@ struct AttnArgs {
   float* dq; float* dk; float* dv; int lddq, lddk, lddv;
 };
 
-__device__ static inline void attn_load_slab(float (*s)[33], const float* src, int ld, int b, int h, int hd, int c0, int tid) {
+__device__ static inline void attn_load_slab(float (*s)[33], const float* src, int ld, int b, int h, int hd, int c0, int tid, const float* zp) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = tid + 256 * u, r = e >> 5, c = e & 31;
-    const float* p = (c0 + c < hd) ? src + ((size_t)(b * 32 + r) * ld + h * hd + c0 + c) : gt_zero_page;   // branch-free
+    const float* p = (c0 + c < hd) ? src + ((size_t)(b * 32 + r) * ld + h * hd + c0 + c) : zp;   // branch-free
     s[r][c] = *p;
   }
 }
@@ -37,10 +37,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   __shared__ float sq[32][33], sk[32][33], sp[32][33];
   const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int i = tid >> 3, jg = tid & 7;
+  const float* const zp = gt_zero_ptr();
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < a.hd; c0 += 32) {
-    attn_load_slab(sq, a.q, a.ldq, b, h, a.hd, c0, tid);
-    attn_load_slab(sk, a.k, a.ldk, b, h, a.hd, c0, tid);
+    attn_load_slab(sq, a.q, a.ldq, b, h, a.hd, c0, tid, zp);
+    attn_load_slab(sk, a.k, a.ldk, b, h, a.hd, c0, tid, zp);
     __syncthreads();
 #pragma unroll 8
     for (int c = 0; c < 32; ++c) {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   }
   __syncthreads();
   for (int c0 = 0; c0 < a.hd; c0 += 32) {
-    attn_load_slab(sk, a.v, a.ldv, b, h, a.hd, c0, tid);
+    attn_load_slab(sk, a.v, a.ldv, b, h, a.hd, c0, tid, zp);
     __syncthreads();
     float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   __shared__ float sa[32][33], sb[32][33], sds[32][33], spd[32][33];
   const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int i = tid >> 3, jg = tid & 7;
+  const float* const zp = gt_zero_ptr();
   const uint32_t dkey = gt_drop_key(a.drop);
   float p[4], mk[4], dp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     spd[i][j] = p[jj] * mk[jj];
   }
   for (int c0 = 0; c0 < a.hd; c0 += 32) {
-    attn_load_slab(sa, a.dctx, a.lddc, b, h, a.hd, c0, tid);
-    attn_load_slab(sb, a.v, a.ldv, b, h, a.hd, c0, tid);
+    attn_load_slab(sa, a.dctx, a.lddc, b, h, a.hd, c0, tid, zp);
+    attn_load_slab(sb, a.v, a.ldv, b, h, a.hd, c0, tid, zp);
     __syncthreads();
 #pragma unroll 8
     for (int c = 0; c < 32; ++c) {
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   __syncthreads();
   // here thread (i, jg) produces rows "i" of dq and rows "j = i" of dk / dv, columns jg + 8*cc
   for (int c0 = 0; c0 < a.hd; c0 += 32) {
-    attn_load_slab(sa, a.dctx, a.lddc, b, h, a.hd, c0, tid);
-    attn_load_slab(sb, a.k, a.ldk, b, h, a.hd, c0, tid);
+    attn_load_slab(sa, a.dctx, a.lddc, b, h, a.hd, c0, tid, zp);
+    attn_load_slab(sb, a.k, a.ldk, b, h, a.hd, c0, tid, zp);
     __syncthreads();
     float odv[4] = {0.f, 0.f, 0.f, 0.f}, odq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
-    attn_load_slab(sa, a.q, a.ldq, b, h, a.hd, c0, tid);
+    attn_load_slab(sa, a.q, a.ldq, b, h, a.hd, c0, tid, zp);
     __syncthreads();
     float odk[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8

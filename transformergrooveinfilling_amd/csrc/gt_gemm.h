@@ -65,6 +65,7 @@ struct TileStage {
   static constexpr int CH = ROWS * CPR;
   static constexpr int PER = (CH + NT - 1) / NT;
   float4 v[PER];
+  const float* zp;           // gt_zero_ptr() of the enclosing kernel
   // Branch-free staging: every lane ALWAYS issues its loads (out-of-range chunks read gt_zero_page).  A guarded `if (ok) t = load` makes hipcc branch around each load
   // and wait vmcnt(0) per element -- one serialized L2 round trip per chunk (cdna_hip_programming.md 5,
   // trap (c)); measured here as ~3.7 us per 64-wide slab before this form.
@@ -77,7 +78,7 @@ struct TileStage {
         const int r = ch / CPR, c = (ch % CPR) * 4;
         const int gr = r0 + r, gc = c0 + c;
         const bool ok = (CH % NT == 0 || ch < CH) && gr < rmax && gc < cmax;
-        const float* p = ok ? src + ((size_t)gr * ld + gc) : gt_zero_page;
+        const float* p = ok ? src + ((size_t)gr * ld + gc) : zp;
         v[i] = *reinterpret_cast<const float4*>(p);
       }
     } else {
@@ -88,10 +89,10 @@ struct TileStage {
         const int gr = r0 + r, gc = c0 + c;
         const bool okr = (CH % NT == 0 || ch < CH) && gr < rmax;
         const float* base = src + ((size_t)gr * ld + gc);
-        const float* p0 = (okr && gc < cmax) ? base : gt_zero_page;
-        const float* p1 = (okr && gc + 1 < cmax) ? base + 1 : gt_zero_page;
-        const float* p2 = (okr && gc + 2 < cmax) ? base + 2 : gt_zero_page;
-        const float* p3 = (okr && gc + 3 < cmax) ? base + 3 : gt_zero_page;
+        const float* p0 = (okr && gc < cmax) ? base : zp;
+        const float* p1 = (okr && gc + 1 < cmax) ? base + 1 : zp;
+        const float* p2 = (okr && gc + 2 < cmax) ? base + 2 : zp;
+        const float* p3 = (okr && gc + 3 < cmax) ? base + 3 : zp;
         v[i] = make_float4(*p0, *p1, *p2, *p3);
       }
     }
@@ -152,8 +153,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const float* const zp = gt_zero_ptr();
   TileStage<Cfg::SA_ROWS, AKM ? BM : BK, NT> la;
   TileStage<Cfg::SB_ROWS, BKM ? BN : BK, NT> lb;
+  la.zp = zp; lb.zp = zp;
   float bsum = 0.f;   // EPI_ATOMIC: bias-grad partial (column sum of the A slab)
 
   auto load_tiles = [&](int k0) {
@@ -230,7 +233,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   // against gt_zero_page for out-of-range elements) into registers, so all loads are in flight together;
   // (2) compute + predicated stores.  Guarded per-element loads would serialise one L2 round trip each.
   const uint32_t dkey = gt_drop_key(g.drop);
-  auto ldg = [](const float* p, size_t idx, bool ok) -> float { return *(ok ? p + idx : gt_zero_page); };
+  auto ldg = [zp](const float* p, size_t idx, bool ok) -> float { return *(ok ? p + idx : zp); };
 
   if (!Cfg::ROW) {
     if (EPI == EPI_ATOMIC && AKM) {
@@ -522,6 +525,9 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   wb.bytes += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
 }
 
+#ifndef GT_T64_MIN
+#define GT_T64_MIN 256
+#endif
 // standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
 template <bool AKM, bool BKM, int EPI>
 static inline void gemm_launch(GemmArgs g, hipStream_t s) {
@@ -532,7 +538,7 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
     return;
   }
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-  if (t64 >= 256) gemm_launch_cfg<2, 2, 2, 2, 64, AKM, BKM, EPI>(g, 1, s);
+  if (t64 >= GT_T64_MIN) gemm_launch_cfg<2, 2, 2, 2, 64, AKM, BKM, EPI>(g, 1, s);
   else            gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
 }
 

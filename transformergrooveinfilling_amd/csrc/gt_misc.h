@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GT_LNB_ROWS;
   const float invN = 1.0f / (float)N;
   const uint32_t dkey = gt_drop_key(drop);
+  const float* const zp = gt_zero_ptr();
   float dg[GT_MAX_D / 64], db[GT_MAX_D / 64];
 #pragma unroll
   for (int i = 0; i < GT_MAX_D / 64; ++i) { dg[i] = 0.f; db[i] = 0.f; }
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < GT_MAX_D / 64; ++i) {          // all loads first, branch-free (address select)
       const int c = lane + 64 * i;
       const bool ok = c < N;
-      d[i] = *(ok ? dy + (size_t)row * N + c : gt_zero_page);
-      xh[i] = *(ok ? xhat + (size_t)row * N + c : gt_zero_page);
-      ga[i] = *(ok ? gamma + c : gt_zero_page);
+      d[i] = *(ok ? dy + (size_t)row * N + c : zp);
+      xh[i] = *(ok ? xhat + (size_t)row * N + c : zp);
+      ga[i] = *(ok ? gamma + c : zp);
     }
 #pragma unroll
     for (int i = 0; i < GT_MAX_D / 64; ++i) {
@@ -101,6 +102,7 @@ struct LnJobs { int n, N; LnJob j[GT_LN_JOBS_MAX]; };
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnJobs jobs) {
   __shared__ float s[4][64];
   const LnJob jb = jobs.j[blockIdx.y];
+  const float* const zp = gt_zero_ptr();
   const int N = jobs.N, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c2 = blockIdx.x * 64 + lane;                 // column in [0, 2N): gamma then beta
   const bool ok = c2 < 2 * N;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnJobs jobs) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int gidx = g0 + 4 * u;
-      v[u] = *((ok && gidx < jb.nwg) ? jb.part + ((size_t)gidx * 2 + which) * N + c : gt_zero_page);
+      v[u] = *((ok && gidx < jb.nwg) ? jb.part + ((size_t)gidx * 2 + which) * N + c : zp);
     }
     acc += (v[0] + v[1]) + (v[2] + v[3]);
   }
