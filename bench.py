@@ -129,6 +129,14 @@ def main():
         cnt, ms, fl, by = dom[1]
         achieved = (fl / cnt) / (ms / cnt * 1e-3) / 1e12 if ms > 0 else 0.0
         tot_ms = sum(v[1] for v in prof.values())
+        # HBM-side bytes per launch of that kernel class: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+        # workload (separate runs, see profiles/README.md), gfx950-corrected; null if the class was not measured
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = json.load(f)["classes"][dom[0]]["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "HVO sequences/sec (32-step, d_model=128) per train step", "value": seq_s, "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -137,7 +145,7 @@ def main():
                                    "dim_feedforward=512, bs=64 per GPU, dropout=0.24, SGD lr=0.07, hit_loss_penalty=0.38, S=16, encoder-only",
                        "global_batch": world * BATCH, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                          "launches_per_step": cnt / 20.0, "avg_launch_us": 1e3 * ms / cnt,
                          "flops_per_launch": fl / cnt, "share_of_kernel_time": ms / tot_ms},
             "step_roofline": {"f_train_mflop_per_seq": ftrain / 1e6, "achieved_tflops": seq_s * ftrain / 1e12,
