@@ -36,6 +36,15 @@ def test_step_parity_row_chain_kernels(cfg, B, p):
     parity.check_step("hip", cfg, B, p, chain=True)
 
 
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(32, 4, 16, 1), 256, 0.1), (cfg_dict(64, 4, 64, 1), 256, 0.2), (cfg_dict(128, 4, 512, 1), 256, 0.24),
+                                     (cfg_dict(256, 2, 512, 1), 256, 0.3), (cfg_dict(512, 8, 512, 1), 256, 0.15),
+                                     (cfg_dict(256, 2, 512, 1, 1), 256, 0.1)])
+def test_step_parity_large_batches(cfg, B, p):
+    """M = 8192 tokens: the 32-row LayerNorm-row tiles of every padded width and the 64x64-tile weight-gradient
+    group (mixed with 32x32-tile problems in one backward) -- tile choices the small cases never reach"""
+    parity.check_step("hip", cfg, B, p)
+
+
 def test_train_step_row_chain_kernels():
     parity.check_train_step("hip", C2, 16, 0.24, chain=True)
 

@@ -1,0 +1,57 @@
+"""Step time of the HIP path for other shapes than the headline workload (C1..C4, the shipped YAML shapes).
+usage: python tools/shape_bench.py [--steps 100]   (one GPU)"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from oracle import numpy_groove as ng  # noqa: E402
+from transformergrooveinfilling_amd.engine import StepEngine  # noqa: E402
+
+SHAPES = [
+    ("C1 HH_testing yaml d32/H4/F16/L6 bs32", dict(d_model=32, n_heads=4, dim_feedforward=16, num_encoder_layers=6, num_decoder_layers=0, dropout=0.18), 32),
+    ("ClosedHH yaml d32/H16/F512/L6 bs16", dict(d_model=32, n_heads=16, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.24), 16),
+    ("C2 d128/H4/F512/L3 bs64", dict(d_model=128, n_heads=4, dim_feedforward=512, num_encoder_layers=3, num_decoder_layers=0, dropout=0.24), 64),
+    ("C2 shape bs256", dict(d_model=128, n_heads=4, dim_feedforward=512, num_encoder_layers=3, num_decoder_layers=0, dropout=0.24), 256),
+    ("K&S/Random yaml d256/H2/F512/L6 bs32", dict(d_model=256, n_heads=2, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3), 32),
+    ("C3 enc-dec d256/H2/F512/L6+6 bs256", dict(d_model=256, n_heads=2, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=6, dropout=0.3), 256),
+    ("C4 d512/H8/F512/L6 bs64 (per-GPU share of 512)", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3), 64),
+    ("C4 d512/H8/F512/L6 bs512", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3), 512),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--only", type=int, default=-1, help="index of the single shape to run")
+    args = ap.parse_args()
+    for i, (name, dims, B) in enumerate(SHAPES):
+        if args.only >= 0 and i != args.only:
+            continue
+        dims = dict(dims, embedding_size_src=16)
+        eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=1, **dims)
+        eng.load_named(ng.init_params(dims, seed=0))
+        x, y = ng.synthetic_batch(B, 16, seed=2)
+        eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))
+        for _ in range(10):
+            eng.train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.train_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        ft = bench.f_train_per_seq(dims)
+        print("%-50s %8.3f ms/step %10.0f seq/s %7.2f TFLOP/s (%.1f %% of fp32 MFMA peak)  loss %.3f" %
+              (name, 1e3 * dt, B / dt, B / dt * ft / 1e12, 100 * B / dt * ft / 1e12 / 157.3, float(eng.stats[0])), flush=True)
+        del eng
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

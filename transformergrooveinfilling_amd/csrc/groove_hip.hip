@@ -379,7 +379,7 @@ extern "C" int gt_set_overlap(int on) { g_overlap = on != 0; return 0; }
 // launch everything queued so far for the layer whose temporaries live in set `set` (call after the last producer of a
 // queued wgrad's inputs has been enqueued)
 static void wgrad_sync(Ctx& x, int set) {
-  if (!x.wb || x.wb->grp.n == 0) return;
+  if (!x.wb || x.wb->empty()) return;
 #ifndef GT_EMU
   if (x.side && !g_prof.on) {
     hipEvent_t ready = next_event(), done = next_event();

@@ -448,12 +448,15 @@ struct GemmGroup {
   int big[GT_GROUP_MAX];       // 1: 64x64 tiles (both output dims >= 64: half the staged bytes and atomics per flop), 0: 32x32
   GemmArgs p[GT_GROUP_MAX];
 };
-// weight-gradient group ("TN", fp32 atomics), 32x32 tiles.  (A 64x64-tile variant sharing the launch was measured
-// slower twice over: fewer workgroups -> longer serial slab chains, and its 70 KB of LDS halved the occupancy of the
-// 32x32 problems in the same launch.)
+// weight-gradient group ("TN", fp32 atomics).  TM = 1: 32x32 tiles -- small problems, where the number of workgroups
+// matters most (64x64 tiles were measured slower at M = 2048, twice: fewer workgroups -> longer serial slab chains).
+// TM = 2: 64x64 tiles -- large problems (d_model 512, thousands of tokens), where 32x32 tiles are bound by staged bytes
+// and atomics per flop (38 % of the C4 step before the split).  The two sizes go out as SEPARATE launches: sharing one,
+// the 70 KB of LDS of the large tiles halved the occupancy of the small ones.
+template <int TM>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(GemmGroup grp) {
-  typedef GemmCfg<2, 2, 1, 1, 64, true, true, EPI_ATOMIC> C32;
-  __shared__ __attribute__((aligned(16))) float smem[C32::SMEM];
+  typedef GemmCfg<2, 2, TM, TM, 64, true, true, EPI_ATOMIC> C;
+  __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
   // XCD-aware placement: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one), each with its own
   // L2.  Give every XCD a CONTIGUOUS range of the logical tile space (tiles of one problem / one token chunk share their
   // dY and X slabs), so each slab is pulled through the fabric once instead of once per XCD.  Placement only changes
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(GemmGroup grp) {
   while (i + 1 < grp.n && b >= grp.start[i + 1]) ++i;
   const int local = b - grp.start[i];
   const int bx = local % grp.gx[i], t = local / grp.gx[i];
-  gemm_body<2, 2, 1, 1, 64, true, true, EPI_ATOMIC>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i], smem);
+  gemm_body<2, 2, TM, TM, 64, true, true, EPI_ATOMIC>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i], smem);
 }
 
 // --------------------------------------------------------------------------------- host dispatch
@@ -489,7 +492,7 @@ static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s)
 static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
   const long tiles = (long)((g.M + tile - 1) / tile) * ((g.N + tile - 1) / tile);
   long want = (target + tiles - 1) / tiles;
-  const long maxs = (g.K + 127) / 128;
+  const long maxs = tile >= 64 ? (g.K + 255) / 256 : (g.K + 127) / 128;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   int chunk = (int)((g.K + want - 1) / want);
@@ -498,31 +501,37 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
   return (g.K + chunk - 1) / chunk;
 }
 
-// all weight gradients queued since the last flush go out as ONE grouped dispatch
+// all weight gradients queued since the last flush go out as (at most) two grouped dispatches, one per tile size
 struct WgradBatch {
-  GemmGroup grp;
-  double flops, bytes;
-  WgradBatch() { grp.n = 0; grp.start[0] = 0; flops = bytes = 0; }
+  GemmGroup grp[2];            // [0]: 32x32-tile problems, [1]: 64x64
+  double flops[2], bytes[2];
+  WgradBatch() { for (int k = 0; k < 2; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
+  bool empty() const { return grp[0].n == 0 && grp[1].n == 0; }
 };
-static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) {
-  if (wb.grp.n == 0) return;
-  gt_prof_tag("gemm_wgrad", wb.flops, wb.bytes);
-  gt_launch(wgrad_group_kernel, dim3(wb.grp.start[wb.grp.n]), dim3(256), s, wb.grp);
-  wb.grp.n = 0; wb.flops = wb.bytes = 0;
+static inline void wgrad_flush_one(WgradBatch& wb, int k, hipStream_t s) {
+  GemmGroup& G = wb.grp[k];
+  if (G.n == 0) return;
+  gt_prof_tag("gemm_wgrad", wb.flops[k], wb.bytes[k]);
+  if (k == 0) gt_launch(wgrad_group_kernel<1>, dim3(G.start[G.n]), dim3(256), s, G);
+  else        gt_launch(wgrad_group_kernel<2>, dim3(G.start[G.n]), dim3(256), s, G);
+  G.n = 0; wb.flops[k] = wb.bytes[k] = 0;
 }
+static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) { wgrad_flush_one(wb, 0, s); wgrad_flush_one(wb, 1, s); }
 static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
-  if (wb.grp.n == GT_GROUP_MAX) wgrad_flush(wb, s);
-  // 64x64 tiles were measured SLOWER here (r01i: 23.7 vs 20.4 us per group): fewer workgroups -> longer serial slab chains
-  const int big = 0, tile = big ? 64 : 32;
-  const int splitk = wgrad_split(g, big ? 256 : 512, tile);
-  const int i = wb.grp.n++;
-  wb.grp.p[i] = g;
-  wb.grp.big[i] = big;
-  wb.grp.gx[i] = (g.N + tile - 1) / tile;
-  wb.grp.gy[i] = (g.M + tile - 1) / tile;
-  wb.grp.start[i + 1] = wb.grp.start[i] + wb.grp.gx[i] * wb.grp.gy[i] * splitk;
-  wb.flops += 2.0 * g.M * g.N * g.K;
-  wb.bytes += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+  // large: 64x64 tiles over >= 256-token chunks still yield >= 512 workgroups (C2: 16 tiles x 8 chunks -> stays 32x32)
+  const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  const int big = (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= 512) ? 1 : 0, tile = big ? 64 : 32;
+  if (wb.grp[big].n == GT_GROUP_MAX) wgrad_flush_one(wb, big, s);
+  const int splitk = wgrad_split(g, big ? 1024 : 512, tile);
+  GemmGroup& G = wb.grp[big];
+  const int i = G.n++;
+  G.p[i] = g;
+  G.big[i] = big;
+  G.gx[i] = (g.N + tile - 1) / tile;
+  G.gy[i] = (g.M + tile - 1) / tile;
+  G.start[i + 1] = G.start[i] + G.gx[i] * G.gy[i] * splitk;
+  wb.flops[big] += 2.0 * g.M * g.N * g.K;
+  wb.bytes[big] += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
 }
 
 #ifndef GT_T64_MIN
@@ -542,8 +551,12 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   else            gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
 }
 
-// row epilogues: BN = padded d_model; 16-row tiles while they still give <= 1024 workgroups, else 32
-static inline int gemm_row_bm(int M) { return M <= 16384 ? 16 : 32; }
+// row epilogues: BN = padded d_model.  16-row tiles while the problem is small (M = 2048 gives only 128 of them); 32-row
+// tiles (twice the flops per staged weight byte) once they still yield >= 256 workgroups
+#ifndef GT_ROW_BM32_MIN
+#define GT_ROW_BM32_MIN 8192
+#endif
+static inline int gemm_row_bm(int M) { return M < GT_ROW_BM32_MIN ? 16 : 32; }
 template <bool AKM, bool BKM, int EPI>
 static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
   const bool small = gemm_row_bm(g.M) == 16;
