@@ -455,7 +455,8 @@ struct GemmGroup {
 // the 70 KB of LDS of the large tiles halved the occupancy of the small ones.
 template <int TM>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(GemmGroup grp) {
-  typedef GemmCfg<2, 2, TM, TM, 64, true, true, EPI_ATOMIC> C;
+  constexpr int BK = TM == 4 ? 32 : 64;            // 128x128 tiles: 32-token slabs (68 KB of LDS, two workgroups per CU)
+  typedef GemmCfg<2, 2, TM, TM, BK, true, true, EPI_ATOMIC> C;
   __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
   // XCD-aware placement: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one), each with its own
   // L2.  Give every XCD a CONTIGUOUS range of the logical tile space (tiles of one problem / one token chunk share their
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(GemmGroup grp) {
   while (i + 1 < grp.n && b >= grp.start[i + 1]) ++i;
   const int local = b - grp.start[i];
   const int bx = local % grp.gx[i], t = local / grp.gx[i];
-  gemm_body<2, 2, TM, TM, 64, true, true, EPI_ATOMIC>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i], smem);
+  gemm_body<2, 2, TM, TM, BK, true, true, EPI_ATOMIC>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i], smem);
 }
 
 // --------------------------------------------------------------------------------- host dispatch
@@ -492,7 +493,7 @@ static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s)
 static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
   const long tiles = (long)((g.M + tile - 1) / tile) * ((g.N + tile - 1) / tile);
   long want = (target + tiles - 1) / tiles;
-  const long maxs = tile >= 64 ? (g.K + 255) / 256 : (g.K + 127) / 128;
+  const long maxs = tile >= 128 ? (g.K + 511) / 512 : tile >= 64 ? (g.K + 255) / 256 : (g.K + 127) / 128;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   int chunk = (int)((g.K + want - 1) / want);
@@ -501,41 +502,51 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
   return (g.K + chunk - 1) / chunk;
 }
 
-// all weight gradients queued since the last flush go out as (at most) two grouped dispatches, one per tile size
+// all weight gradients queued since the last flush go out as (at most) three grouped dispatches, one per tile size
+#ifndef GT_WGRAD_T128_MIN
+#define GT_WGRAD_T128_MIN 512
+#endif
 struct WgradBatch {
-  GemmGroup grp[2];            // [0]: 32x32-tile problems, [1]: 64x64
-  double flops[2], bytes[2];
-  WgradBatch() { for (int k = 0; k < 2; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
-  bool empty() const { return grp[0].n == 0 && grp[1].n == 0; }
+  GemmGroup grp[3];            // [0]: 32x32-tile problems, [1]: 64x64, [2]: 128x128
+  double flops[3], bytes[3];
+  WgradBatch() { for (int k = 0; k < 3; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
+  bool empty() const { return grp[0].n == 0 && grp[1].n == 0 && grp[2].n == 0; }
 };
 static inline void wgrad_flush_one(WgradBatch& wb, int k, hipStream_t s) {
   GemmGroup& G = wb.grp[k];
   if (G.n == 0) return;
   gt_prof_tag("gemm_wgrad", wb.flops[k], wb.bytes[k]);
-  if (k == 0) gt_launch(wgrad_group_kernel<1>, dim3(G.start[G.n]), dim3(256), s, G);
-  else        gt_launch(wgrad_group_kernel<2>, dim3(G.start[G.n]), dim3(256), s, G);
+  if (k == 0)      gt_launch(wgrad_group_kernel<1>, dim3(G.start[G.n]), dim3(256), s, G);
+  else if (k == 1) gt_launch(wgrad_group_kernel<2>, dim3(G.start[G.n]), dim3(256), s, G);
+  else             gt_launch(wgrad_group_kernel<4>, dim3(G.start[G.n]), dim3(256), s, G);
   G.n = 0; wb.flops[k] = wb.bytes[k] = 0;
 }
-static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) { wgrad_flush_one(wb, 0, s); wgrad_flush_one(wb, 1, s); }
+static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) { for (int k = 0; k < 3; ++k) wgrad_flush_one(wb, k, s); }
 static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
-  // large: 64x64 tiles over >= 256-token chunks still yield >= 512 workgroups (C2: 16 tiles x 8 chunks -> stays 32x32)
-  const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-  const int big = (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= 512) ? 1 : 0, tile = big ? 64 : 32;
-  if (wb.grp[big].n == GT_GROUP_MAX) wgrad_flush_one(wb, big, s);
-  const int splitk = wgrad_split(g, big ? 1024 : 512, tile);
-  GemmGroup& G = wb.grp[big];
+  // tile size by how many workgroups the problem still yields: 128x128 over >= 512-token chunks, else 64x64 over >= 256-token
+  // chunks, else 32x32 (C2 at bs 64: 16 64x64-tiles x 8 chunks -> stays 32x32)
+  const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  const int cls = (g.M >= 128 && g.N >= 128 && t128 * ((g.K + 511) / 512) >= GT_WGRAD_T128_MIN) ? 2
+                : (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= 512) ? 1 : 0;
+  const int tile = 32 << cls;
+  if (wb.grp[cls].n == GT_GROUP_MAX) wgrad_flush_one(wb, cls, s);
+  const int splitk = wgrad_split(g, cls ? 1024 : 512, tile);
+  GemmGroup& G = wb.grp[cls];
   const int i = G.n++;
   G.p[i] = g;
-  G.big[i] = big;
+  G.big[i] = cls;
   G.gx[i] = (g.N + tile - 1) / tile;
   G.gy[i] = (g.M + tile - 1) / tile;
   G.start[i + 1] = G.start[i] + G.gx[i] * G.gy[i] * splitk;
-  wb.flops[big] += 2.0 * g.M * g.N * g.K;
-  wb.bytes[big] += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+  wb.flops[cls] += 2.0 * g.M * g.N * g.K;
+  wb.bytes[cls] += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
 }
 
 #ifndef GT_T64_MIN
 #define GT_T64_MIN 256
+#endif
+#ifndef GT_T128_MIN
+#define GT_T128_MIN 512
 #endif
 // standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
 template <bool AKM, bool BKM, int EPI>
@@ -547,7 +558,12 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
     return;
   }
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-  if (t64 >= GT_T64_MIN) gemm_launch_cfg<2, 2, 2, 2, 64, AKM, BKM, EPI>(g, 1, s);
+  const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  // 128x128 tiles once they still fill the chip twice over: a 64x64x64 slab needs ~38 GB/s of L2->LDS staging per
+  // workgroup to keep its MFMAs fed, two resident workgroups ask a CU for more than it delivers (46-70 GB/s measured);
+  // 128x128x32 slabs need half of that per flop
+  if (t128 >= GT_T128_MIN) { g.k_chunk = (g.K + 31) / 32 * 32; gemm_launch_cfg<2, 2, 4, 4, 32, AKM, BKM, EPI>(g, 1, s); }
+  else if (t64 >= GT_T64_MIN) gemm_launch_cfg<2, 2, 2, 2, 64, AKM, BKM, EPI>(g, 1, s);
   else            gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
 }
 
