@@ -38,10 +38,12 @@ def test_step_parity_row_chain_kernels(cfg, B, p):
 
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(32, 4, 16, 1), 256, 0.1), (cfg_dict(64, 4, 64, 1), 256, 0.2), (cfg_dict(128, 4, 512, 1), 256, 0.24),
                                      (cfg_dict(256, 2, 512, 1), 256, 0.3), (cfg_dict(512, 8, 512, 1), 256, 0.15),
-                                     (cfg_dict(256, 2, 512, 1, 1), 256, 0.1)])
+                                     (cfg_dict(256, 2, 512, 1, 1), 256, 0.1), (cfg_dict(512, 8, 512, 1), 512, 0.1),
+                                     (cfg_dict(256, 2, 512, 1), 512, 0.2)])
 def test_step_parity_large_batches(cfg, B, p):
-    """M = 8192 tokens: the 32-row LayerNorm-row tiles of every padded width and the 64x64-tile weight-gradient
-    group (mixed with 32x32-tile problems in one backward) -- tile choices the small cases never reach"""
+    """M = 8192 / 16384 tokens: the 32- and 64-row LayerNorm-row tiles of every padded width, 128x128 GEMM tiles and the
+    64x64 / 128x128-tile weight-gradient groups (mixed with 32x32-tile problems in one backward) -- tile choices the
+    small cases never reach"""
     parity.check_step("hip", cfg, B, p)
 
 

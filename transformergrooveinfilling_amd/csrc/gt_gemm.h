@@ -572,10 +572,15 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
 #ifndef GT_ROW_BM32_MIN
 #define GT_ROW_BM32_MIN 8192
 #endif
-static inline int gemm_row_bm(int M) { return M < GT_ROW_BM32_MIN ? 16 : 32; }
+#ifndef GT_ROW_BM64_MIN
+#define GT_ROW_BM64_MIN 16384
+#endif
+// wide rows (d_model > 128) go on to 64-row tiles when even those fill the chip: per flop they stage half the weight bytes
+static inline int gemm_row_bm(int M, int N) { return M < GT_ROW_BM32_MIN ? 16 : (N > 128 && M >= GT_ROW_BM64_MIN) ? 64 : 32; }
 template <bool AKM, bool BKM, int EPI>
 static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
-  const bool small = gemm_row_bm(g.M) == 16;
+  const int bm = gemm_row_bm(g.M, g.N);
+  const bool small = bm == 16;
   if (g.N <= 32) {
     g.k_chunk = (g.K + 63) / 64 * 64;
     if (small) gemm_launch_cfg<1, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
@@ -591,12 +596,14 @@ static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
     else       gemm_launch_cfg<2, 2, 1, 4, 64, AKM, BKM, EPI>(g, 1, s);
   } else if (g.N <= 256) {
     g.k_chunk = (g.K + 31) / 32 * 32;
-    if (small) gemm_launch_cfg<1, 4, 1, 4, 32, AKM, BKM, EPI>(g, 1, s);
-    else       gemm_launch_cfg<1, 4, 2, 4, 32, AKM, BKM, EPI>(g, 1, s);
+    if (small)        gemm_launch_cfg<1, 4, 1, 4, 32, AKM, BKM, EPI>(g, 1, s);
+    else if (bm == 32) gemm_launch_cfg<1, 4, 2, 4, 32, AKM, BKM, EPI>(g, 1, s);
+    else              gemm_launch_cfg<1, 4, 4, 4, 32, AKM, BKM, EPI>(g, 1, s);
   } else if (g.N <= 512) {
     g.k_chunk = (g.K + 15) / 16 * 16;
-    if (small) gemm_launch_cfg<1, 4, 1, 8, 16, AKM, BKM, EPI>(g, 1, s);
-    else       gemm_launch_cfg<1, 4, 2, 8, 16, AKM, BKM, EPI>(g, 1, s);
+    if (small)        gemm_launch_cfg<1, 4, 1, 8, 16, AKM, BKM, EPI>(g, 1, s);
+    else if (bm == 32) gemm_launch_cfg<1, 4, 2, 8, 16, AKM, BKM, EPI>(g, 1, s);
+    else              gemm_launch_cfg<1, 4, 4, 8, 16, AKM, BKM, EPI>(g, 1, s);
   } else {
     return -1;
   }
