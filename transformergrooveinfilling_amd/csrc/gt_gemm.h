@@ -25,6 +25,7 @@
 // the accumulators through LDS and runs LayerNorm forward/backward with 64-lane wave reductions.
 #pragma once
 #include "gt_common.h"
+#include <type_traits>
 
 enum {
   EPI_STORE = 0,          // C = acc + bias (+ C if accumulate)
@@ -64,8 +65,26 @@ struct TileStage {
   static constexpr int CPR = COLS / 4;            // float4 chunks per row
   static constexpr int CH = ROWS * CPR;
   static constexpr int PER = (CH + NT - 1) / NT;
+  static constexpr bool FAST_OK = (CH % NT) == 0;
   float4 v[PER];
   const float* zp;           // gt_zero_ptr() of the enclosing kernel
+  uint32_t boff[PER];        // interior fast path: byte offset of chunk i from the (wave-uniform) slab origin
+  // Interior tiles (whole tile in range, 16-byte aligned rows, full slabs) need none of the per-chunk bounds work below:
+  // the offsets are computed once, the slab origin is a scalar, and each load is `global_load_dwordx4 v, v_off, s[base]`.
+  // With one wave per SIMD (128x128 tiles) the ~150 VALU instructions per slab of the checked form are not hidden behind
+  // anything -- they were 15-25 % of a slab's MFMA time.
+  __device__ __forceinline__ void prep(int ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int ch = tid + i * NT;
+      boff[i] = (uint32_t)((ch / CPR) * ld + (ch % CPR) * 4) * 4u;
+    }
+  }
+  __device__ __forceinline__ void load_fast(const float* __restrict__ origin) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(origin) + boff[i]);
+  }
   // Branch-free staging: every lane ALWAYS issues its loads (out-of-range chunks read gt_zero_page).  A guarded `if (ok) t = load` makes hipcc branch around each load
   // and wait vmcnt(0) per element -- one serialized L2 round trip per chunk (cdna_hip_programming.md 5,
   // trap (c)); measured here as ~3.7 us per 64-wide slab before this form.
@@ -159,30 +178,41 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   la.zp = zp; lb.zp = zp;
   float bsum = 0.f;   // EPI_ATOMIC: bias-grad partial (column sum of the A slab)
 
-  auto load_tiles = [&](int k0) {
-    if (AKM) la.load(g.A, g.lda, k0, m0, kend, g.M, vecA, tid);
-    else     la.load(g.A, g.lda, m0, k0, g.M, kend, vecA, tid);
-    if (BKM) lb.load(g.B, g.ldb, k0, n0, kend, g.N, vecB, tid);
-    else     lb.load(g.B, g.ldb, n0, k0, g.N, kend, vecB, tid);
-  };
+  // wave-uniform: this workgroup's tile lies wholly inside A and B and every slab is full
+  const bool fast = decltype(la)::FAST_OK && decltype(lb)::FAST_OK && vecA && vecB && nk > 0 && ((kend - kbeg) % BK) == 0 &&
+                    m0 + BM <= g.M && n0 + BN <= g.N;
 
-  if (nk > 0) {
-    load_tiles(kbeg);
-    la.store(smem, SA_STR, tid);
-    lb.store(smem + 2 * SA_SZ, SB_STR, tid);
-  }
-  __syncthreads();
+  auto main_loop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    if (FAST) { la.prep(g.lda, tid); lb.prep(g.ldb, tid); }
+    auto load_tiles = [&](int k0) {
+      if (FAST) {
+        la.load_fast(AKM ? g.A + ((size_t)k0 * g.lda + m0) : g.A + ((size_t)m0 * g.lda + k0));
+        lb.load_fast(BKM ? g.B + ((size_t)k0 * g.ldb + n0) : g.B + ((size_t)n0 * g.ldb + k0));
+      } else {
+        if (AKM) la.load(g.A, g.lda, k0, m0, kend, g.M, vecA, tid);
+        else     la.load(g.A, g.lda, m0, k0, g.M, kend, vecA, tid);
+        if (BKM) lb.load(g.B, g.ldb, k0, n0, kend, g.N, vecB, tid);
+        else     lb.load(g.B, g.ldb, n0, k0, g.N, kend, vecB, tid);
+      }
+    };
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const float* sA = smem + cur * SA_SZ;
-    const float* sB = smem + 2 * SA_SZ + cur * SB_SZ;
-    if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
-    // (no tail skip: slabs are zero-filled beyond K; a branch here splits the MFMA block and hipcc then shuttles the
-    //  accumulators VGPR<->AGPR around every few MFMAs, exposing the LDS latency each time)
+    if (nk > 0) {
+      load_tiles(kbeg);
+      la.store(smem, SA_STR, tid);
+      lb.store(smem + 2 * SA_SZ, SB_STR, tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const float* sA = smem + cur * SA_SZ;
+      const float* sB = smem + 2 * SA_SZ + cur * SB_SZ;
+      if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+      // (no tail skip: slabs are zero-filled beyond K; a branch here splits the MFMA block and hipcc then shuttles the
+      //  accumulators VGPR<->AGPR around every few MFMAs, exposing the LDS latency each time)
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      {
+      for (int kk = 0; kk < BK / 16; ++kk) {
         float af[TM][4], bf[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -213,20 +243,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
             for (int b = 0; b < TN; ++b) acc[a][b] = GT_MFMA16(af[a][j], bf[b][j], acc[a][b]);
       }
-    }
 
-    if (EPI == EPI_ATOMIC && AKM) {
-      if (g.dbias != nullptr && bx == 0 && tid < BM) {
+      if (EPI == EPI_ATOMIC && AKM) {
+        if (g.dbias != nullptr && bx == 0 && tid < BM) {
 #pragma unroll 8
-        for (int kk = 0; kk < BK; ++kk) bsum += sA[kk * SA_STR + tid];
+          for (int kk = 0; kk < BK; ++kk) bsum += sA[kk * SA_STR + tid];
+        }
       }
+      if (kt + 1 < nk) {
+        la.store(smem + (cur ^ 1) * SA_SZ, SA_STR, tid);
+        lb.store(smem + 2 * SA_SZ + (cur ^ 1) * SB_SZ, SB_STR, tid);
+      }
+      __syncthreads();
     }
-    if (kt + 1 < nk) {
-      la.store(smem + (cur ^ 1) * SA_SZ, SA_STR, tid);
-      lb.store(smem + 2 * SA_SZ + (cur ^ 1) * SB_SZ, SB_STR, tid);
-    }
-    __syncthreads();
-  }
+  };
+  if (fast) main_loop(std::true_type{}); else main_loop(std::false_type{});
 
   // ------------------------------------------------------------------------------- epilogues
   // Two-phase everywhere: (1) every global input of the epilogue is loaded UNCONDITIONALLY (address-select
