@@ -220,7 +220,7 @@ static WLayout ws_layout(const gt_config& c) {
   W.loss_part = add(((M * GT_VOICES + 255) / 256) * 4);
   // dgamma/dbeta partials: one [row_tiles][2][d] block per LayerNorm instance (2 per encoder layer, 3 per decoder
   // layer, the final norms)
-  W.ln_part_stride = ((M + 15) / 16) * 2 * d;
+  W.ln_part_stride = ((M + 7) / 8) * 2 * d;
   W.ln_part = add(W.ln_part_stride * (2 * c.n_enc_layers + 3 * c.n_dec_layers + 2));
   W.dctx = add(M * d);
   W.da0_dec = c.n_dec_layers > 0 ? add(M * d) : -1;
@@ -324,6 +324,7 @@ static DropArgs mk_drop(const Ctx& x, int site) {
   da.scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
   return da;
 }
+static DropArgs no_drop() { DropArgs da; da.st = nullptr; da.site = 0u; da.thr = 0u; da.scale = 1.0f; return da; }
 static int lsite(int gl, int kind) { return GT_SITE_LAYER0 + 8 * gl + kind; }
 static GemmArgs mk_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K) {
   GemmArgs g;
@@ -408,8 +409,25 @@ static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, 
   gemm_launch<false, true, EPI_STORE>(g, x.s);
 }
 // dz = LNbwd(dY W + res) with the LayerNorm whose (xhat, rstd, gamma) are given; dzm = dz * dropout mask
+// Row-owning GEMM tiles fuse the LayerNorm into the producing linear -- but every workgroup then streams the WHOLE weight
+// matrix.  Wide d_model at few tokens (d 512, M 2048: 128 workgroups x up to 3 MB at ~40 GB/s per CU) makes that the bound
+// (23 TF measured); there the linear runs as an ordinary tiled GEMM and the norm as its own in-place row pass.
+#ifndef GT_ROW_FUSE_MAX_D
+#define GT_ROW_FUSE_MAX_D 64
+#endif
+#ifndef GT_ROW_FUSE_MIN_M
+#define GT_ROW_FUSE_MIN_M 8192
+#endif
+static bool row_fused(const Ctx& x) { return x.d <= GT_ROW_FUSE_MAX_D || x.M >= GT_ROW_FUSE_MIN_M; }
+static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float* xhat, const float* rstd, int64_t gamma_off, float* dz,
+                   float* dzm, int site);
 static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, int K, const float* res, const float* xhat,
                        const float* rstd, int64_t gamma_off, float* dz, float* dzm, int site) {
+  if (!row_fused(x)) {
+    dgrad_store(x, dY, ldy, W, x.d, dz, x.d, K, 0);
+    ln_bwd(x, dz, res, xhat, rstd, gamma_off, dz, dzm, site);
+    return 0;
+  }
   GemmArgs g = mk_gemm(dY, ldy, W, x.d, dz, x.d, x.M, x.d, K);
   g.res = res; g.ldres = x.d;
   g.xhat = xhat; g.rstd = rstd; g.gamma = x.prm + gamma_off;
@@ -420,21 +438,31 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
   g.ln_part = ln_job(x, gamma_off, (x.M + bm - 1) / bm);
   return gemm_launch_row<false, true, EPI_RES_LNBWD>(g, x.s);
 }
-static void ln_bwd(const Ctx& x, const float* dy, const float* xhat, const float* rstd, int64_t gamma_off, float* dz, float* dzm,
-                   int site) {
-  const int rows_per_block = 4 * GT_LNB_ROWS;
+// dz = LNbwd(dy (+ res)); dzm = dz * dropout mask.  Few tokens: 2 rows per wave (one wave per CU cannot hide its own load
+// latency); many: 8 rows per wave, fewer partials to sum.
+static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float* xhat, const float* rstd, int64_t gamma_off, float* dz,
+                   float* dzm, int site) {
+  const int rpw = x.M <= 4096 ? 2 : GT_LNB_ROWS;
+  const int rows_per_block = 4 * rpw;
   const int nblk = (x.M + rows_per_block - 1) / rows_per_block;
   float* part = ln_job(x, gamma_off, nblk);
-  gt_prof_tag("ln_bwd", 0, 12.0 * x.M * x.d);
-  gt_launch(ln_bwd_kernel, dim3(nblk), dim3(256), x.s, dy, xhat, rstd,
+  gt_prof_tag("ln_bwd", 0, (res ? 16.0 : 12.0) * x.M * x.d);
+  gt_launch(ln_bwd_kernel, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd,
             x.prm + gamma_off, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
-            x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d);
+            x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d, rpw);
 }
 // x_out = LN(drop(in W^T + b) + res)
 static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, int64_t b_off, const float* res, int64_t gamma_off,
                          float* out, float* xhat, float* rstd, int site) {
   GemmArgs g = mk_gemm(in, K, x.prm + w_off, K, out, x.d, x.M, x.d, K);
   g.bias = x.prm + b_off;
+  if (!row_fused(x)) {
+    gemm_launch<false, false, EPI_STORE>(g, x.s);
+    gt_prof_tag("ln_fwd", 0, 16.0 * x.M * x.d);
+    gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
+              x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, x.M, x.d);
+    return 0;
+  }
   g.res = res; g.ldres = x.d;
   g.gamma = x.prm + gamma_off; g.beta = x.prm + gamma_off + (x.d + 63) / 64 * 64;
   g.aux = xhat; g.aux2 = rstd;
@@ -569,8 +597,8 @@ static int encoder_fwd(const Ctx& x, const float* pe, const float* src) {
     cur = ws + w.xout;
   }
   gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
-  gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, x.prm + x.P.encn_w, x.prm + x.P.encn_b, ws + x.W.memory,
-            ws + x.W.enc_xhat, ws + x.W.enc_rstd, x.M, x.d);
+  gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, (const float*)nullptr, no_drop(), x.prm + x.P.encn_w,
+            x.prm + x.P.encn_b, ws + x.W.memory, ws + x.W.enc_xhat, ws + x.W.enc_rstd, x.M, x.d);
   return 0;
 }
 static int decoder_fwd(const Ctx& x, const float* pe, const float* tgt_in) {
@@ -593,8 +621,8 @@ static int decoder_fwd(const Ctx& x, const float* pe, const float* tgt_in) {
     cur = ws + w.xout;
   }
   gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
-  gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, x.prm + x.P.decn_w, x.prm + x.P.decn_b, ws + x.W.dec_final,
-            ws + x.W.dec_xhat, ws + x.W.dec_rstd, x.M, x.d);
+  gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, (const float*)nullptr, no_drop(), x.prm + x.P.decn_w,
+            x.prm + x.P.decn_b, ws + x.W.dec_final, ws + x.W.dec_xhat, ws + x.W.dec_rstd, x.M, x.d);
   return 0;
 }
 static void output_layer_fwd(const Ctx& x, float* hvo_out) {
@@ -764,7 +792,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     {
       const LayerW& w = W.layers[top];
       Tmp t = tmp_set(x, top);
-      ln_bwd(x, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.dec[Ld - 1].n3w, t.dzA, t.dzAm, lsite(top, GT_SITE_DROPF));
+      ln_bwd(x, ws + W.dctx, nullptr, ws + w.xhat2, ws + w.rstd2, P.dec[Ld - 1].n3w, t.dzA, t.dzAm, lsite(top, GT_SITE_DROPF));
     }
     for (int l = Ld - 1; l >= 0; --l) {
       const LayerP& p = P.dec[l];
@@ -801,13 +829,13 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
       }
     }
     // encoder final norm backward (input: accumulated dmem) -> grad w.r.t. the last encoder layer's output
-    ln_bwd(x, ws + W.dmem, ws + W.enc_xhat, ws + W.enc_rstd, P.encn_w, ws + W.dctx, nullptr, 0);
+    ln_bwd(x, ws + W.dmem, nullptr, ws + W.enc_xhat, ws + W.enc_rstd, P.encn_w, ws + W.dctx, nullptr, 0);
   }
   {
     const LayerW& w = W.layers[L - 1];
     const Tmp t = tmp_set(x, L - 1);
     acquire_set(x, L - 1);
-    ln_bwd(x, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.enc[L - 1].n2w, t.dzA, t.dzAm, lsite(L - 1, GT_SITE_DROPF));
+    ln_bwd(x, ws + W.dctx, nullptr, ws + w.xhat2, ws + w.rstd2, P.enc[L - 1].n2w, t.dzA, t.dzAm, lsite(L - 1, GT_SITE_DROPF));
   }
   for (int l = L - 1; l >= 0; --l) {
     const LayerP& p = P.enc[l];

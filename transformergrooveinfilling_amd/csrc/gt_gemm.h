@@ -462,8 +462,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   }
 }
 
+// 128x128 tiles: ask for two waves per SIMD (<= 256 registers) so that two workgroups share a CU and one's prologue, barriers
+// and epilogue hide behind the other's MFMAs (unconstrained, hipcc spends 320 registers and only one workgroup fits)
+#ifndef GT_T128_WAVES
+#define GT_T128_WAVES 2
+#endif
 template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN >= 16 && TN == 4) ? GT_T128_WAVES : 1) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI>::SMEM];
   gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
@@ -485,7 +490,7 @@ struct GemmGroup {
 // and atomics per flop (38 % of the C4 step before the split).  The two sizes go out as SEPARATE launches: sharing one,
 // the 70 KB of LDS of the large tiles halved the occupancy of the small ones.
 template <int TM>
-__global__ __launch_bounds__(256) void wgrad_group_kernel(GemmGroup grp) {
+__global__ __launch_bounds__(256, TM == 4 ? GT_T128_WAVES : 1) void wgrad_group_kernel(GemmGroup grp) {
   constexpr int BK = TM == 4 ? 32 : 64;            // 128x128 tiles: 32-token slabs (68 KB of LDS, two workgroups per CU)
   typedef GemmCfg<2, 2, TM, TM, BK, true, true, EPI_ATOMIC> C;
   __shared__ __attribute__((aligned(16))) float smem[C::SMEM];

@@ -5,58 +5,86 @@
 #pragma once
 #include "gt_common.h"
 
-// ---- LayerNorm forward: one wave per row -------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ y,
+// ---- LayerNorm forward: one wave per row, the row lives in registers --------------------------------
+//   z = x * dropmask(+ res);  y = LN(z) * gamma + beta;  xhat, rstd saved for backward.   y may alias x (in place).
+// Used for the final encoder / decoder norms and -- with res / dropout -- as the second half of the UN-fused
+// `LN(drop(linear) + res)` (wide d_model at few tokens, where a row-owning GEMM tile would make every workgroup stream
+// the whole weight matrix; see linear_res_ln in groove_hip.hip).
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float* __restrict__ res, DropArgs drop,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* y,
                                                      float* __restrict__ xhat, float* __restrict__ rstd_out, int M, int N) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const float* xr = x + (size_t)row * N;
+  const float* const zp = gt_zero_ptr();
+  const uint32_t dkey = gt_drop_key(drop);
   const float invN = 1.0f / (float)N;
+  float z[GT_MAX_D / 64], r[GT_MAX_D / 64], ga[GT_MAX_D / 64], be[GT_MAX_D / 64];
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) {            // all loads first, branch-free (address select)
+    const int c = lane + 64 * i;
+    const bool ok = c < N;
+    z[i] = *(ok ? x + (size_t)row * N + c : zp);
+    r[i] = *((ok && res != nullptr) ? res + (size_t)row * N + c : zp);
+    ga[i] = *(ok ? gamma + c : zp);
+    be[i] = *(ok ? beta + c : zp);
+  }
   float s = 0.f;
-  for (int c = lane; c < N; c += 64) s += xr[c];
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) {
+    const int c = lane + 64 * i;
+    z[i] = (c < N) ? z[i] * gt_drop_mul(drop, dkey, (uint32_t)((size_t)row * N + c)) + r[i] : 0.f;
+    s += z[i];
+  }
   const float mean = gt_wave_sum(s) * invN;
   float q = 0.f;
-  for (int c = lane; c < N; c += 64) { const float d = xr[c] - mean; q += d * d; }
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) { if (lane + 64 * i < N) { const float d = z[i] - mean; q += d * d; } }
   const float rstd = 1.0f / sqrtf(gt_wave_sum(q) * invN + GT_LN_EPS);
-  for (int c = lane; c < N; c += 64) {
-    const float xh = (xr[c] - mean) * rstd;
-    xhat[(size_t)row * N + c] = xh;
-    y[(size_t)row * N + c] = xh * gamma[c] + beta[c];
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) {
+    const int c = lane + 64 * i;
+    if (c < N) {
+      const float xh = (z[i] - mean) * rstd;
+      xhat[(size_t)row * N + c] = xh;
+      y[(size_t)row * N + c] = xh * ga[i] + be[i];
+    }
   }
   if (lane == 0) rstd_out[row] = rstd;
 }
 
-// ---- LayerNorm backward: one wave walks ROWS_PER_WAVE rows, then one atomic per column ----------
+// ---- LayerNorm backward: one wave walks `rows_per_wave` rows; dgamma/dbeta leave as one partial per workgroup ------
+//   g = dy (+ res);  dz = LNbwd(g);  dz_masked = dz * dropmask.   dz may alias dy (in place).
 #define GT_LNB_ROWS 8
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* __restrict__ res, const float* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     float* __restrict__ dz, float* __restrict__ dz_masked, DropArgs drop,
+                                                     float* dz, float* __restrict__ dz_masked, DropArgs drop,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part,
-                                                     int M, int N) {
+                                                     int M, int N, int rows_per_wave) {
   __shared__ float sred[4][2][GT_MAX_D];
   const int lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GT_LNB_ROWS;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
   const float invN = 1.0f / (float)N;
   const uint32_t dkey = gt_drop_key(drop);
   const float* const zp = gt_zero_ptr();
   float dg[GT_MAX_D / 64], db[GT_MAX_D / 64];
 #pragma unroll
   for (int i = 0; i < GT_MAX_D / 64; ++i) { dg[i] = 0.f; db[i] = 0.f; }
-  for (int rr = 0; rr < GT_LNB_ROWS; ++rr) {
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
     const int row = row0 + rr;
     if (row >= M) break;
-    float s1 = 0.f, s2 = 0.f, d[GT_MAX_D / 64], xh[GT_MAX_D / 64], ga[GT_MAX_D / 64];
+    float s1 = 0.f, s2 = 0.f, d[GT_MAX_D / 64], e[GT_MAX_D / 64], xh[GT_MAX_D / 64], ga[GT_MAX_D / 64];
 #pragma unroll
     for (int i = 0; i < GT_MAX_D / 64; ++i) {          // all loads first, branch-free (address select)
       const int c = lane + 64 * i;
       const bool ok = c < N;
       d[i] = *(ok ? dy + (size_t)row * N + c : zp);
+      e[i] = *((ok && res != nullptr) ? res + (size_t)row * N + c : zp);
       xh[i] = *(ok ? xhat + (size_t)row * N + c : zp);
       ga[i] = *(ok ? gamma + c : zp);
     }
 #pragma unroll
     for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      d[i] += e[i];
       const float gd = d[i] * ga[i];
       s1 += gd; s2 += gd * xh[i]; dg[i] += d[i] * xh[i]; db[i] += d[i];
     }
