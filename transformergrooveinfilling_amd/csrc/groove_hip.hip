@@ -37,20 +37,16 @@ GtProfile g_prof;
 #ifndef GT_EMU
 struct ProfRec { const char* label; double flops, bytes; hipEvent_t a, b; };
 static std::vector<ProfRec> g_recs;
-void gt_prof_before(hipStream_t s) {
+void gt_prof_events(hipEvent_t* start, hipEvent_t* stop) {
   ProfRec r{g_prof.label, g_prof.flops, g_prof.bytes, nullptr, nullptr};
   (void)hipEventCreate(&r.a);
   (void)hipEventCreate(&r.b);
-  (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
-}
-void gt_prof_after(hipStream_t s) {
-  (void)hipEventRecord(g_recs.back().b, s);
+  *start = r.a; *stop = r.b;
   g_prof.label = "other"; g_prof.flops = 0; g_prof.bytes = 0;
 }
 #else
-void gt_prof_before(hipStream_t) {}
-void gt_prof_after(hipStream_t) {}
+void gt_prof_events(hipEvent_t*, hipEvent_t*) {}
 #endif
 extern "C" int gt_profile_enable(int on) {
   g_prof.on = on != 0;
