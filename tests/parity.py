@@ -1,7 +1,8 @@
 """Parity checks shared by the emulator tests (CPU, small) and the GPU tests (real HIP library).
 Tolerances (fp32 path, stated per BASELINE.json north_star): outputs max-abs <= 1e-4 vs the fp64
 oracle (we assert 2e-5), gradients <= 1e-3 relative to the tensor's max (we assert 2e-4), hit masks
-bit-exact wherever |sigmoid(logit) - thres| exceeds 1e-4."""
+bit-exact wherever |sigmoid(logit) - thres| exceeds 1e-4; ReLU decisions identical wherever the oracle's
+|pre-activation| exceeds 1e-5 (adopt_device_kinks)."""
 import glob
 import os
 
@@ -20,6 +21,32 @@ def shift_right(y):
 
 def rel_err(a, ref):
     return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-12))
+
+
+KINK = 1e-5
+
+
+def adopt_device_kinks(r, C, cfg):
+    """ReLU has no derivative at 0.  Where the fp64 oracle's pre-activation lies within KINK of the kink, the fp32 device
+    may round to the other side (about one element per 1e6 pre-activations: BASELINE configs[1] at full size has 1e6 per
+    layer) and both subgradients are legitimate -- the same reasoning as the hit-threshold margin above.  Take the
+    device's decision for exactly those elements so that both backward passes differentiate the same function; a
+    differing decision anywhere else is an error.  Returns the number of adopted elements."""
+    n_enc, adopted = len(C["enc"]), 0
+    todo = [(c, "hpre", c["mf"], r.ws_get("hact", l)) for l, c in enumerate(C["enc"])]
+    todo += [(c, "hpre", c["mf"], r.ws_get("hact", n_enc + l)) for l, c in enumerate(C["dec"])]
+    todo.append((C["in_enc"], "a", None, r.ws_get("a0")))
+    for c, key, keep, dev in todo:
+        pre = c[key]
+        on = dev.reshape(pre.shape) > 0
+        flips = on != (pre > 0)
+        if keep is not None:
+            flips &= keep != 0                      # dropped elements are zero on both sides whatever the sign
+        if flips.any():
+            assert (np.abs(pre[flips]) < KINK).all(), "ReLU decision differs away from the kink: max |pre| %g" % np.abs(pre[flips]).max()
+            pre[flips] = np.where(on[flips], 1e-30, -1e-30)
+            adopted += int(flips.sum())
+    return adopted
 
 
 def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chain=False):
@@ -48,6 +75,8 @@ def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chai
         assert abs(stats[i] - rstats[i]) < 1e-5 * max(1.0, abs(rstats[i])), (i, stats[i], rstats[i])
     assert rel_err(d_hvo, np.concatenate(dpred, -1)) < 1e-5
     G = r.backward(train=p > 0)
+    adopted = adopt_device_kinks(r, C, cfg)
+    assert adopted <= 4 + r.M * cfg["dim_feedforward"] * (len(C["enc"]) + len(C["dec"])) // 100000, adopted
     Gr = ng.backward(P, cfg, C, dpred, dtype=np.float64)
     assert set(G) == set(Gr)
     for k in Gr:

@@ -465,6 +465,12 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
   g.drop = mk_drop(x, site);
   return gemm_launch_row<false, false, EPI_RES_LN>(g, x.s);
 }
+// head dims served by the MFMA attention kernels (0: use the generic LDS/VALU kernels); GT_ATTN_MFMA=0 forces the generic ones
+static int attn_mfma_hd(const Ctx& x) {
+  static const int enabled = [] { const char* e = getenv("GT_ATTN_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();
+  const int hd = x.d / x.H;
+  return (enabled && (hd == 16 || hd == 32 || hd == 64 || hd == 128)) ? hd : 0;
+}
 static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, float* P, float* ctx,
                           int causal, int site) {
   AttnArgs a;
@@ -472,7 +478,14 @@ static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k,
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = P; a.ctx = ctx; a.ldc = x.d;
   a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.causal = causal; a.drop = mk_drop(x, site);
   gt_prof_tag("attn_fwd", 4.0 * x.M * 32 * x.d, 4.0 * (4.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
-  gt_launch(attn_fwd_kernel, dim3(x.c.batch * x.H), dim3(256), x.s, a);
+  const dim3 grid(x.c.batch * x.H);
+  switch (attn_mfma_hd(x)) {
+    case 16:  gt_launch(attn_fwd_mfma_kernel<16>, grid, dim3(128), x.s, a); break;
+    case 32:  gt_launch(attn_fwd_mfma_kernel<32>, grid, dim3(128), x.s, a); break;
+    case 64:  gt_launch(attn_fwd_mfma_kernel<64>, grid, dim3(128), x.s, a); break;
+    case 128: gt_launch(attn_fwd_mfma_kernel<128>, grid, dim3(128), x.s, a); break;
+    default:  gt_launch(attn_fwd_kernel, grid, dim3(256), x.s, a);
+  }
 }
 static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* P,
                           const float* dctx, float* dq, int lddq, float* dk, float* dv, int lddkv, int site) {
@@ -482,7 +495,14 @@ static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k,
   a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.drop = mk_drop(x, site);
   a.dctx = dctx; a.lddc = x.d; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddkv; a.lddv = lddkv;
   gt_prof_tag("attn_bwd", 10.0 * x.M * 32 * x.d, 4.0 * (7.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
-  gt_launch(attn_bwd_kernel, dim3(x.c.batch * x.H), dim3(256), x.s, a);
+  const dim3 grid(x.c.batch * x.H);
+  switch (attn_mfma_hd(x)) {
+    case 16:  gt_launch(attn_bwd_mfma_kernel<16>, grid, dim3(128), x.s, a); break;
+    case 32:  gt_launch(attn_bwd_mfma_kernel<32>, grid, dim3(128), x.s, a); break;
+    case 64:  gt_launch(attn_bwd_mfma_kernel<64>, grid, dim3(128), x.s, a); break;
+    case 128: gt_launch(attn_bwd_mfma_kernel<128>, grid, dim3(128), x.s, a); break;
+    default:  gt_launch(attn_bwd_kernel, grid, dim3(256), x.s, a);
+  }
 }
 
 static int make_ctx(Ctx& x, const gt_config* cfg, const float* params, float* grads, float* ws, const gt_step_state* st,

@@ -7,6 +7,11 @@
 // walking head_dim in 32-column slabs.
 // Saved for backward: P (pre-dropout probabilities, (B*H,32,32)); the dropout mask is regenerated
 // from the counter-based hash.
+//
+// Two implementations with identical interfaces and results:
+//   attn_*_mfma_kernel<HD>  head_dim 16/32/64/128: everything on v_mfma_f32_16x16x4_f32, operands straight from global
+//                           memory into registers, no LDS tiles (see the layout notes above the kernels);
+//   attn_*_kernel           any head_dim (1..512): LDS-tiled VALU code, 32-column slabs.
 #pragma once
 #include "gt_common.h"
 
@@ -166,5 +171,216 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
+  }
+}
+
+
+// ================================================================================================================
+// MFMA variant (head_dim % 16 == 0).  Workgroup = 2 waves per (sequence, head); wave w owns query tile w (16 rows).
+//
+// The trick that removes every LDS round trip: compute the TRANSPOSED score tile  S^T = K Q^T  (A = K rows, B = Q rows).
+// An MFMA result lives as D[row = 4g + r][col = l16]  (l16 = lane & 15, g = lane >> 4, r = register 0..3), so a lane
+// holds  S^T[j = 16 tj + 4g + r][i = l16]  -- i.e. for ITS query row i = l16 the four keys 4g..4g+3 of each key tile.
+//   * softmax over keys = in-lane over (tj, r), then over the 4 lane groups (xor 16, 32);
+//   * as the A operand of the next product (A[m = l16][k = lane group g]) the same registers ARE  P[i][k]  for the
+//     k-step numbering  k = 16 tj + 4g + c  (c = register): feeding V rows in that same order (B = V[16 tj + 4g + c][col])
+//     makes  ctx = P V  a sequence of 8 MFMAs per 16 output columns with no data movement at all.
+// Q/K fragments use the k-permutation of gt_gemm.h: lane (l16, g) loads ONE float4 = columns 16q + 4g .. +3 of its row
+// and uses the components as four consecutive k-steps; A and B permute alike, so the contraction is unchanged.
+// ================================================================================================================
+template <int HD>
+__global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
+  constexpr int NQ = HD / 16;
+  const int lane = threadIdx.x & 63, ti = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int i = 16 * ti + l16;                                   // this lane's query row
+  const float* qrow = a.q + (size_t)(b * 32 + i) * a.ldq + h * HD + 4 * g;
+  const float* krow = a.k + (size_t)(b * 32 + l16) * a.ldk + h * HD + 4 * g;      // key tile 0; tile 1 = + 16 rows
+  f32x4 st[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};           // S^T tiles [tj]
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float4 qf = *reinterpret_cast<const float4*>(qrow + 16 * q);
+    const float4 k0 = *reinterpret_cast<const float4*>(krow + 16 * q);
+    const float4 k1 = *reinterpret_cast<const float4*>(krow + (size_t)16 * a.ldk + 16 * q);
+    st[0] = GT_MFMA16(k0.x, qf.x, st[0]); st[1] = GT_MFMA16(k1.x, qf.x, st[1]);
+    st[0] = GT_MFMA16(k0.y, qf.y, st[0]); st[1] = GT_MFMA16(k1.y, qf.y, st[1]);
+    st[0] = GT_MFMA16(k0.z, qf.z, st[0]); st[1] = GT_MFMA16(k1.z, qf.z, st[1]);
+    st[0] = GT_MFMA16(k0.w, qf.w, st[0]); st[1] = GT_MFMA16(k1.w, qf.w, st[1]);
+  }
+  float sv[2][4], mx = -INFINITY;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * tj + 4 * g + r;
+      sv[tj][r] = (a.causal && j > i) ? -INFINITY : st[tj][r] * a.scale;
+      mx = fmaxf(mx, sv[tj][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sv[tj][r] = expf(sv[tj][r] - mx); sum += sv[tj][r]; }
+  sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  const uint32_t dkey = gt_drop_key(a.drop);
+  float pd[2][4];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const uint32_t idx0 = (uint32_t)((bh * 32 + i) * 32 + 16 * tj + 4 * g);
+    float4 pv;
+    pv.x = sv[tj][0] * inv; pv.y = sv[tj][1] * inv; pv.z = sv[tj][2] * inv; pv.w = sv[tj][3] * inv;
+    *reinterpret_cast<float4*>(a.P + idx0) = pv;
+    pd[tj][0] = pv.x * gt_drop_mul(a.drop, dkey, idx0);
+    pd[tj][1] = pv.y * gt_drop_mul(a.drop, dkey, idx0 + 1);
+    pd[tj][2] = pv.z * gt_drop_mul(a.drop, dkey, idx0 + 2);
+    pd[tj][3] = pv.w * gt_drop_mul(a.drop, dkey, idx0 + 3);
+  }
+  const float* vcol = a.v + (size_t)(b * 32 + 4 * g) * a.ldv + h * HD + l16;     // V[4g + c + 16 tj][16 ct + l16]
+  float* orow = a.ctx + (size_t)(b * 32 + 16 * ti + 4 * g) * a.ldc + h * HD + l16;
+#pragma unroll
+  for (int ct = 0; ct < NQ; ++ct) {
+    float vb[2][4];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vb[tj][c] = vcol[(size_t)(16 * tj + c) * a.ldv + 16 * ct];
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o = GT_MFMA16(pd[tj][c], vb[tj][c], o);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) orow[(size_t)r * a.ldc + 16 * ct] = o[r];
+  }
+}
+
+// Backward.  Each wave plays two roles, because dq contracts over keys and dk / dv contract over queries:
+//   role 1 (query tile w, S^T layout as above): dPd^T = V dO^T, dS in registers -> dq rows of tile w;  row sums
+//           rd[i] = sum_j dP P go through 32 floats of LDS so that role 2 can read the other wave's rows;
+//   role 2 (key tile w, S layout: lane holds X[i = 16 ti + 4g + r][j = l16]): dPd = dO V^T, P reloaded in this layout,
+//           (P*mask) and dS are then the A operands (A[m = j][k = i]) of  dv = (P*mask)^T dO  and  dk = dS^T q.
+template <int HD>
+__global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
+  constexpr int NQ = HD / 16;
+  __shared__ float srd[32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const uint32_t dkey = gt_drop_key(a.drop);
+  const size_t row0 = (size_t)b * 32;
+  const int hc = h * HD;
+
+  // ---------------------------------------------------------------- role 1: query tile w
+  {
+    const int i = 16 * w + l16;
+    const float* dorow = a.dctx + (row0 + i) * a.lddc + hc + 4 * g;
+    const float* vrow = a.v + (row0 + l16) * a.ldv + hc + 4 * g;
+    f32x4 dt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // dPd^T tiles [tj]
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float4 df = *reinterpret_cast<const float4*>(dorow + 16 * q);
+      const float4 v0 = *reinterpret_cast<const float4*>(vrow + 16 * q);
+      const float4 v1 = *reinterpret_cast<const float4*>(vrow + (size_t)16 * a.ldv + 16 * q);
+      dt[0] = GT_MFMA16(v0.x, df.x, dt[0]); dt[1] = GT_MFMA16(v1.x, df.x, dt[1]);
+      dt[0] = GT_MFMA16(v0.y, df.y, dt[0]); dt[1] = GT_MFMA16(v1.y, df.y, dt[1]);
+      dt[0] = GT_MFMA16(v0.z, df.z, dt[0]); dt[1] = GT_MFMA16(v1.z, df.z, dt[1]);
+      dt[0] = GT_MFMA16(v0.w, df.w, dt[0]); dt[1] = GT_MFMA16(v1.w, df.w, dt[1]);
+    }
+    float p[2][4], dp[2][4], rd = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const uint32_t idx0 = (uint32_t)((bh * 32 + i) * 32 + 16 * tj + 4 * g);
+      const float4 pv = *reinterpret_cast<const float4*>(a.P + idx0);
+      p[tj][0] = pv.x; p[tj][1] = pv.y; p[tj][2] = pv.z; p[tj][3] = pv.w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dp[tj][r] = dt[tj][r] * gt_drop_mul(a.drop, dkey, idx0 + r);
+        rd += dp[tj][r] * p[tj][r];
+      }
+    }
+    rd += __shfl_xor(rd, 16); rd += __shfl_xor(rd, 32);
+    if (g == 0) srd[i] = rd;
+    float ds[2][4];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[tj][r] = p[tj][r] * (dp[tj][r] - rd) * a.scale;
+    const float* kcol = a.k + (row0 + 4 * g) * a.ldk + hc + l16;
+    float* dqrow = a.dq + (row0 + 16 * w + 4 * g) * a.lddq + hc + l16;
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct) {
+      float kb[2][4];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kb[tj][c] = kcol[(size_t)(16 * tj + c) * a.ldk + 16 * ct];
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o = GT_MFMA16(ds[tj][c], kb[tj][c], o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dqrow[(size_t)r * a.lddq + 16 * ct] = o[r];
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- role 2: key tile w
+  {
+    const int j = 16 * w + l16;
+    const float* dorow = a.dctx + (row0 + l16) * a.lddc + hc + 4 * g;               // query tile 0; tile 1 = + 16 rows
+    const float* vrow = a.v + (row0 + j) * a.ldv + hc + 4 * g;
+    f32x4 dd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // dPd tiles [ti]
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float4 vf = *reinterpret_cast<const float4*>(vrow + 16 * q);
+      const float4 d0 = *reinterpret_cast<const float4*>(dorow + 16 * q);
+      const float4 d1 = *reinterpret_cast<const float4*>(dorow + (size_t)16 * a.lddc + 16 * q);
+      dd[0] = GT_MFMA16(d0.x, vf.x, dd[0]); dd[1] = GT_MFMA16(d1.x, vf.x, dd[1]);
+      dd[0] = GT_MFMA16(d0.y, vf.y, dd[0]); dd[1] = GT_MFMA16(d1.y, vf.y, dd[1]);
+      dd[0] = GT_MFMA16(d0.z, vf.z, dd[0]); dd[1] = GT_MFMA16(d1.z, vf.z, dd[1]);
+      dd[0] = GT_MFMA16(d0.w, vf.w, dd[0]); dd[1] = GT_MFMA16(d1.w, vf.w, dd[1]);
+    }
+    float pdm[2][4], ds[2][4];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + 4 * g + r;
+        const uint32_t idx = (uint32_t)((bh * 32 + i) * 32 + j);
+        const float pv = a.P[idx];
+        const float mk = gt_drop_mul(a.drop, dkey, idx);
+        pdm[ti][r] = pv * mk;
+        ds[ti][r] = pv * (dd[ti][r] * mk - srd[i]) * a.scale;
+      }
+    const float* docol = a.dctx + (row0 + 4 * g) * a.lddc + hc + l16;
+    const float* qcol = a.q + (row0 + 4 * g) * a.ldq + hc + l16;
+    float* dvrow = a.dv + (row0 + 16 * w + 4 * g) * a.lddv + hc + l16;
+    float* dkrow = a.dk + (row0 + 16 * w + 4 * g) * a.lddk + hc + l16;
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct) {
+      float db[2][4], qb[2][4];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          db[ti][c] = docol[(size_t)(16 * ti + c) * a.lddc + 16 * ct];
+          qb[ti][c] = qcol[(size_t)(16 * ti + c) * a.ldq + 16 * ct];
+        }
+      f32x4 ov = f32x4{0.f, 0.f, 0.f, 0.f}, ok = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          ov = GT_MFMA16(pdm[ti][c], db[ti][c], ov);
+          ok = GT_MFMA16(ds[ti][c], qb[ti][c], ok);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dvrow[(size_t)r * a.lddv + 16 * ct] = ov[r];
+        dkrow[(size_t)r * a.lddk + 16 * ct] = ok[r];
+      }
+    }
   }
 }
