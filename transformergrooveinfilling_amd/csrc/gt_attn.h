@@ -196,16 +196,30 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
   const int i = 16 * ti + l16;                                   // this lane's query row
   const float* qrow = a.q + (size_t)(b * 32 + i) * a.ldq + h * HD + 4 * g;
   const float* krow = a.k + (size_t)(b * 32 + l16) * a.ldk + h * HD + 4 * g;      // key tile 0; tile 1 = + 16 rows
+  // Every operand of the kernel is requested up front (Q, K fragments and all of V: 40 registers at head_dim 32, 160 at
+  // 128) so the loads are all in flight together; issued tile by tile each one would cost its own memory round trip.
   f32x4 st[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};           // S^T tiles [tj]
+  float4 qf[NQ], k0[NQ], k1[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const float4 qf = *reinterpret_cast<const float4*>(qrow + 16 * q);
-    const float4 k0 = *reinterpret_cast<const float4*>(krow + 16 * q);
-    const float4 k1 = *reinterpret_cast<const float4*>(krow + (size_t)16 * a.ldk + 16 * q);
-    st[0] = GT_MFMA16(k0.x, qf.x, st[0]); st[1] = GT_MFMA16(k1.x, qf.x, st[1]);
-    st[0] = GT_MFMA16(k0.y, qf.y, st[0]); st[1] = GT_MFMA16(k1.y, qf.y, st[1]);
-    st[0] = GT_MFMA16(k0.z, qf.z, st[0]); st[1] = GT_MFMA16(k1.z, qf.z, st[1]);
-    st[0] = GT_MFMA16(k0.w, qf.w, st[0]); st[1] = GT_MFMA16(k1.w, qf.w, st[1]);
+    qf[q] = *reinterpret_cast<const float4*>(qrow + 16 * q);
+    k0[q] = *reinterpret_cast<const float4*>(krow + 16 * q);
+    k1[q] = *reinterpret_cast<const float4*>(krow + (size_t)16 * a.ldk + 16 * q);
+  }
+  const float* __restrict__ vcol = a.v + (size_t)(b * 32 + 4 * g) * a.ldv + h * HD + l16;     // V[4g + c + 16 tj][16 ct + l16]
+  float vb[NQ][2][4];
+#pragma unroll
+  for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vb[ct][tj][c] = vcol[(size_t)(16 * tj + c) * a.ldv + 16 * ct];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    st[0] = GT_MFMA16(k0[q].x, qf[q].x, st[0]); st[1] = GT_MFMA16(k1[q].x, qf[q].x, st[1]);
+    st[0] = GT_MFMA16(k0[q].y, qf[q].y, st[0]); st[1] = GT_MFMA16(k1[q].y, qf[q].y, st[1]);
+    st[0] = GT_MFMA16(k0[q].z, qf[q].z, st[0]); st[1] = GT_MFMA16(k1[q].z, qf[q].z, st[1]);
+    st[0] = GT_MFMA16(k0[q].w, qf[q].w, st[0]); st[1] = GT_MFMA16(k1[q].w, qf[q].w, st[1]);
   }
   float sv[2][4], mx = -INFINITY;
 #pragma unroll
@@ -237,23 +251,22 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
     pd[tj][2] = pv.z * gt_drop_mul(a.drop, dkey, idx0 + 2);
     pd[tj][3] = pv.w * gt_drop_mul(a.drop, dkey, idx0 + 3);
   }
-  const float* vcol = a.v + (size_t)(b * 32 + 4 * g) * a.ldv + h * HD + l16;     // V[4g + c + 16 tj][16 ct + l16]
-  float* orow = a.ctx + (size_t)(b * 32 + 16 * ti + 4 * g) * a.ldc + h * HD + l16;
+  // all V loads and MFMAs first, stores last: a store between two column tiles would pin the next tile's loads behind it
+  // (the pointers may alias as far as the compiler knows) and every tile would pay a full memory round trip
+  float* __restrict__ orow = a.ctx + (size_t)(b * 32 + 16 * ti + 4 * g) * a.ldc + h * HD + l16;
+  f32x4 o[NQ];
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct) {
-    float vb[2][4];
+    o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) vb[tj][c] = vcol[(size_t)(16 * tj + c) * a.ldv + 16 * ct];
-    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) o = GT_MFMA16(pd[tj][c], vb[tj][c], o);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) orow[(size_t)r * a.ldc + 16 * ct] = o[r];
+      for (int c = 0; c < 4; ++c) o[ct] = GT_MFMA16(pd[tj][c], vb[ct][tj][c], o[ct]);
   }
+#pragma unroll
+  for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) orow[(size_t)r * a.ldc + 16 * ct] = o[ct][r];
 }
 
 // Backward.  Each wave plays two roles, because dq contracts over keys and dk / dv contract over queries:
@@ -270,6 +283,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
   const uint32_t dkey = gt_drop_key(a.drop);
   const size_t row0 = (size_t)b * 32;
   const int hc = h * HD;
+  f32x4 dq_out[NQ];
 
   // ---------------------------------------------------------------- role 1: query tile w
   {
@@ -277,15 +291,27 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
     const float* dorow = a.dctx + (row0 + i) * a.lddc + hc + 4 * g;
     const float* vrow = a.v + (row0 + l16) * a.ldv + hc + 4 * g;
     f32x4 dt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // dPd^T tiles [tj]
+    float4 df[NQ], v0[NQ], v1[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {                       // all loads of this role first (see the forward kernel)
+      df[q] = *reinterpret_cast<const float4*>(dorow + 16 * q);
+      v0[q] = *reinterpret_cast<const float4*>(vrow + 16 * q);
+      v1[q] = *reinterpret_cast<const float4*>(vrow + (size_t)16 * a.ldv + 16 * q);
+    }
+    const float* __restrict__ kcol = a.k + (row0 + 4 * g) * a.ldk + hc + l16;
+    float kb[NQ][2][4];
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kb[ct][tj][c] = kcol[(size_t)(16 * tj + c) * a.ldk + 16 * ct];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const float4 df = *reinterpret_cast<const float4*>(dorow + 16 * q);
-      const float4 v0 = *reinterpret_cast<const float4*>(vrow + 16 * q);
-      const float4 v1 = *reinterpret_cast<const float4*>(vrow + (size_t)16 * a.ldv + 16 * q);
-      dt[0] = GT_MFMA16(v0.x, df.x, dt[0]); dt[1] = GT_MFMA16(v1.x, df.x, dt[1]);
-      dt[0] = GT_MFMA16(v0.y, df.y, dt[0]); dt[1] = GT_MFMA16(v1.y, df.y, dt[1]);
-      dt[0] = GT_MFMA16(v0.z, df.z, dt[0]); dt[1] = GT_MFMA16(v1.z, df.z, dt[1]);
-      dt[0] = GT_MFMA16(v0.w, df.w, dt[0]); dt[1] = GT_MFMA16(v1.w, df.w, dt[1]);
+      dt[0] = GT_MFMA16(v0[q].x, df[q].x, dt[0]); dt[1] = GT_MFMA16(v1[q].x, df[q].x, dt[1]);
+      dt[0] = GT_MFMA16(v0[q].y, df[q].y, dt[0]); dt[1] = GT_MFMA16(v1[q].y, df[q].y, dt[1]);
+      dt[0] = GT_MFMA16(v0[q].z, df[q].z, dt[0]); dt[1] = GT_MFMA16(v1[q].z, df[q].z, dt[1]);
+      dt[0] = GT_MFMA16(v0[q].w, df[q].w, dt[0]); dt[1] = GT_MFMA16(v1[q].w, df[q].w, dt[1]);
     }
     float p[2][4], dp[2][4], rd = 0.f;
 #pragma unroll
@@ -306,23 +332,19 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[tj][r] = p[tj][r] * (dp[tj][r] - rd) * a.scale;
-    const float* kcol = a.k + (row0 + 4 * g) * a.ldk + hc + l16;
-    float* dqrow = a.dq + (row0 + 16 * w + 4 * g) * a.lddq + hc + l16;
+    f32x4 o[NQ];
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct) {
-      float kb[2][4];
+      o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) kb[tj][c] = kcol[(size_t)(16 * tj + c) * a.ldk + 16 * ct];
-      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o = GT_MFMA16(ds[tj][c], kb[tj][c], o);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dqrow[(size_t)r * a.lddq + 16 * ct] = o[r];
+        for (int c = 0; c < 4; ++c) o[ct] = GT_MFMA16(ds[tj][c], kb[ct][tj][c], o[ct]);
     }
+    // the dq stores wait until role 2 has issued its loads (dq may share a buffer with k / v: packed dqkv next to qkv is not
+    // the case here, but the compiler cannot know) -- they are written at the very end of the kernel
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct) dq_out[ct] = o[ct];
   }
   __syncthreads();
 
@@ -332,15 +354,31 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
     const float* dorow = a.dctx + (row0 + l16) * a.lddc + hc + 4 * g;               // query tile 0; tile 1 = + 16 rows
     const float* vrow = a.v + (row0 + j) * a.ldv + hc + 4 * g;
     f32x4 dd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // dPd tiles [ti]
+    float4 vf[NQ], d0[NQ], d1[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const float4 vf = *reinterpret_cast<const float4*>(vrow + 16 * q);
-      const float4 d0 = *reinterpret_cast<const float4*>(dorow + 16 * q);
-      const float4 d1 = *reinterpret_cast<const float4*>(dorow + (size_t)16 * a.lddc + 16 * q);
-      dd[0] = GT_MFMA16(d0.x, vf.x, dd[0]); dd[1] = GT_MFMA16(d1.x, vf.x, dd[1]);
-      dd[0] = GT_MFMA16(d0.y, vf.y, dd[0]); dd[1] = GT_MFMA16(d1.y, vf.y, dd[1]);
-      dd[0] = GT_MFMA16(d0.z, vf.z, dd[0]); dd[1] = GT_MFMA16(d1.z, vf.z, dd[1]);
-      dd[0] = GT_MFMA16(d0.w, vf.w, dd[0]); dd[1] = GT_MFMA16(d1.w, vf.w, dd[1]);
+      vf[q] = *reinterpret_cast<const float4*>(vrow + 16 * q);
+      d0[q] = *reinterpret_cast<const float4*>(dorow + 16 * q);
+      d1[q] = *reinterpret_cast<const float4*>(dorow + (size_t)16 * a.lddc + 16 * q);
+    }
+    const float* __restrict__ docol = a.dctx + (row0 + 4 * g) * a.lddc + hc + l16;
+    const float* __restrict__ qcol = a.q + (row0 + 4 * g) * a.ldq + hc + l16;
+    float db[NQ][2][4], qb[NQ][2][4];
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          db[ct][ti][c] = docol[(size_t)(16 * ti + c) * a.lddc + 16 * ct];
+          qb[ct][ti][c] = qcol[(size_t)(16 * ti + c) * a.ldq + 16 * ct];
+        }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      dd[0] = GT_MFMA16(d0[q].x, vf[q].x, dd[0]); dd[1] = GT_MFMA16(d1[q].x, vf[q].x, dd[1]);
+      dd[0] = GT_MFMA16(d0[q].y, vf[q].y, dd[0]); dd[1] = GT_MFMA16(d1[q].y, vf[q].y, dd[1]);
+      dd[0] = GT_MFMA16(d0[q].z, vf[q].z, dd[0]); dd[1] = GT_MFMA16(d1[q].z, vf[q].z, dd[1]);
+      dd[0] = GT_MFMA16(d0[q].w, vf[q].w, dd[0]); dd[1] = GT_MFMA16(d1[q].w, vf[q].w, dd[1]);
     }
     float pdm[2][4], ds[2][4];
 #pragma unroll
@@ -354,33 +392,28 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
         pdm[ti][r] = pv * mk;
         ds[ti][r] = pv * (dd[ti][r] * mk - srd[i]) * a.scale;
       }
-    const float* docol = a.dctx + (row0 + 4 * g) * a.lddc + hc + l16;
-    const float* qcol = a.q + (row0 + 4 * g) * a.ldq + hc + l16;
-    float* dvrow = a.dv + (row0 + 16 * w + 4 * g) * a.lddv + hc + l16;
-    float* dkrow = a.dk + (row0 + 16 * w + 4 * g) * a.lddk + hc + l16;
+    f32x4 ov[NQ], ok[NQ];
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct) {
-      float db[2][4], qb[2][4];
+      ov[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          db[ti][c] = docol[(size_t)(16 * ti + c) * a.lddc + 16 * ct];
-          qb[ti][c] = qcol[(size_t)(16 * ti + c) * a.ldq + 16 * ct];
+          ov[ct] = GT_MFMA16(pdm[ti][c], db[ct][ti][c], ov[ct]);
+          ok[ct] = GT_MFMA16(ds[ti][c], qb[ct][ti][c], ok[ct]);
         }
-      f32x4 ov = f32x4{0.f, 0.f, 0.f, 0.f}, ok = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float* __restrict__ dqrow = a.dq + (row0 + 16 * w + 4 * g) * a.lddq + hc + l16;
+    float* __restrict__ dvrow = a.dv + (row0 + 16 * w + 4 * g) * a.lddv + hc + l16;
+    float* __restrict__ dkrow = a.dk + (row0 + 16 * w + 4 * g) * a.lddk + hc + l16;
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          ov = GT_MFMA16(pdm[ti][c], db[ti][c], ov);
-          ok = GT_MFMA16(ds[ti][c], qb[ti][c], ok);
-        }
+    for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        dvrow[(size_t)r * a.lddv + 16 * ct] = ov[r];
-        dkrow[(size_t)r * a.lddk + 16 * ct] = ok[r];
+        dqrow[(size_t)r * a.lddq + 16 * ct] = dq_out[ct][r];
+        dvrow[(size_t)r * a.lddv + 16 * ct] = ov[ct][r];
+        dkrow[(size_t)r * a.lddk + 16 * ct] = ok[ct][r];
       }
-    }
   }
 }

@@ -538,9 +538,12 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
   return (g.K + chunk - 1) / chunk;
 }
 
-// all weight gradients queued since the last flush go out as (at most) three grouped dispatches, one per tile size
+// all weight gradients queued since the last flush go out as (at most) three grouped dispatches, one per tile size.
+// GT_WGRAD_T128_MIN counts ONE problem's 128x128-tile workgroups; a launch groups the 4-6 problems of a layer, so 32 per
+// problem already fills the chip (A/B on one box: 512 -> 32 took C3 from 6.92 to 6.22 ms; 16 pulls C2's M=2048 problems in
+// and costs the headline shape 30 %).
 #ifndef GT_WGRAD_T128_MIN
-#define GT_WGRAD_T128_MIN 512
+#define GT_WGRAD_T128_MIN 32
 #endif
 struct WgradBatch {
   GemmGroup grp[3];            // [0]: 32x32-tile problems, [1]: 64x64, [2]: 128x128
