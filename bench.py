@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="1 GPU only: run the data-parallel step sequence (graph, RCCL all-reduce in a 1-rank group, update) to "
+                         "measure its non-communication overhead")
     args = ap.parse_args()
 
     import torch
@@ -90,12 +93,15 @@ def main():
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     eng = StepEngine(batch_size=BATCH, optimizer="sgd", learning_rate=LR, hit_loss_penalty=PENALTY, seed=1234 + rank,
                      device=dev, world_size=world, use_graph=not args.no_graph, **WORK)
+    eng.force_dp = bool(args.force_dp)
     eng.load_named(ng.init_params(WORK, seed=0))                       # identical replicas
     x, y = ng.synthetic_batch(BATCH, WORK["embedding_size_src"], seed=1234 + rank)
     eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))   # inputs resident in HBM
@@ -155,11 +161,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit -- AFTER this line.
+        # The JSON must be the last line on stdout.
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -29,16 +29,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--only", type=int, default=-1, help="index of the single shape to run")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (for rocprofv3 --pmc passes)")
+    ap.add_argument("--warmup", type=int, default=10)
     args = ap.parse_args()
     for i, (name, dims, B) in enumerate(SHAPES):
         if args.only >= 0 and i != args.only:
             continue
         dims = dict(dims, embedding_size_src=16)
-        eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=1, **dims)
+        eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=1, use_graph=not args.no_graph, **dims)
         eng.load_named(ng.init_params(dims, seed=0))
         x, y = ng.synthetic_batch(B, 16, seed=2)
         eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))
-        for _ in range(10):
+        for _ in range(args.warmup):
             eng.train_step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -14,7 +14,7 @@
 // load->barrier hand-offs rare on these short-K GEMMs), double-buffered in LDS with register staging (global loads of slab
 // t+1 are in flight while slab t is multiplied; one barrier per slab).  Tiles are kept in LDS in
 // SOURCE orientation so both global->LDS copies are 16-byte vector moves:
-//   k-contiguous source : s[row][BK+4]  -> fragment for 4 MFMA k-steps = ONE ds_read_b128
+//   k-contiguous source : s[row][BK+8]  -> fragment for 4 MFMA k-steps = ONE ds_read_b128
 //                         (lane (r=l&15, g=l>>4) reads k = 4g..4g+3; A and B use the same
 //                         k permutation, so the products pair up correctly)
 //   row-contiguous source: s[k][rows+4] -> fragment = 4 ds_read_b32 (stride%8==4: conflict-free)
@@ -131,8 +131,13 @@ struct TileStage {
 template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
 struct GemmCfg {
   static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = BK_, NT = WM * WN * 64;
-  static constexpr int SA_STR = AKM ? BM + 4 : BK + 4, SA_ROWS = AKM ? BK : BM;
-  static constexpr int SB_STR = BKM ? BN + 4 : BK + 4, SB_ROWS = BKM ? BK : BN;
+  // k-contiguous tiles are read with ds_read_b128, which the LDS services in four NON-contiguous 16-lane groups
+  // ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md "LDS"), each mixing all 16 rows at two neighbouring k-offsets: the row
+  // stride must be == 8 (mod 16) floats for the 16 slots of a group to be distinct.  BK+4 (an odd number of 16-byte slots)
+  // made 7 of 8 pairs collide -- SQ_LDS_BANK_CONFLICT was 33-48 % of SQ_LDS_IDX_ACTIVE in the NT kernels.
+  // Row-contiguous tiles (ds_read_b32, two 32-lane groups, banks mod 32) are conflict-free at +4.
+  static constexpr int SA_STR = AKM ? BM + 4 : BK + 8, SA_ROWS = AKM ? BK : BM;
+  static constexpr int SB_STR = BKM ? BN + 4 : BK + 8, SB_ROWS = BKM ? BK : BN;
   static constexpr int SA_SZ = SA_ROWS * SA_STR, SB_SZ = SB_ROWS * SB_STR;
   static constexpr bool ROW = (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD);
   static constexpr int CSTR = BN + 4;
@@ -470,6 +475,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN >= 16 && TN == 4) ? GT_T128_WAVES : 1) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI>::SMEM];
+#ifndef GT_NO_XCD_REMAP
+  if (gridDim.z == 1) {
+    // XCD-aware placement (as in wgrad_group_kernel): workgroups are dealt round-robin over the 8 XCDs in dispatch order
+    // (x fastest), so the tiles of one A row-panel would land in 8 different L2s and the panel would cross the fabric 8
+    // times -- the waves of the 128x128 kernel spent 71 % of their cycles in s_waitcnt on exactly those loads.  Give each
+    // XCD a contiguous range of the x-fastest tile order instead.  Placement changes speed only, never results.
+    const int gx = gridDim.x, nb = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+    const int xcd = lin & 7, q = nb >> 3, r = nb & 7;
+    const int b = xcd * q + (xcd < r ? xcd : r) + (lin >> 3);
+    gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(g, b % gx, b / gx, 0, smem);
+    return;
+  }
+#endif
   gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
@@ -489,9 +507,15 @@ struct GemmGroup {
 // TM = 2: 64x64 tiles -- large problems (d_model 512, thousands of tokens), where 32x32 tiles are bound by staged bytes
 // and atomics per flop (38 % of the C4 step before the split).  The two sizes go out as SEPARATE launches: sharing one,
 // the 70 KB of LDS of the large tiles halved the occupancy of the small ones.
+#ifndef GT_WGRAD_T64_BK
+#define GT_WGRAD_T64_BK 64
+#endif
+#ifndef GT_WGRAD_T64_MIN
+#define GT_WGRAD_T64_MIN 512
+#endif
 template <int TM>
 __global__ __launch_bounds__(256, TM == 4 ? GT_T128_WAVES : 1) void wgrad_group_kernel(GemmGroup grp) {
-  constexpr int BK = TM == 4 ? 32 : 64;            // 128x128 tiles: 32-token slabs (68 KB of LDS, two workgroups per CU)
+  constexpr int BK = TM == 4 ? 32 : TM == 2 ? GT_WGRAD_T64_BK : 64;   // 128x128 tiles: 32-token slabs (68 KB of LDS, two workgroups per CU)
   typedef GemmCfg<2, 2, TM, TM, BK, true, true, EPI_ATOMIC> C;
   __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
   // XCD-aware placement: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one), each with its own
@@ -566,7 +590,7 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   // chunks, else 32x32 (C2 at bs 64: 16 64x64-tiles x 8 chunks -> stays 32x32)
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
   const int cls = (g.M >= 128 && g.N >= 128 && t128 * ((g.K + 511) / 512) >= GT_WGRAD_T128_MIN) ? 2
-                : (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= 512) ? 1 : 0;
+                : (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= GT_WGRAD_T64_MIN) ? 1 : 0;
   const int tile = 32 << cls;
   if (wb.grp[cls].n == GT_GROUP_MAX) wgrad_flush_one(wb, cls, s);
   const int splitk = wgrad_split(g, cls ? 1024 : 512, tile);
@@ -582,7 +606,10 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
 }
 
 #ifndef GT_T64_MIN
-#define GT_T64_MIN 256
+#define GT_T64_MIN 512
+#endif
+#ifndef GT_T64_BK
+#define GT_T64_BK 32
 #endif
 #ifndef GT_T128_MIN
 #define GT_T128_MIN 512
@@ -602,7 +629,7 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   // workgroup to keep its MFMAs fed, two resident workgroups ask a CU for more than it delivers (46-70 GB/s measured);
   // 128x128x32 slabs need half of that per flop
   if (t128 >= GT_T128_MIN) { g.k_chunk = (g.K + 31) / 32 * 32; gemm_launch_cfg<2, 2, 4, 4, 32, AKM, BKM, EPI>(g, 1, s); }
-  else if (t64 >= GT_T64_MIN) gemm_launch_cfg<2, 2, 2, 2, 64, AKM, BKM, EPI>(g, 1, s);
+  else if (t64 >= GT_T64_MIN) { g.k_chunk = (g.K + GT_T64_BK - 1) / GT_T64_BK * GT_T64_BK; gemm_launch_cfg<2, 2, 2, 2, GT_T64_BK, AKM, BKM, EPI>(g, 1, s); }
   else            gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
 }
 

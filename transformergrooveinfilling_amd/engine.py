@@ -60,6 +60,7 @@ class StepEngine:
         self.algo = ALGO[optimizer.lower()]
         self.penalty = float(hit_loss_penalty)
         self.world_size = int(world_size)
+        self.force_dp = False          # measurement aid: take the data-parallel step sequence even with one rank
         self.use_graph = use_graph
         self.dims = dict(d_model=int(d_model), n_heads=int(n_heads), dim_feedforward=int(dim_feedforward),
                          num_encoder_layers=int(num_encoder_layers), num_decoder_layers=int(num_decoder_layers),
@@ -179,7 +180,7 @@ class StepEngine:
             s.x.copy_(x, non_blocking=True)
         if y is not None:
             s.y.copy_(y, non_blocking=True)
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_dp:
             self._replay(s, ("fused", self.algo, self.penalty), lambda: self._enqueue_step(s, 0))
         else:
             import torch.distributed as dist
