@@ -121,9 +121,17 @@ int gt_backward(const gt_config* cfg, const float* params, float* grads, const f
 int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n,
                       gt_step_state* state, int zero_grads, gt_stream_t stream);
 
+/* Gradient buckets for overlapping the data-parallel all-reduce with backward (no reference counterpart: the
+ * reference is single-device).  Writes up to two [offset, offset+count) ranges of the flat gradient buffer in the order
+ * backward completes them and returns their number: 2 when the model splits (encoder-decoder: decoder half first;
+ * encoder-only with >= 2 layers: upper half of the layers first), else 1 (the whole buffer). */
+int gt_grad_buckets(const gt_config* cfg, int64_t* offsets, int64_t* counts);
+
 /* One whole train step of train_loop's batch body (ref:train.py:195-215): [shift y for the decoder]
  * forward, loss, backward, optimizer update.  tgt_scratch (M,27) is only used when n_dec_layers>0.
- * With skip_update != 0 the optimizer is left to the caller (data-parallel: all-reduce grads first).
+ * skip_update: 0 = the whole step; 1 = no optimizer update (data-parallel: all-reduce grads, then gt_optimizer_step);
+ * 2 = as 1 but backward stops as soon as bucket 0 of gt_grad_buckets() is final; 3 = ONLY the rest of that backward
+ * (same buffers, directly after a skip_update=2 call) -- the caller all-reduces bucket 0 while 3 runs.
  * PRECONDITION: grads is all zeros on entry (zero it once after allocation; the update this call -- or the
  * caller's gt_optimizer_step(zero_grads=1) -- leaves it zeroed again, so no per-step memset is enqueued). */
 int gt_train_step(const gt_config* cfg, int algo, float* params, float* grads, float* m, float* v,

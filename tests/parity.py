@@ -201,3 +201,31 @@ def check_demo_ckpt(backend):
 
 def golden_files():
     return sorted(glob.glob(os.path.join(GOLD, "g2_*.npz")))
+
+
+def check_bucketed_backward(backend, cfg, B, p, n_buckets, exact):
+    """gt_train_step(skip_update=2) must leave bucket 0 of gt_grad_buckets FINAL (that is what the data-parallel path
+    all-reduces while skip_update=3 runs), and 2 followed by 3 must equal the one-call backward (skip_update=1)."""
+    cfg = dict(cfg, dropout=p)
+    P = ng.init_params(cfg, seed=11, perturb=0.05)
+    x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=12)
+    whole = Runner(cfg, B, backend, rng=(5, 6, 0))
+    whole.set_params(P)
+    whole.train_step(x, y, 0.47, skip_update=1)
+    gw = whole.grads.numpy().copy()
+    r = Runner(cfg, B, backend, rng=(5, 6, 0))
+    r.set_params(P)
+    buckets = r.lib.grad_buckets(r.c)
+    assert len(buckets) == n_buckets
+    assert sum(c for _, c in buckets) == r.total and min(o for o, _ in buckets) == 0
+    r.train_step(x, y, 0.47, skip_update=2)
+    g2 = r.grads.numpy().copy()
+    r.train_step(x, y, 0.47, skip_update=3)
+    g3 = r.grads.numpy().copy()
+    tol = 0.0 if exact else 2e-6 * np.abs(gw).max()
+    o0, c0 = buckets[0]
+    assert np.abs(g2[o0:o0 + c0] - gw[o0:o0 + c0]).max() <= tol, "bucket 0 not final after the first half"
+    assert np.abs(g3 - gw).max() <= tol, "two halves differ from the whole backward"
+    if n_buckets == 2:
+        o1, c1 = buckets[1]
+        assert np.abs(gw[o1:o1 + c1]).max() > 0 and np.abs(g2[o1:o1 + c1] - gw[o1:o1 + c1]).max() > 0   # the first half really stops early

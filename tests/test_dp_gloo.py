@@ -1,6 +1,6 @@
 """Data-parallel path on CPU: world_size 2 over gloo.  Each rank runs forward+loss+backward of ITS shard through the
-C ABI (host-emulator build of the kernels), gradients are summed with ONE all-reduce of the flat buffer and
-averaged by grad_scale in the optimizer kernel -> identical replicas that match a single process on the full batch."""
+C ABI (host-emulator build of the kernels), gradients are summed bucket by bucket (gt_grad_buckets: the upper bucket's all-reduce is started
+between the two halves of backward) and averaged by grad_scale in the optimizer kernel -> identical replicas that match a single process on the full batch."""
 import os
 import socket
 import sys
@@ -39,9 +39,14 @@ def _worker(rank, world, port, out):
     flat = torch.from_numpy(run.params.numpy())                            # shares memory with the runner's buffer
     parallel.broadcast_parameters(flat, src=0)                             # ... then made identical
     sl = slice(rank * (B // world), (rank + 1) * (B // world))
-    run.train_step(x[sl], y[sl], 0.47, algo=0, skip_update=True)
+    buckets = run.lib.grad_buckets(run.c)
+    assert len(buckets) == 2                                               # 2 encoder layers: upper layer + heads first
+    run.train_step(x[sl], y[sl], 0.47, algo=0, skip_update=2)              # forward, loss, backward until bucket 0 is final
     g = torch.from_numpy(run.grads.numpy())
-    parallel.allreduce_gradients(g)                                        # ONE collective, SUM
+    w0 = parallel.allreduce_bucket_async(g, *buckets[0])                   # reduced while the rest of backward runs
+    run.train_step(x[sl], y[sl], 0.47, algo=0, skip_update=3)
+    w1 = parallel.allreduce_bucket_async(g, *buckets[1])
+    w0.wait(); w1.wait()
     st = run.step_state()
     st.grad_scale = 1.0 / world
     run.state.numpy()[:] = np.frombuffer(bytes(st), dtype=np.uint8)

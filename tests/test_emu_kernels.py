@@ -57,3 +57,9 @@ def test_golden_small():
 
 def test_demo_checkpoint():
     parity.check_demo_ckpt("emu")
+
+
+@pytest.mark.parametrize("cfg,B,p,nb", [(ENC, 2, 0.25, 2), (cfg_dict(32, 4, 16, 3), 2, 0.0, 2), (ENCDEC, 2, 0.2, 2), (cfg_dict(32, 2, 16, 1, 1), 1, 0.0, 2),
+                                        (cfg_dict(32, 4, 16, 1), 2, 0.1, 1)])
+def test_bucketed_backward(cfg, B, p, nb):
+    parity.check_bucketed_backward("emu", cfg, B, p, nb, exact=True)

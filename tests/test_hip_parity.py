@@ -47,6 +47,12 @@ def test_step_parity_large_batches(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 
 
+@pytest.mark.parametrize("cfg,B,p,nb", [(C2, 64, 0.24, 2), (C3, 4, 0.3, 2), (C1, 32, 0.18, 2), (cfg_dict(128, 4, 512, 1), 8, 0.1, 1)])
+def test_bucketed_backward(cfg, B, p, nb):
+    """data-parallel overlap: the first half of a bucketed backward leaves bucket 0 final, both halves equal the whole"""
+    parity.check_bucketed_backward("hip", cfg, B, p, nb, exact=False)
+
+
 def test_train_step_row_chain_kernels():
     parity.check_train_step("hip", C2, 16, 0.24, chain=True)
 

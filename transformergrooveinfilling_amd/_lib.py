@@ -53,6 +53,7 @@ _SIGS = {
                                      _vp, _vp, _vp, ctypes.c_int, _vp]),
     # cfg, params, pe, x, hvo_out, thres, use_thres, tgt_scratch, ws, stream
     "gt_predict": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),
+    "gt_grad_buckets": (ctypes.c_int, [_cfgp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "gt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_overlap": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_chain": (ctypes.c_int, [ctypes.c_int]),
@@ -102,6 +103,14 @@ class GrooveLib:
         if b == 0:
             raise GrooveLibError("gt_workspace_bytes failed: %s" % self.cdll.gt_last_error().decode())
         return b // 4
+
+    def grad_buckets(self, cfg):
+        """-> [(offset, count)] of the flat gradient buffer in the order backward completes them (1 or 2 buckets)."""
+        off, cnt = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
+        n = self.cdll.gt_grad_buckets(ctypes.byref(cfg), off, cnt)
+        if n < 1:
+            raise GrooveLibError("gt_grad_buckets failed: %s" % self.cdll.gt_last_error().decode())
+        return [(off[i], cnt[i]) for i in range(n)]
 
     def ws_find(self, cfg, name, layer=0):
         o, c = ctypes.c_int64(), ctypes.c_int64()

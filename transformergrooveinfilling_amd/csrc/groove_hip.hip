@@ -556,6 +556,7 @@ static int self_attn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const f
 }
 
 static bool use_chain(const Ctx& x) { return x.c.n_dec_layers == 0 && chain_supported(x.d, x.F) && chain_enabled(); }
+static bool chain_path_for(const gt_config& c) { return c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff) && chain_enabled(); }
 
 template <typename Args>
 static void chain_launch(void (*k64)(Args), void (*k128)(Args), void (*k256)(Args), const Ctx& x, const Args& a) {
@@ -708,9 +709,37 @@ static void input_layer_bwd(const Ctx& x, const LayerP& first, const Tmp& t, con
 }
 
 // d_hvo == nullptr: ws.dlogits already holds d loss / d logits (the fused loss kernel wrote it)
+// Gradient buckets for data-parallel overlap, in the order backward completes them.  Parameters are laid out
+// [in | enc layers | enc norm | (dec in | dec layers | dec norm) | out] and backward walks that list from its end, so
+// "everything from tensor X to the end" is final early: X = the decoder input layer of an encoder-decoder model, else
+// encoder layer L/2.  split_layer: first encoder layer of the upper bucket (enc-dec: L, i.e. no encoder layer).
+struct GradSplit { int nb; int split_layer; int64_t off[2], cnt[2]; };
+static bool chain_path_for(const gt_config& c);
+static GradSplit grad_split(const gt_config& c, const PLayout& P) {
+  GradSplit g;
+  g.nb = 1; g.split_layer = 0; g.off[0] = 0; g.cnt[0] = P.total; g.off[1] = g.cnt[1] = 0;
+  int64_t cut = 0;
+  if (c.n_dec_layers > 0) { cut = P.din_w; g.split_layer = c.n_enc_layers; }
+  else if (c.n_enc_layers >= 2) { g.split_layer = c.n_enc_layers / 2; cut = P.enc[g.split_layer].sa.in_w; }
+  if (cut > 0 && !chain_path_for(c)) {
+    g.nb = 2; g.off[0] = cut; g.cnt[0] = P.total - cut; g.off[1] = 0; g.cnt[1] = cut;
+  }
+  return g;
+}
+extern "C" int gt_grad_buckets(const gt_config* cfg, int64_t* offsets, int64_t* counts) {
+  if (check_cfg(cfg)) return -1;
+  if (!offsets || !counts) return gt_fail("gt_grad_buckets: offsets / counts must not be NULL");
+  const PLayout P = param_layout(*cfg);
+  const GradSplit g = grad_split(*cfg, P);
+  for (int i = 0; i < 2; ++i) { offsets[i] = g.off[i]; counts[i] = g.cnt[i]; }
+  return g.nb;
+}
+
+// phase 0: the whole backward; 1: only until bucket 0 of grad_split() is final; 2: the rest (after a phase-1 call on the
+// same workspace -- the hand-over temporaries live there)
 static int backward_impl(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
                          const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
-                         gt_stream_t stream) {
+                         gt_stream_t stream, int phase = 0) {
   Ctx x;
   if (make_ctx(x, cfg, params, grads, ws, state, train, stream)) return -1;
   if (!grads || !xin) return gt_fail("gt_backward: grads / x must not be NULL");
@@ -729,6 +758,21 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   lnjobs.n = 0; lnjobs.N = d;
   x.ln = &lnjobs;
   const int top = L + Ld - 1;                       // global index of the last layer
+  const GradSplit split = grad_split(*cfg, P);
+  if (split.nb < 2) {                               // nothing to split: phase 1 does everything, phase 2 nothing
+    if (phase == 2) return 0;
+    phase = 0;
+  }
+  // end of a phase: join the side stream, sum the LayerNorm parameter-gradient partials queued so far
+  auto finish = [&]() -> int {
+    acquire_set(x, 0);                              // join: every side-stream dispatch is ordered before what follows
+    acquire_set(x, 1);
+    if (lnjobs.n > 0) {                             // LayerNorm dgamma/dbeta: one launch, fixed order
+      gt_prof_tag("ln_param_reduce", 0, 4.0 * lnjobs.n * W.ln_part_stride);
+      gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(256), x.s, lnjobs);
+    }
+    return launch_status("gt_backward");
+  };
 
   if (use_chain(x)) {
     // ---- row-chain path: per layer ONE chain launch + ONE attention-backward launch; every weight gradient of the
@@ -788,6 +832,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     return launch_status("gt_backward");
   }
 
+  if (phase != 2) {
   // OutputLayer: dlogits, dW_out, then d(final) fused with the final norm's backward
   if (d_hvo != nullptr) {
     gt_prof_tag("heads_bwd", 0, 12.0 * M * GT_TGT);
@@ -844,16 +889,20 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
         wgrad_sync(x, gl);
       }
     }
+  }
+  }                                                 // phase != 2
+  if (Ld > 0) {
+    if (phase == 1) return finish();                // decoder half (bucket 0) done; ws.dmem holds the memory gradient
     // encoder final norm backward (input: accumulated dmem) -> grad w.r.t. the last encoder layer's output
     ln_bwd(x, ws + W.dmem, nullptr, ws + W.enc_xhat, ws + W.enc_rstd, P.encn_w, ws + W.dctx, nullptr, 0);
   }
-  {
+  if (phase != 2 || Ld > 0) {
     const LayerW& w = W.layers[L - 1];
     const Tmp t = tmp_set(x, L - 1);
     acquire_set(x, L - 1);
     ln_bwd(x, ws + W.dctx, nullptr, ws + w.xhat2, ws + w.rstd2, P.enc[L - 1].n2w, t.dzA, t.dzAm, lsite(L - 1, GT_SITE_DROPF));
   }
-  for (int l = L - 1; l >= 0; --l) {
+  for (int l = (phase == 2 && Ld == 0) ? split.split_layer - 1 : L - 1; l >= 0; --l) {
     const LayerP& p = P.enc[l];
     const LayerW& w = W.layers[l];
     const Tmp t = tmp_set(x, l);
@@ -868,18 +917,13 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
       if (dgrad_lnbwd(x, t.dqkv, 3 * d, params + p.sa.in_w, 3 * d, t.dzB, ws + wp.xhat2, ws + wp.rstd2, P.enc[l - 1].n2w, tn.dzA, tn.dzAm,
                       lsite(l - 1, GT_SITE_DROPF)))
         return -1;
+      if (phase == 1 && Ld == 0 && l == split.split_layer) return finish();   // layers >= split are final; (dzA, dzAm) of l-1 handed over
     } else {
       input_layer_bwd(x, p, t, t.dzB, ws + W.a0, xin, cfg->src_dim, P.in_w, P.in_b, GT_SITE_PE_ENC, ws + W.dctx);
       wgrad_sync(x, l);
     }
   }
-  acquire_set(x, 0);                                // join: every side-stream dispatch is ordered before what follows
-  acquire_set(x, 1);
-  if (lnjobs.n > 0) {                               // all LayerNorm dgamma/dbeta of the step: one launch, fixed order
-    gt_prof_tag("ln_param_reduce", 0, 4.0 * lnjobs.n * W.ln_part_stride);
-    gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(256), x.s, lnjobs);
-  }
-  return launch_status("gt_backward");
+  return finish();
 }
 
 extern "C" int gt_backward(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
@@ -915,14 +959,17 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
                              float* tgt_scratch, float* ws, gt_step_state* state, int skip_update, gt_stream_t stream) {
   if (check_cfg(cfg)) return -1;
   if (!y || !state) return gt_fail("gt_train_step: y / state must not be NULL");
+  if (skip_update < 0 || skip_update > 3) return gt_fail("gt_train_step: skip_update %d outside 0..3", skip_update);
   const int M = cfg->batch * 32;
   hipStream_t s = (hipStream_t)stream;
   const float* tgt_in = nullptr;
   if (cfg->n_dec_layers > 0) {
     if (!tgt_scratch) return gt_fail("gt_train_step: encoder-decoder model needs tgt_scratch");
-    gt_launch(shift_right_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), s, y, tgt_scratch, M * GT_TGT);
     tgt_in = tgt_scratch;
   }
+  if (skip_update == 3)                             // second half of a bucketed backward (tgt_scratch still holds the shifted y)
+    return backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, 2);
+  if (tgt_in) gt_launch(shift_right_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), s, y, tgt_scratch, M * GT_TGT);
   if (gt_forward(cfg, params, pe, xin, tgt_in, hvo_out, ws, state, 1, stream)) return -1;
   // loss + head-activation backward in one kernel: d loss / d logits straight into ws.dlogits; workgroup partials are
   // combined by the last-arriving workgroup (ticket in the step state), so there is no memset node and the stats are
@@ -932,7 +979,7 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   gt_prof_tag("loss", 0, 12.0 * M * GT_TGT);
   gt_launch(loss_kernel<true, true>, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, (const float*)hvo_out, y, hit_loss_penalty, stats,
             ws + W.dlogits, M, ws + W.loss_part, reinterpret_cast<unsigned*>(&state->pad2[0]));
-  if (backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream)) return -1;
+  if (backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, skip_update == 2 ? 1 : 0)) return -1;
   if (!skip_update) {
     PLayout P = param_layout(*cfg);
     if (gt_optimizer_step(algo, params, grads, m, v, P.total, state, 1, stream)) return -1;

@@ -13,6 +13,7 @@ model.predict (ref:evaluator.py:173).  Data-parallel: one process per GPU, gradi
 all-reduce over the flat buffer and averaged inside the optimizer kernel (grad_scale = 1/world).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -42,7 +43,7 @@ class _Slot:
         self.tgt = torch.zeros(B, 32, 27, **f32)
         self.stats = torch.zeros(8, **f32)
         self.graph = None
-        self.graph_key = None
+        self.graphs = {}               # step recipe -> captured hipGraph
 
 
 class StepEngine:
@@ -61,6 +62,10 @@ class StepEngine:
         self.penalty = float(hit_loss_penalty)
         self.world_size = int(world_size)
         self.force_dp = False          # measurement aid: take the data-parallel step sequence even with one rank
+        # Two gradient buckets, the first all-reduced under the rest of backward.  Opt-in: splitting the step into two graphs
+        # costs ~90 us per step on one GPU (0.434 vs 0.344 ms at the C2 shape, bench.py --force-dp), more than a 2.4 MB
+        # all-reduce takes; it can only pay for models whose all-reduce is several hundred microseconds.
+        self.overlap_allreduce = os.environ.get("GT_DP_OVERLAP", "0") == "1"
         self.use_graph = use_graph
         self.dims = dict(d_model=int(d_model), n_heads=int(n_heads), dim_feedforward=int(dim_feedforward),
                          num_encoder_layers=int(num_encoder_layers), num_decoder_layers=int(num_decoder_layers),
@@ -149,15 +154,20 @@ class StepEngine:
         self.lib.call("gt_optimizer_step", self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v),
                       ctypes.c_int64(self.total), _ptr(self.state), int(zero_grads), self.stream)
 
-    def _replay(self, s, key, fn):
+    def _replay(self, s, key, fn, aux=False):
+        """Replay the hipGraph captured for `key` on slot s (captured on first use).  aux=True: a graph that continues a
+        step another graph began (second half of a bucketed backward) -- it keeps the slot's other graphs."""
         if not self.use_graph:
             fn()
             return
-        if s.graph_key != key:
-            # one launch outside capture (code-object load), state restored, then capture once
+        if key not in s.graphs:
+            if not aux:
+                s.graphs.clear()                  # a new step recipe (optimizer / penalty changed): drop the old graphs
+            # one launch outside capture (code-object load), every buffer it touched restored, then capture once
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
-            snap = (self.params.clone(), self.state.clone(), None if self.m is None else (self.m.clone(), self.v.clone()))
+            snap = (self.params.clone(), self.state.clone(), None if self.m is None else (self.m.clone(), self.v.clone()),
+                    self.grads.clone())
             with torch.cuda.stream(side):
                 fn()
             torch.cuda.current_stream(self.device).wait_stream(side)
@@ -165,12 +175,12 @@ class StepEngine:
             self.params.copy_(snap[0]); self.state.copy_(snap[1])
             if snap[2] is not None:
                 self.m.copy_(snap[2][0]); self.v.copy_(snap[2][1])
-            self.grads.zero_()                    # gt_train_step's precondition (the update re-zeroes it every step)
+            self.grads.copy_(snap[3])             # zeros for a whole-step graph (gt_train_step's precondition), else what the first half left
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fn()
-            s.graph, s.graph_key = g, key
-        s.graph.replay()
+            s.graphs[key] = g
+        s.graphs[key].replay()
 
     def train_step(self, x=None, y=None):
         """One optimisation step on (x, y) (device or host tensors; None = reuse the static buffers).
@@ -184,8 +194,22 @@ class StepEngine:
             self._replay(s, ("fused", self.algo, self.penalty), lambda: self._enqueue_step(s, 0))
         else:
             import torch.distributed as dist
-            self._replay(s, ("fwdbwd", self.algo, self.penalty), lambda: self._enqueue_step(s, 1))
-            dist.all_reduce(self.grads)                      # RCCL sum over xGMI; averaged by grad_scale
+            buckets = self.lib.grad_buckets(s.cfg) if self.overlap_allreduce else []
+            if len(buckets) == 2:
+                # bucketed overlap: graph A ends as soon as the upper bucket's gradients are final; its
+                # all-reduce (RCCL stream) runs under graph B, the rest of backward.  The collectives stay OUTSIDE the
+                # captured graphs.  Sums over ranks; averaged by grad_scale inside the optimizer kernel.
+                (o0, c0), (o1, c1) = buckets
+                self._replay(s, ("bwd_top", self.algo, self.penalty), lambda: self._enqueue_step(s, 2))
+                w0 = dist.all_reduce(self.grads[o0:o0 + c0], async_op=True)
+                if self.use_graph and ("bwd_rest", self.algo, self.penalty) not in s.graphs:
+                    w0.wait()                     # first step only: the capture warm-up snapshots and restores the gradient buffer
+                self._replay(s, ("bwd_rest", self.algo, self.penalty), lambda: self._enqueue_step(s, 3), aux=True)
+                w1 = dist.all_reduce(self.grads[o1:o1 + c1], async_op=True)
+                w0.wait(); w1.wait()
+            else:
+                self._replay(s, ("fwdbwd", self.algo, self.penalty), lambda: self._enqueue_step(s, 1))
+                dist.all_reduce(self.grads)                  # RCCL sum over xGMI; averaged by grad_scale
             self.enqueue_update()
         return s.stats
 

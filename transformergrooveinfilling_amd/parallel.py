@@ -46,6 +46,15 @@ def allreduce_gradients(flat, average=False):
     return flat
 
 
+def allreduce_bucket_async(flat, offset, count):
+    """Start the SUM all-reduce of flat[offset:offset+count] (one gradient bucket of gt_grad_buckets) and return its work
+    handle (None without a process group); call .wait() before the optimizer reads the buffer.  Issued between the two
+    halves of a bucketed backward, the collective runs while the second half computes."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.all_reduce(flat[offset:offset + count], op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
 class ShardedBatchSampler:
     """Replaces DataLoader(shuffle=True) (ref:train.py:156-158) under DP: every rank draws the SAME seeded
     permutation of the epoch and keeps indices rank, rank+world, ...; yields lists of `batch_size` indices.
