@@ -781,7 +781,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     acquire_set(x, 1);
     if (lnjobs.n > 0) {                             // LayerNorm dgamma/dbeta: one launch, fixed order
       gt_prof_tag("ln_param_reduce", 0, 4.0 * lnjobs.n * W.ln_part_stride);
-      gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(256), x.s, lnjobs);
+      gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(1024), x.s, lnjobs);
     }
     return launch_status("gt_backward");
   };
@@ -840,7 +840,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     wgrad(x, ws + W.dctx, d, xin, cfg->src_dim, grads + P.in_w, grads + P.in_b, d, cfg->src_dim);
     if (!wbatch.empty()) wgrad_flush(wbatch, x.s);
     gt_prof_tag("ln_param_reduce", 0, 4.0 * lnjobs.n * W.ln_part_stride);
-    gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(256), x.s, lnjobs);
+    gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(1024), x.s, lnjobs);
     return launch_status("gt_backward");
   }
 

@@ -566,6 +566,13 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
 // GT_WGRAD_T128_MIN counts ONE problem's 128x128-tile workgroups; a launch groups the 4-6 problems of a layer, so 32 per
 // problem already fills the chip (A/B on one box: 512 -> 32 took C3 from 6.92 to 6.22 ms; 16 pulls C2's M=2048 problems in
 // and costs the headline shape 30 %).
+// workgroups one problem is split into (over the token dimension); a dispatch groups every problem of the step
+#ifndef GT_WGRAD_SPLIT_SMALL
+#define GT_WGRAD_SPLIT_SMALL 512
+#endif
+#ifndef GT_WGRAD_SPLIT_BIG
+#define GT_WGRAD_SPLIT_BIG 1024
+#endif
 #ifndef GT_WGRAD_T128_MIN
 #define GT_WGRAD_T128_MIN 32
 #endif
@@ -593,7 +600,7 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
                 : (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= GT_WGRAD_T64_MIN) ? 1 : 0;
   const int tile = 32 << cls;
   if (wb.grp[cls].n == GT_GROUP_MAX) wgrad_flush_one(wb, cls, s);
-  const int splitk = wgrad_split(g, cls ? 1024 : 512, tile);
+  const int splitk = wgrad_split(g, cls ? GT_WGRAD_SPLIT_BIG : GT_WGRAD_SPLIT_SMALL, tile);
   GemmGroup& G = wb.grp[cls];
   const int i = G.n++;
   G.p[i] = g;

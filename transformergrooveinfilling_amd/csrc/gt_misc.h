@@ -123,12 +123,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
 }
 
 // dgamma / dbeta of every LayerNorm of the step in ONE launch: job j sums its workgroup partials [nwg][2][N] in a fixed
-// order (deterministic) and adds them into the gradient buffer.  grid = (ceil(2N/64), jobs); 4 waves split the partials.
+// order (deterministic) and adds them into the gradient buffer.  grid = (ceil(2N/64), jobs); 16 waves split the partials.
 #define GT_LN_JOBS_MAX 96
 struct LnJob { const float* part; float* dgamma; float* dbeta; int nwg; };
 struct LnJobs { int n, N; LnJob j[GT_LN_JOBS_MAX]; };
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnJobs jobs) {
-  __shared__ float s[4][64];
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnJobs jobs) {
+  // 16 waves split the partial rows; every lane has 8 independent loads in flight per trip (a 4-wave version walking 16
+  // dependent trips took 8.4 us for 3.7 MB of partials: latency, not bandwidth).  Fixed summation order -> deterministic.
+  __shared__ float s[16][64];
   const LnJob jb = jobs.j[blockIdx.y];
   const float* const zp = gt_zero_ptr();
   const int N = jobs.N, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -136,20 +138,23 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnJobs jobs) {
   const bool ok = c2 < 2 * N;
   const int which = (ok && c2 >= N) ? 1 : 0, c = ok ? c2 - which * N : 0;
   float acc = 0.f;
-  for (int g0 = w; g0 < jb.nwg; g0 += 16) {              // 4 independent loads in flight per lane
-    float v[4];
+  for (int g0 = w; g0 < jb.nwg; g0 += 128) {
+    float v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int gidx = g0 + 4 * u;
+    for (int u = 0; u < 8; ++u) {
+      const int gidx = g0 + 16 * u;
       v[u] = *((ok && gidx < jb.nwg) ? jb.part + ((size_t)gidx * 2 + which) * N + c : zp);
     }
-    acc += (v[0] + v[1]) + (v[2] + v[3]);
+    acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   }
   s[w][lane] = acc;
   __syncthreads();
   if (w == 0 && ok) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s[q][lane];
     float* dst = which ? jb.dbeta : jb.dgamma;
-    dst[c] += (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+    dst[c] += t;
   }
 }
 
@@ -217,11 +222,14 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ hvo
   }
   __syncthreads();
   if (!is_last) return;
-  // fixed-order sum: thread q (q < 4) walks all workgroups for quantity q
-  if (threadIdx.x < 4) {
+  // fixed-order sum: wave q sums quantity q -- lane l takes workgroups l, l+64, ... (all loads in flight at once), then
+  // the xor-tree of gt_wave_sum; the order depends only on the grid size, so the stats stay bitwise reproducible
+  {
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
     float acc = 0.f;
-    for (unsigned bk = 0; bk < gridDim.x; ++bk) acc += partials[bk * 4 + threadIdx.x];
-    red[0][threadIdx.x] = acc * invM;
+    for (unsigned bk = l; bk < gridDim.x; bk += 64) acc += partials[bk * 4 + q];
+    acc = gt_wave_sum(acc);
+    if (l == 0) red[0][q] = acc * invM;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
