@@ -750,7 +750,7 @@ extern "C" int gt_grad_buckets(const gt_config* cfg, int64_t* offsets, int64_t* 
 // same workspace -- the hand-over temporaries live there)
 static int backward_impl(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
                          const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
-                         gt_stream_t stream, int phase = 0) {
+                         gt_stream_t stream, int phase = 0, gt_step_state* bump_state = nullptr) {
   Ctx x;
   if (make_ctx(x, cfg, params, grads, ws, state, train, stream)) return -1;
   if (!grads || !xin) return gt_fail("gt_backward: grads / x must not be NULL");
@@ -766,7 +766,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   x.wb = &wbatch;
   x.side = side_stream();
   LnJobs lnjobs;
-  lnjobs.n = 0; lnjobs.N = d;
+  lnjobs.n = 0; lnjobs.N = d; lnjobs.bump = nullptr;
   x.ln = &lnjobs;
   const int top = L + Ld - 1;                       // global index of the last layer
   const GradSplit split = grad_split(*cfg, P);
@@ -780,6 +780,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     acquire_set(x, 0);                              // join: every side-stream dispatch is ordered before what follows
     acquire_set(x, 1);
     if (lnjobs.n > 0) {                             // LayerNorm dgamma/dbeta: one launch, fixed order
+      lnjobs.bump = bump_state;
       gt_prof_tag("ln_param_reduce", 0, 4.0 * lnjobs.n * W.ln_part_stride);
       gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(1024), x.s, lnjobs);
     }
@@ -839,6 +840,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     }
     wgrad(x, ws + W.dctx, d, xin, cfg->src_dim, grads + P.in_w, grads + P.in_b, d, cfg->src_dim);
     if (!wbatch.empty()) wgrad_flush(wbatch, x.s);
+    lnjobs.bump = bump_state;
     gt_prof_tag("ln_param_reduce", 0, 4.0 * lnjobs.n * W.ln_part_stride);
     gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(1024), x.s, lnjobs);
     return launch_status("gt_backward");
@@ -946,8 +948,9 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
 }
 
 // ------------------------------------------------------------------------------------ optimizer
-extern "C" int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n, gt_step_state* state,
-                                 int zero_grads, gt_stream_t stream) {
+// step_advanced: the caller's previous launch already advanced step / opt_step (fused train step, see LnJobs::bump)
+static int optimizer_step_impl(int algo, float* params, float* grads, float* m, float* v, int64_t n, gt_step_state* state,
+                               int zero_grads, gt_stream_t stream, int step_advanced) {
   if (!params || !grads || !state || n <= 0) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 1023) / 1024);
@@ -957,12 +960,16 @@ extern "C" int gt_optimizer_step(int algo, float* params, float* grads, float* m
   } else if (algo == 1) {
     if (!m || !v) return gt_fail("gt_optimizer_step: adam needs m and v");
     gt_prof_tag("optimizer", 0, 28.0 * n);
-    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state, zero_grads);
+    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state, zero_grads, step_advanced);
   } else {
     return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
   }
-  gt_launch(step_inc_kernel, dim3(1), dim3(64), s, state);
+  if (!step_advanced) gt_launch(step_inc_kernel, dim3(1), dim3(64), s, state);
   return launch_status("gt_optimizer_step");
+}
+extern "C" int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n, gt_step_state* state,
+                                 int zero_grads, gt_stream_t stream) {
+  return optimizer_step_impl(algo, params, grads, m, v, n, state, zero_grads, stream, 0);
 }
 
 // ------------------------------------------------------------------------------------ fused train step
@@ -991,10 +998,14 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   gt_prof_tag("loss", 0, 12.0 * M * GT_TGT);
   gt_launch(loss_kernel<true, true>, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, (const float*)hvo_out, y, hit_loss_penalty, stats,
             ws + W.dlogits, M, ws + W.loss_part, reinterpret_cast<unsigned*>(&state->pad2[0]));
-  if (backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, skip_update == 2 ? 1 : 0)) return -1;
+  // whole step: the last launch of backward (the LayerNorm partials reduce -- every model has LayerNorms) also advances the
+  // step counters, and the optimizer is told so: one launch less than update + step_inc
+  if (backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, skip_update == 2 ? 1 : 0,
+                    skip_update == 0 ? state : nullptr))
+    return -1;
   if (!skip_update) {
     PLayout P = param_layout(*cfg);
-    if (gt_optimizer_step(algo, params, grads, m, v, P.total, state, 1, stream)) return -1;
+    if (optimizer_step_impl(algo, params, grads, m, v, P.total, state, 1, stream, 1)) return -1;
   }
   return 0;
 }

@@ -126,11 +126,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
 // order (deterministic) and adds them into the gradient buffer.  grid = (ceil(2N/64), jobs); 16 waves split the partials.
 #define GT_LN_JOBS_MAX 96
 struct LnJob { const float* part; float* dgamma; float* dbeta; int nwg; };
-struct LnJobs { int n, N; LnJob j[GT_LN_JOBS_MAX]; };
+struct LnJobs {
+  int n, N;
+  gt_step_state* bump;       // fused train step: this launch (the last of backward; nothing after it regenerates a dropout mask) also
+                             // advances step / opt_step -- the optimizer that follows is told so -- saving the step_inc launch
+  LnJob j[GT_LN_JOBS_MAX];
+};
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnJobs jobs) {
   // 16 waves split the partial rows; every lane has 8 independent loads in flight per trip (a 4-wave version walking 16
   // dependent trips took 8.4 us for 3.7 MB of partials: latency, not bandwidth).  Fixed summation order -> deterministic.
   __shared__ float s[16][64];
+  if (jobs.bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { jobs.bump->step += 1u; jobs.bump->opt_step += 1u; }
   const LnJob jb = jobs.j[blockIdx.y];
   const float* const zp = gt_zero_ptr();
   const int N = jobs.N, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -279,8 +285,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, const gt_step_state* st, int zero_grads) {
-  const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->opt_step + 1u);
+                                                   float* __restrict__ v, int64_t n, const gt_step_state* st, int zero_grads,
+                                                   int step_advanced) {
+  const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->opt_step + (step_advanced ? 0u : 1u));
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = st->lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
   const float gs = st->grad_scale, eps = st->eps;
