@@ -1,0 +1,63 @@
+// Micro-benchmark over the REAL kernels of gt_gemm.h: one GEMM shape, several tile configurations, TFLOP/s each.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I transformergrooveinfilling_amd/csrc tools/ubench/gemm_bench.hip -o tools/ubench/gemm_bench
+//   tools/ubench/gemm_bench [M N K]        (default: the d_model 512 QKV projection at 16384 tokens)
+#include "gt_gemm.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+GtProfile g_prof;
+void gt_prof_events(hipEvent_t*, hipEvent_t*) {}
+
+template <int WM, int WN, int TM, int TN, int BK, bool AKM, bool BKM, int EPI>
+static void run(const char* tag, GemmArgs g, int reps) {
+  typedef GemmCfg<WM, WN, TM, TN, BK, AKM, BKM, EPI> Cfg;
+  g.k_chunk = (g.K + BK - 1) / BK * BK;
+  dim3 grid((g.N + Cfg::BN - 1) / Cfg::BN, (g.M + Cfg::BM - 1) / Cfg::BM, 1);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) gemm_kernel<WM, WN, TM, TN, BK, AKM, BKM, EPI><<<grid, dim3(Cfg::NT)>>>(g);
+  hipEventRecord(a);
+  for (int i = 0; i < reps; ++i) gemm_kernel<WM, WN, TM, TN, BK, AKM, BKM, EPI><<<grid, dim3(Cfg::NT)>>>(g);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double us = 1e3 * ms / reps, tf = 2.0 * g.M * g.N * g.K / us / 1e6;
+  printf("%-44s grid %5d x %3d  LDS %6d B  %8.1f us  %6.1f TFLOP/s  (%.1f %% of 157.3)\n", tag, grid.y, grid.x, (int)(Cfg::SMEM * 4), us, tf,
+         100.0 * tf / 157.3);
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 3 ? atoi(argv[1]) : 16384, N = argc > 3 ? atoi(argv[2]) : 1536, K = argc > 3 ? atoi(argv[3]) : 512;
+  float *A, *B, *C, *bias;
+  hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&bias, (size_t)N * 4);
+  std::vector<float> h((size_t)M * K);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 20 & 1023) / 1024.0f - 0.5f;
+  hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
+  hipMemcpy(B, h.data(), (size_t)(N < M ? N : M) * K * 4, hipMemcpyHostToDevice);
+  hipMemset(bias, 0, (size_t)N * 4);
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.bias = bias;
+  printf("C[%d,%d] = A[%d,%d] * B[%d,%d]^T   (NT: both operands k-contiguous, EPI_STORE)\n", M, N, M, K, N, K);
+  const int reps = 20;
+#ifdef GT_BENCH_NOEPI
+  g.mask_scale = 12345.f;
+  printf("(epilogue skipped: main loop only)\n");
+#endif
+  run<2, 2, 1, 1, 64, false, false, EPI_STORE>("32x32   <2,2,1,1,BK64>", g, reps);
+  run<2, 2, 2, 2, 32, false, false, EPI_STORE>("64x64   <2,2,2,2,BK32>", g, reps);
+  run<2, 2, 2, 2, 64, false, false, EPI_STORE>("64x64   <2,2,2,2,BK64>", g, reps);
+  run<2, 2, 4, 4, 16, false, false, EPI_STORE>("128x128 <2,2,4,4,BK16>", g, reps);
+  run<2, 2, 4, 4, 32, false, false, EPI_STORE>("128x128 <2,2,4,4,BK32>", g, reps);
+  run<2, 2, 4, 4, 64, false, false, EPI_STORE>("128x128 <2,2,4,4,BK64>", g, reps);
+  run<2, 4, 4, 2, 32, false, false, EPI_STORE>("128x128 <2,4,4,2,BK32> 8 waves", g, reps);
+  run<4, 2, 4, 4, 32, false, false, EPI_STORE>("256x128 <4,2,4,4,BK32> 8 waves", g, reps);
+  run<2, 4, 4, 4, 32, false, false, EPI_STORE>("128x256 <2,4,4,4,BK32> 8 waves", g, reps);
+  run<4, 2, 4, 4, 16, false, false, EPI_STORE>("256x128 <4,2,4,4,BK16> 8 waves", g, reps);
+  // NN (dgrad): B row-contiguous
+  g.ldb = N;   // B[k*ldb + n]: reuse the buffer as a (K x N) matrix (N*K floats)
+  printf("NN (dgrad layout: B[k][n])\n");
+  run<2, 2, 1, 1, 64, false, true, EPI_STORE>("32x32   <2,2,1,1,BK64>", g, reps);
+  run<2, 2, 4, 4, 32, false, true, EPI_STORE>("128x128 <2,2,4,4,BK32>", g, reps);
+  run<4, 2, 4, 4, 32, false, true, EPI_STORE>("256x128 <4,2,4,4,BK32> 8 waves", g, reps);
+  return 0;
+}

@@ -246,7 +246,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
           for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b] = GT_MFMA16(af[a][j], bf[b][j], acc[a][b]);
+            for (int b = 0; b < TN; ++b)      // D = Btile Atile^T except for the atomic epilogue: see "accumulator layout"
+              acc[a][b] = (EPI != EPI_ATOMIC) ? GT_MFMA16(bf[b][j], af[a][j], acc[a][b]) : GT_MFMA16(af[a][j], bf[b][j], acc[a][b]);
       }
 
       if (EPI == EPI_ATOMIC && AKM) {
@@ -271,72 +272,149 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   const uint32_t dkey = gt_drop_key(g.drop);
   auto ldg = [zp](const float* p, size_t idx, bool ok) -> float { return *(ok ? p + idx : zp); };
 
+#ifdef GT_BENCH_NOEPI
+  // tools/ubench/gemm_bench.hip only: main loop alone (the accumulators stay live through a store that never happens)
+  if (EPI == EPI_STORE && g.mask_scale == 12345.f) {
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) t += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (t == 123.456f) g.C[0] = t;
+    return;
+  }
+#endif
   if (!Cfg::ROW) {
     if (EPI == EPI_ATOMIC && AKM) {
       if (g.dbias != nullptr && bx == 0 && tid < BM && m0 + tid < g.M) atomicAdd(&g.dbias[m0 + tid], bsum);
     }
+    // Accumulator layout.  The MFMAs compute the TRANSPOSED tile (first operand = B fragment, second = A fragment), so lane
+    // (l16, lg) holds, in the 4 registers of tile (a, b), output row  m0 + (wm TM + a) 16 + l16  and the four CONSECUTIVE
+    // columns  n0 + (wn TN + b) 16 + 4 lg + r:  one 16-byte store per tile per lane (64-byte row segments per 4 lanes)
+    // instead of four 4-byte stores -- the untransposed form spent 12 % of a 128x128 GEMM in its epilogue.
+    // EPI_ATOMIC keeps the untransposed tile (rows 4 lg + r, column l16): one atomic instruction then covers 4 rows x 64
+    // contiguous bytes; transposed it would touch 16 rows x 4 scattered dwords (measured: weight gradients 47 -> 78 us).
+    constexpr bool TR = (EPI != EPI_ATOMIC);
     constexpr bool NEED_R1 = (EPI == EPI_STORE || EPI == EPI_RELU_PE || EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP);
     constexpr bool NEED_R2 = (EPI == EPI_ADD_RELUMASK_DROP);
     constexpr bool NEED_BIAS = (EPI == EPI_STORE || EPI == EPI_RELU_PE || EPI == EPI_RELU_DROP || EPI == EPI_HEADS);
-    float bia[TN], r1[NEED_R1 ? TM : 1][NEED_R1 ? TN : 1][4], r2[NEED_R2 ? TM : 1][NEED_R2 ? TN : 1][4];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int col = n0 + (wn * TN + b) * 16 + l16;
-      bia[b] = NEED_BIAS ? ldg(g.bias, col, g.bias != nullptr && col < g.N) : 0.f;
-    }
-    if (NEED_R1) {
+    const bool need_r1 = NEED_R1 && (EPI != EPI_STORE || g.accumulate != 0);      // wave-uniform: no dummy loads for a plain store
+    const float* r1src = EPI == EPI_STORE ? g.C : EPI == EPI_RELU_PE ? g.pe : g.res;
+    const int r1ld = EPI == EPI_STORE ? g.ldc : EPI == EPI_RELU_PE ? g.N : g.ldres;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // 16-byte path: every row start and every 4-column group is 16-byte aligned in all tensors the epilogue touches
+    const bool vec = EPI != EPI_ATOMIC && EPI != EPI_HEADS && (g.N & 3) == 0 && (g.ldc & 3) == 0 && al16(g.C) &&
+                     (!NEED_BIAS || g.bias == nullptr || al16(g.bias)) && (!need_r1 || ((r1ld & 3) == 0 && al16(r1src))) &&
+                     (!NEED_R2 || al16(g.aux_in)) && (EPI != EPI_RELU_PE || al16(g.aux));
+    auto row_of = [&](int a) { return m0 + (wm * TM + a) * 16 + (TR ? l16 : 4 * lg); };     // + r if !TR
+    auto col_of = [&](int b) { return n0 + (wn * TN + b) * 16 + (TR ? 4 * lg : l16); };     // + r if TR
+    float bia[TN][4], r1[NEED_R1 ? TM : 1][NEED_R1 ? TN : 1][4], r2[NEED_R2 ? TM : 1][NEED_R2 ? TN : 1][4];
+    if (NEED_R1 && !need_r1) {                    // plain store: nothing to read back
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = m0 + (wm * TM + a) * 16 + 4 * lg + r;
-            const int col = n0 + (wn * TN + b) * 16 + l16;
-            const bool ok = row < g.M && col < g.N;
-            if (EPI == EPI_STORE) r1[a][b][r] = ldg(g.C, (size_t)row * g.ldc + col, ok && g.accumulate);
-            else if (EPI == EPI_RELU_PE) r1[a][b][r] = ldg(g.pe, (size_t)(row & 31) * g.N + col, ok);
-            else r1[a][b][r] = ldg(g.res, (size_t)row * g.ldres + col, ok);
-            if (NEED_R2) r2[a][b][r] = ldg(g.aux_in, (size_t)row * g.N + col, ok);
-          }
+          for (int r = 0; r < 4; ++r) r1[a][b][r] = 0.f;
     }
+    // ---- phase 1: every global input of the epilogue, unconditionally (address-select against the zero page)
+    if (vec) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+      for (int b = 0; b < TN; ++b) {
+        const int col = col_of(b);
+        const float4 t = *reinterpret_cast<const float4*>((NEED_BIAS && g.bias != nullptr && col < g.N) ? g.bias + col : zp);
+        bia[b][0] = t.x; bia[b][1] = t.y; bia[b][2] = t.z; bia[b][3] = t.w;
+      }
+      if (NEED_R1 && need_r1) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            const int row = row_of(a), col = col_of(b);
+            const bool ok = row < g.M && col < g.N;
+            const int rrow = EPI == EPI_RELU_PE ? (row & 31) : row;
+            const float4 t = *reinterpret_cast<const float4*>(ok ? r1src + ((size_t)rrow * r1ld + col) : zp);
+            r1[a][b][0] = t.x; r1[a][b][1] = t.y; r1[a][b][2] = t.z; r1[a][b][3] = t.w;
+            if (NEED_R2) {
+              const float4 u = *reinterpret_cast<const float4*>(ok ? g.aux_in + ((size_t)row * g.N + col) : zp);
+              r2[a][b][0] = u.x; r2[a][b][1] = u.y; r2[a][b][2] = u.z; r2[a][b][3] = u.w;
+            }
+          }
+      }
+    } else {
 #pragma unroll
       for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = m0 + (wm * TM + a) * 16 + 4 * lg + r;
-          const int col = n0 + (wn * TN + b) * 16 + l16;
-          if (row < g.M && col < g.N) {
-            float v = acc[a][b][r];
-            const size_t ci = (size_t)row * g.ldc + col;
-            if (EPI == EPI_STORE) {
-              g.C[ci] = v + bia[b] + r1[a][b][r];
-            } else if (EPI == EPI_ATOMIC) {
-              atomicAdd(&g.C[ci], v);
-            } else if (EPI == EPI_RELU_PE) {
-              v += bia[b];
-              g.aux[(size_t)row * g.N + col] = v;
-              v = fmaxf(v, 0.f) + r1[a][b][r];
-              g.C[ci] = v * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
-            } else if (EPI == EPI_RELU_DROP) {
-              v = fmaxf(v + bia[b], 0.f);
-              g.C[ci] = v * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
-            } else if (EPI == EPI_HEADS) {
-              v += bia[b];
-              if (col >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
-              else if (col >= GT_VOICES) v = gt_sigmoid(v);
-              g.C[ci] = v;
-            } else if (EPI == EPI_MASK_NZ) {
-              g.C[ci] = (r1[a][b][r] != 0.f) ? v * g.mask_scale : 0.f;
-            } else if (EPI == EPI_ADD_RELUMASK_DROP) {
-              v += r1[a][b][r];
-              v *= gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col));
-              g.C[ci] = (r2[a][b][r] > 0.f) ? v : 0.f;
+          const int col = col_of(b) + (TR ? r : 0);
+          bia[b][r] = NEED_BIAS ? ldg(g.bias, col, g.bias != nullptr && col < g.N) : 0.f;
+        }
+      if (NEED_R1 && need_r1) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = row_of(a) + (TR ? 0 : r), col = col_of(b) + (TR ? r : 0);
+              const bool ok = row < g.M && col < g.N;
+              const int rrow = EPI == EPI_RELU_PE ? (row & 31) : row;
+              r1[a][b][r] = ldg(r1src, (size_t)rrow * r1ld + col, ok);
+              if (NEED_R2) r2[a][b][r] = ldg(g.aux_in, (size_t)row * g.N + col, ok);
+            }
+      }
+    }
+    // ---- phase 2: compute + predicated stores
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int row0 = row_of(a), col0 = col_of(b);
+        float o[4], o2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + (TR ? 0 : r), col = col0 + (TR ? r : 0);
+          float v = acc[a][b][r];
+          const uint32_t didx = (uint32_t)(row * g.N + col);
+          o2[r] = 0.f;
+          if (EPI == EPI_STORE) {
+            v = v + bia[b][r] + r1[a][b][r];
+          } else if (EPI == EPI_RELU_PE) {
+            v += bia[b][r];
+            o2[r] = v;                                                   // aux = pre-activation
+            v = (fmaxf(v, 0.f) + r1[a][b][r]) * gt_drop_mul(g.drop, dkey, didx);
+          } else if (EPI == EPI_RELU_DROP) {
+            v = fmaxf(v + bia[b][r], 0.f) * gt_drop_mul(g.drop, dkey, didx);
+          } else if (EPI == EPI_HEADS) {
+            v += bia[b][r];
+            if (col >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
+            else if (col >= GT_VOICES) v = gt_sigmoid(v);
+          } else if (EPI == EPI_MASK_NZ) {
+            v = (r1[a][b][r] != 0.f) ? v * g.mask_scale : 0.f;
+          } else if (EPI == EPI_ADD_RELUMASK_DROP) {
+            v = (v + r1[a][b][r]) * gt_drop_mul(g.drop, dkey, didx);
+            v = (r2[a][b][r] > 0.f) ? v : 0.f;
+          }
+          o[r] = v;
+        }
+        if (vec) {
+          if (row0 < g.M && col0 < g.N) {
+            *reinterpret_cast<float4*>(&g.C[(size_t)row0 * g.ldc + col0]) = make_float4(o[0], o[1], o[2], o[3]);
+            if (EPI == EPI_RELU_PE) *reinterpret_cast<float4*>(&g.aux[(size_t)row0 * g.N + col0]) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row0 + (TR ? 0 : r), col = col0 + (TR ? r : 0);
+            if (row < g.M && col < g.N) {
+              const size_t ci = (size_t)row * g.ldc + col;
+              if (EPI == EPI_ATOMIC) atomicAdd(&g.C[ci], o[r]);
+              else g.C[ci] = o[r];
+              if (EPI == EPI_RELU_PE) g.aux[(size_t)row * g.N + col] = o2[r];
             }
           }
         }
+      }
     return;
   }
 
@@ -348,10 +426,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sC[((wm * TM + a) * 16 + 4 * lg + r) * CSTR + (wn * TN + b) * 16 + l16] = acc[a][b][r];
+    for (int b = 0; b < TN; ++b)   // transposed accumulator layout (above): 4 consecutive columns of one row per lane
+      *reinterpret_cast<float4*>(&sC[((wm * TM + a) * 16 + l16) * CSTR + (wn * TN + b) * 16 + 4 * lg]) =
+          make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
   __syncthreads();
 
   constexpr int CPL = BN / 16;            // columns per lane of a 16-lane row group
