@@ -46,7 +46,7 @@ def test_train_step(cfg, p):
     parity.check_train_step("emu", cfg, 2, p)
 
 
-@pytest.mark.parametrize("cfg,use_thres", [(ENC, True), (ENC, False), (ENCDEC, True)])
+@pytest.mark.parametrize("cfg,use_thres", [(ENC, True), (ENC, False), (ENCDEC, True), (ENCDEC, False), (cfg_dict(64, 2, 24, 1, 2), True)])
 def test_predict(cfg, use_thres):
     parity.check_predict("emu", cfg, 2, use_thres)
 

@@ -76,7 +76,8 @@ def test_train_step(cfg, B, p):
     parity.check_train_step("hip", cfg, B, p)
 
 
-@pytest.mark.parametrize("cfg,B,use_thres", [(ENC, 8, True), (ENC, 3, False), (ENCDEC, 4, True), (C2, 32, True)])
+@pytest.mark.parametrize("cfg,B,use_thres", [(ENC, 8, True), (ENC, 3, False), (ENCDEC, 4, True), (C2, 32, True), (ENCDEC, 5, False), (C3, 6, True),
+                                             (cfg_dict(128, 4, 64, 2, 2), 33, True)])
 def test_predict(cfg, B, use_thres):
     parity.check_predict("hip", cfg, B, use_thres)
 

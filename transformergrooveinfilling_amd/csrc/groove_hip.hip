@@ -467,7 +467,7 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
     gemm_launch<false, false, EPI_STORE>(g, x.s);
     gt_prof_tag("ln_fwd", 0, 16.0 * x.M * x.d);
     gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
-              x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, x.M, x.d);
+              x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d);
     return 0;
   }
   g.res = res; g.ldres = x.d;
@@ -626,7 +626,7 @@ static int encoder_fwd(const Ctx& x, const float* pe, const float* src) {
   }
   gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
   gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, (const float*)nullptr, no_drop(), x.prm + x.P.encn_w,
-            x.prm + x.P.encn_b, ws + x.W.memory, ws + x.W.enc_xhat, ws + x.W.enc_rstd, x.M, x.d);
+            x.prm + x.P.encn_b, ws + x.W.memory, ws + x.W.enc_xhat, ws + x.W.enc_rstd, x.M, x.d, x.d, x.d, x.d);
   return 0;
 }
 static int decoder_fwd(const Ctx& x, const float* pe, const float* tgt_in) {
@@ -650,8 +650,65 @@ static int decoder_fwd(const Ctx& x, const float* pe, const float* tgt_in) {
   }
   gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
   gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, (const float*)nullptr, no_drop(), x.prm + x.P.decn_w,
-            x.prm + x.P.decn_b, ws + x.W.dec_final, ws + x.W.dec_xhat, ws + x.W.dec_rstd, x.M, x.d);
+            x.prm + x.P.decn_b, ws + x.W.dec_final, ws + x.W.dec_xhat, ws + x.W.dec_rstd, x.M, x.d, x.d, x.d, x.d);
   return 0;
+}
+// ---- greedy decoding, one time step: every row-wise op of the decoder runs on row t of each sequence only (a GEMM with
+// M = B and leading dimensions x 32 over the SAME workspace buffers decoder_fwd uses).  The K/V rows self-attention wrote
+// at steps < t are the KV cache; cross-attention K/V (ws.kvx) is computed once per layer before the loop.
+static void step_linear(const Ctx& x, int B, const float* in, int ldin, const float* W, const float* b, float* out, int ldout, int N, int K) {
+  GemmArgs g = mk_gemm(in, 32 * ldin, W, K, out, 32 * ldout, B, N, K);
+  g.bias = b;
+  gemm_launch<false, false, EPI_STORE>(g, x.s);
+}
+// out_t = LN(in_t W^T + b + res_t)   (eval: no dropout)
+static void step_linear_res_ln(const Ctx& x, int B, const float* in, int ldin, int K, int64_t w_off, int64_t b_off, const float* res,
+                               int64_t gamma_off, float* out, float* xhat, float* rstd) {
+  step_linear(x, B, in, ldin, x.prm + w_off, x.prm + b_off, out, x.d, x.d, K);
+  gt_launch(ln_fwd_kernel, dim3((B + 3) / 4), dim3(256), x.s, (const float*)out, res, no_drop(), x.prm + gamma_off,
+            x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, B, x.d, 32 * x.d, 32 * x.d, 32 * x.d);
+}
+static void step_attention(const Ctx& x, int B, const float* q, int ldq, const float* k, const float* v, int ldkv, float* ctx, int nkeys) {
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ctx = ctx; a.ldc = x.d;
+  a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.drop = no_drop();
+  gt_launch(attn_decode_kernel, dim3(B * x.H), dim3(64), x.s, a, nkeys);
+}
+static void decoder_step(const Ctx& x, const float* pe, const float* tgt, int t, float* hvo_tmp) {
+  float* ws = x.ws;
+  const int d = x.d, F = x.F, L = x.c.n_enc_layers, B = x.c.batch;
+  const size_t r = (size_t)t;                       // row offset multiplier: buffer + r * ld
+  {   // InputLayerDecoder on tgt row t with pe[t]
+    GemmArgs g = mk_gemm(tgt + r * GT_TGT, 32 * GT_TGT, x.prm + x.P.din_w, GT_TGT, ws + x.W.y0 + r * d, 32 * d, B, d, GT_TGT);
+    g.bias = x.prm + x.P.din_b; g.aux = ws + x.W.b0; g.pe = pe + r * d; g.pe_fixed = 1; g.drop = no_drop();
+    gemm_launch<false, false, EPI_RELU_PE>(g, x.s);
+  }
+  const float* cur = ws + x.W.y0;
+  for (int l = 0; l < x.c.n_dec_layers; ++l) {
+    const LayerP& p = x.P.dec[l];
+    const LayerW& w = x.W.layers[L + l];
+    // masked self-attention: q, k, v of row t; keys 0..t are in ws.qkv from the earlier steps
+    step_linear(x, B, cur + r * d, d, x.prm + p.sa.in_w, x.prm + p.sa.in_b, ws + w.qkv + r * 3 * d, 3 * d, 3 * d, d);
+    step_attention(x, B, ws + w.qkv + r * 3 * d, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.ctx + r * d, t + 1);
+    step_linear_res_ln(x, B, ws + w.ctx + r * d, d, d, p.sa.out_w, p.sa.out_b, cur + r * d, p.n1w, ws + w.x1 + r * d, ws + w.xhat1, ws + w.rstd1);
+    // cross attention over the 32 memory positions
+    step_linear(x, B, ws + w.x1 + r * d, d, x.prm + p.xa.in_w, x.prm + p.xa.in_b, ws + w.qx + r * d, d, d, d);
+    step_attention(x, B, ws + w.qx + r * d, d, ws + w.kvx, ws + w.kvx + d, 2 * d, ws + w.ctxx + r * d, 32);
+    step_linear_res_ln(x, B, ws + w.ctxx + r * d, d, d, p.xa.out_w, p.xa.out_b, ws + w.x1 + r * d, p.n2w, ws + w.x2 + r * d, ws + w.xhatx, ws + w.rstdx);
+    {   // FFN
+      GemmArgs g = mk_gemm(ws + w.x2 + r * d, 32 * d, x.prm + p.w1, d, ws + w.hact + r * F, 32 * F, B, F, d);
+      g.bias = x.prm + p.b1; g.drop = no_drop();
+      gemm_launch<false, false, EPI_RELU_DROP>(g, x.s);
+    }
+    step_linear_res_ln(x, B, ws + w.hact + r * F, F, F, p.w2, p.b2, ws + w.x2 + r * d, p.n3w, ws + w.xout + r * d, ws + w.xhat2, ws + w.rstd2);
+    cur = ws + w.xout;
+  }
+  gt_launch(ln_fwd_kernel, dim3((B + 3) / 4), dim3(256), x.s, cur + r * d, (const float*)nullptr, no_drop(), x.prm + x.P.decn_w,
+            x.prm + x.P.decn_b, ws + x.W.dec_final + r * d, ws + x.W.dec_xhat, ws + x.W.dec_rstd, B, d, 32 * d, 32 * d, 32 * d);
+  GemmArgs g = mk_gemm(ws + x.W.dec_final + r * d, 32 * d, x.prm + x.P.out_w, d, hvo_tmp + r * GT_TGT, 32 * GT_TGT, B, GT_TGT, d);
+  g.bias = x.prm + x.P.out_b;
+  gemm_launch<false, false, EPI_HEADS>(g, x.s);
 }
 static void output_layer_fwd(const Ctx& x, float* hvo_out) {
   const float* fin = x.ws + (x.c.n_dec_layers > 0 ? x.W.dec_final : x.W.memory);
@@ -1025,13 +1082,28 @@ extern "C" int gt_predict(const gt_config* cfg, const float* params, const float
     return launch_status("gt_predict");
   }
   if (!tgt_scratch) return gt_fail("gt_predict: encoder-decoder model needs tgt_scratch");
-  // greedy decode: tgt row 0 = zeros, row t+1 = thresholded step t.  The encoder memory is computed once
-  // (it does not depend on tgt); each step re-runs the decoder stack on the current tgt.
+  // greedy decode: tgt row 0 = zeros, row t+1 = thresholded step t.  The encoder memory and every layer's cross-attention
+  // K/V are computed once; step t then touches only row t of each sequence (decoder_step; the self-attention K/V rows of
+  // the earlier steps are the cache).  GT_PREDICT_FULL=1 keeps the plain form -- the whole decoder stack over all 32
+  // positions at every step, 20-30x the work -- for A/B runs and tests.
   float* tmp = ws + x.W.hvo_tmp;
-  hipMemsetAsync(tgt_scratch, 0, (size_t)M * GT_TGT * sizeof(float), x.s);
+  (void)hipMemsetAsync(tgt_scratch, 0, (size_t)M * GT_TGT * sizeof(float), x.s);
+  static const int full = [] { const char* e = getenv("GT_PREDICT_FULL"); return (e && e[0] == '1') ? 1 : 0; }();
+  if (!full) {
+    const int d = x.d, L = cfg->n_enc_layers;
+    for (int l = 0; l < cfg->n_dec_layers; ++l) {
+      const LayerP& p = x.P.dec[l];
+      const LayerW& w = x.W.layers[L + l];
+      linear_fwd(x, ws + x.W.memory, d, x.prm + p.xa.in_w + (int64_t)d * d, x.prm + p.xa.in_b + d, ws + w.kvx, 2 * d, 2 * d, d);
+    }
+  }
   for (int t = 0; t < 32; ++t) {
-    if (decoder_fwd(x, pe, tgt_scratch)) return -1;
-    output_layer_fwd(x, tmp);
+    if (full) {
+      if (decoder_fwd(x, pe, tgt_scratch)) return -1;
+      output_layer_fwd(x, tmp);
+    } else {
+      decoder_step(x, pe, tgt_scratch, t, tmp);
+    }
     gt_launch(predict_head_kernel, dim3((B * GT_TGT + 255) / 256), dim3(256), x.s, (const float*)tmp, hvo_out, tgt_scratch, thres,
               use_thres, t, B);
   }

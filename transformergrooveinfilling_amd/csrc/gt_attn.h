@@ -417,3 +417,59 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
       }
   }
 }
+
+
+// ================================================================================================================
+// Greedy decoding (gt_predict, encoder-decoder): ONE query row per (sequence, head) against the first `nkeys` key/value
+// rows of the sequence -- the rows the earlier decode steps wrote are the KV cache (self-attention: nkeys = t + 1, which
+// IS the causal mask), or the cross-attention keys/values of the encoder memory (nkeys = 32).  No dropout (eval), P is
+// not saved.  One wave per (sequence, head): lane j scores key j, wave reductions for the softmax, then lanes own output
+// columns.  q / ctx point at the query's time step; row stride between sequences is 32 * ld.
+// ================================================================================================================
+__global__ __launch_bounds__(64) void attn_decode_kernel(AttnArgs a, int nkeys) {
+  // K is walked in 64-column slabs: 32 coalesced row loads (one 256-byte row segment per instruction, all in flight
+  // together) staged in LDS, from which lane j takes the dot product of key j.  (A first version let every lane walk its
+  // own key row straight from global memory: 32 cache lines per load instruction, 265 us per call at 8192 heads.)
+  __shared__ float sk[32][65], sq[64], sp[32];
+  const int lane = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H, hd = a.hd;
+  const float* const zp = gt_zero_ptr();
+  const float* q = a.q + (size_t)b * 32 * a.ldq + h * hd;
+  const float* kb = a.k + (size_t)b * 32 * a.ldk + h * hd;
+  const float* vb = a.v + (size_t)b * 32 * a.ldv + h * hd;
+  float s = 0.f;
+  for (int c0 = 0; c0 < hd; c0 += 64) {
+    const bool okc = c0 + lane < hd;
+    float kr[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) kr[j] = *((okc && j < nkeys) ? kb + (size_t)j * a.ldk + c0 + lane : zp);
+    sq[lane] = *(okc ? q + c0 + lane : zp);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) sk[j][lane] = kr[j];
+    __syncthreads();
+    if (lane < 32) {
+#pragma unroll 16
+      for (int c = 0; c < 64; ++c) s += sq[c] * sk[lane][c];
+    }
+    __syncthreads();
+  }
+  s = (lane < nkeys) ? s * a.scale : -INFINITY;
+  float mx = s;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+  float e = (lane < nkeys) ? expf(s - mx) : 0.f, sum = e;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+  if (lane < 32) sp[lane] = e / sum;
+  __syncthreads();
+  float* o = a.ctx + (size_t)b * 32 * a.ldc + h * hd;
+  for (int c0 = 0; c0 < hd; c0 += 64) {
+    const bool okc = c0 + lane < hd;
+    float vr[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) vr[j] = *((okc && j < nkeys) ? vb + (size_t)j * a.ldv + c0 + lane : zp);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc += sp[j] * vr[j];          // sp[j] = 0 beyond nkeys
+    if (okc) o[c0 + lane] = acc;
+  }
+}

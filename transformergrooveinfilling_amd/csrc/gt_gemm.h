@@ -55,6 +55,7 @@ struct GemmArgs {
   float* dgamma; float* dbeta;
   float* ln_part;            // if set: per-row-tile partials [row_tile][2][N] instead of contended atomics
   const float* pe;           // [32, N]
+  int pe_fixed;              // EPI_RELU_PE: 0 = row m uses pe[m & 31]; 1 = every row uses pe[0] (caller points pe at one time step)
   float* dbias;              // EPI_ATOMIC: column sums of A over k (grad of the bias), or nullptr
   float mask_scale;
   DropArgs drop;
@@ -332,7 +333,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
           for (int b = 0; b < TN; ++b) {
             const int row = row_of(a), col = col_of(b);
             const bool ok = row < g.M && col < g.N;
-            const int rrow = EPI == EPI_RELU_PE ? (row & 31) : row;
+            const int rrow = EPI == EPI_RELU_PE ? (g.pe_fixed ? 0 : (row & 31)) : row;
             const float4 t = *reinterpret_cast<const float4*>(ok ? r1src + ((size_t)rrow * r1ld + col) : zp);
             r1[a][b][0] = t.x; r1[a][b][1] = t.y; r1[a][b][2] = t.z; r1[a][b][3] = t.w;
             if (NEED_R2) {
@@ -358,7 +359,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
             for (int r = 0; r < 4; ++r) {
               const int row = row_of(a) + (TR ? 0 : r), col = col_of(b) + (TR ? r : 0);
               const bool ok = row < g.M && col < g.N;
-              const int rrow = EPI == EPI_RELU_PE ? (row & 31) : row;
+              const int rrow = EPI == EPI_RELU_PE ? (g.pe_fixed ? 0 : (row & 31)) : row;
               r1[a][b][r] = ldg(r1src, (size_t)rrow * r1ld + col, ok);
               if (NEED_R2) r2[a][b][r] = ldg(g.aux_in, (size_t)row * g.N + col, ok);
             }

@@ -7,12 +7,15 @@
 
 // ---- LayerNorm forward: one wave per row, the row lives in registers --------------------------------
 //   z = x * dropmask(+ res);  y = LN(z) * gamma + beta;  xhat, rstd saved for backward.   y may alias x (in place).
+//   x / res / y have their own leading dimensions (the greedy decoder works on one time step of every sequence: ld = 32 N);
+//   xhat / rstd are dense (M, N) / (M).  The dropout index is row * N + c (dense rows: training never uses a strided view).
 // Used for the final encoder / decoder norms and -- with res / dropout -- as the second half of the UN-fused
 // `LN(drop(linear) + res)` (wide d_model at few tokens, where a row-owning GEMM tile would make every workgroup stream
 // the whole weight matrix; see linear_res_ln in groove_hip.hip).
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float* __restrict__ res, DropArgs drop,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* y,
-                                                     float* __restrict__ xhat, float* __restrict__ rstd_out, int M, int N) {
+                                                     float* __restrict__ xhat, float* __restrict__ rstd_out, int M, int N,
+                                                     int ldx, int ldres, int ldy) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* const zp = gt_zero_ptr();
@@ -23,8 +26,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
   for (int i = 0; i < GT_MAX_D / 64; ++i) {            // all loads first, branch-free (address select)
     const int c = lane + 64 * i;
     const bool ok = c < N;
-    z[i] = *(ok ? x + (size_t)row * N + c : zp);
-    r[i] = *((ok && res != nullptr) ? res + (size_t)row * N + c : zp);
+    z[i] = *(ok ? x + (size_t)row * ldx + c : zp);
+    r[i] = *((ok && res != nullptr) ? res + (size_t)row * ldres + c : zp);
     ga[i] = *(ok ? gamma + c : zp);
     be[i] = *(ok ? beta + c : zp);
   }
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
     if (c < N) {
       const float xh = (z[i] - mean) * rstd;
       xhat[(size_t)row * N + c] = xh;
-      y[(size_t)row * N + c] = xh * ga[i] + be[i];
+      y[(size_t)row * ldy + c] = xh * ga[i] + be[i];
     }
   }
   if (lane == 0) rstd_out[row] = rstd;
