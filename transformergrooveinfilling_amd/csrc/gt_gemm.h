@@ -27,6 +27,9 @@
 #include "gt_common.h"
 #include <type_traits>
 
+#ifndef GT_MIDSLAB_STORE
+#define GT_MIDSLAB_STORE 1
+#endif
 enum {
   EPI_STORE = 0,          // C = acc + bias (+ C if accumulate)
   EPI_ATOMIC = 1,         // atomicAdd(C, acc)            (split-K wgrad; + bias-grad column sums of A)
@@ -219,6 +222,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
       //  accumulators VGPR<->AGPR around every few MFMAs, exposing the LDS latency each time)
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
+        if (GT_MIDSLAB_STORE && BK / 16 >= 2 && TM * TN >= 16 && kk == BK / 32 && kt + 1 < nk) {
+          // mid-slab hand-over: the next slab goes into the other LDS buffer while half of this slab's MFMAs are still to
+          // come (that buffer was last read before the previous barrier), so the barrier below waits on nothing
+          la.store(smem + (cur ^ 1) * SA_SZ, SA_STR, tid);
+          lb.store(smem + 2 * SA_SZ + (cur ^ 1) * SB_SZ, SB_STR, tid);
+        }
         float af[TM][4], bf[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -257,7 +266,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
           for (int kk = 0; kk < BK; ++kk) bsum += sA[kk * SA_STR + tid];
         }
       }
-      if (kt + 1 < nk) {
+      if (kt + 1 < nk && !(GT_MIDSLAB_STORE && BK / 16 >= 2 && TM * TN >= 16)) {
         la.store(smem + (cur ^ 1) * SA_SZ, SA_STR, tid);
         lb.store(smem + 2 * SA_SZ + (cur ^ 1) * SB_SZ, SB_STR, tid);
       }
