@@ -52,11 +52,6 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
 void block_sync();
 float wave_shfl(float v, int src_lane);
 f32x4 mfma16(float a, float b, f32x4 c);
-// global_load_lds_dwordx4: lane i of the wave writes its 16 bytes at (wave-uniform LDS base) + i*16
-static inline void glds16(const void* g, void* lds_base) {
-  int lane = (threadIdx_.x + threadIdx_.y * blockDim_.x) & 63;
-  memcpy((char*)lds_base + lane * 16, g, 16);
-}
 }  // namespace emu
 
 #define threadIdx emu::threadIdx_

@@ -17,45 +17,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include "../../include/groove_hip.h"
 
-// ---- LDS-DMA (global_load_lds_dwordx4) and the counted-wait / raw-barrier pair that goes with it -----------------
-// GT_GLDS16(g, l): every lane moves 16 bytes from ITS global address g to LDS at (wave-uniform l) + lane*16, with no
-// VGPR in between; it is a pending vector-memory op (vmcnt).  GT_WAIT_VM(n): wait until at most n of this wave's
-// vector-memory ops are outstanding.  GT_BARRIER(): LDS-visible workgroup barrier that does NOT drain LDS-DMA
-// (__syncthreads() would insert vmcnt(0): cdna_hip_programming.md 5, "Pipelining across barriers").
-// GT_LDS_READ128 / GT_LDS_READ32: ds_read issued from inline asm, so hipcc's waitcnt pass does not see an LDS read that
-// "may alias" an in-flight LDS-DMA write and drain the DMA queue with vmcnt(0) in front of it (measured: it does, for a
-// ring that lives in the same __shared__ array).  The reader counts lgkmcnt itself: GT_LDS_FENCE() waits for every
-// asm read, GT_LDS_TIE(x) makes later uses of x depend on that wait.
-// GT_GLOAD32: an ordinary global load issued from inline asm for the same reason -- hipcc cannot count LDS-DMA ops
-// issued in a loop, so it would wait vmcnt(0) (draining the ring) before the first use of a compiler-visible load.
-// The issuer waits itself (SlabPipe::wait_older_than) and ties the registers with GT_LDS_TIE.
+// GT_BARRIER(): workgroup barrier of the wave-specialised chain kernels (gt_chain.h): waits for this wave's LDS traffic
+// only -- __syncthreads() would also drain its vector-memory queue (vmcnt(0)), which the loader waves must keep in flight
+// across barriers (cdna_hip_programming.md 5, "Pipelining across barriers").
+// (The LDS-DMA staging path this file once carried -- global_load_lds + inline-asm LDS reads -- measured ~27 GB/s per CU
+// against 46-70 GB/s through registers and was removed; DESIGN.md 3, rejected experiments.)
 #ifdef GT_EMU
-#define GT_GLOAD32(dst, ptr) ((dst) = *(ptr))
-#else
-#define GT_GLOAD32(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr))
-#endif
-
-#ifdef GT_EMU
-#define GT_LDS_READ128(dst, ptr) ((dst) = *reinterpret_cast<const f32x4*>(ptr))
-#define GT_LDS_READ32(dst, ptr) ((dst) = *(ptr))
-#define GT_LDS_FENCE() ((void)0)
-#define GT_LDS_TIE(x) ((void)0)
-#else
-#define GT_LDS_READ128(dst, ptr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((uint32_t)(uintptr_t)(ptr)))
-#define GT_LDS_READ32(dst, ptr) asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"((uint32_t)(uintptr_t)(ptr)))
-#define GT_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define GT_LDS_TIE(x) asm volatile("" : "+v"(x))
-#endif
-
-#ifdef GT_EMU
-#define GT_GLDS16(g, l) emu::glds16((g), (l))
-#define GT_WAIT_VM(n) ((void)0)
 #define GT_BARRIER() __syncthreads()
 #else
-#define GT_GLDS16(g, l)                                                                                       \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),                       \
-                                   (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
-#define GT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define GT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 

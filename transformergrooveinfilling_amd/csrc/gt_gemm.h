@@ -586,7 +586,6 @@ struct GemmGroup {
   int n;
   int start[GT_GROUP_MAX + 1];
   int gx[GT_GROUP_MAX], gy[GT_GROUP_MAX];
-  int big[GT_GROUP_MAX];       // 1: 64x64 tiles (both output dims >= 64: half the staged bytes and atomics per flop), 0: 32x32
   GemmArgs p[GT_GROUP_MAX];
 };
 // weight-gradient group ("TN", fp32 atomics).  TM = 1: 32x32 tiles -- small problems, where the number of workgroups
@@ -691,7 +690,6 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   GemmGroup& G = wb.grp[cls];
   const int i = G.n++;
   G.p[i] = g;
-  G.big[i] = cls;
   G.gx[i] = (g.N + tile - 1) / tile;
   G.gy[i] = (g.M + tile - 1) / tile;
   G.start[i + 1] = G.start[i] + G.gx[i] * G.gy[i] * splitk;
