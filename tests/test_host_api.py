@@ -100,3 +100,30 @@ def test_model_needs_gpu_and_has_no_cpu_fallback():
     from transformergrooveinfilling_amd.model import GrooveTransformerEncoder
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         GrooveTransformerEncoder(d_model=32, nhead=4, num_encoder_layers=1, dim_feedforward=16)
+
+
+def test_device_batch_loader_matches_sharded_sampler():
+    """DeviceBatchLoader (dataset resident on the device, gathers instead of a DataLoader) visits exactly the batches the
+    ShardedBatchSampler prescribes: same seeded permutation on every rank, rank-strided, every index at most once."""
+    import torch
+    from transformergrooveinfilling_amd.parallel import DeviceBatchLoader, ShardedBatchSampler
+    n, bs = 103, 8
+    x = torch.arange(n, dtype=torch.float32).reshape(n, 1, 1).repeat(1, 32, 16)
+    y = -torch.arange(n, dtype=torch.float32).reshape(n, 1, 1).repeat(1, 32, 27)
+    for world in (1, 2, 4):
+        seen = []
+        for rank in range(world):
+            dl = DeviceBatchLoader(x, y, bs, "cpu", rank, world, seed=7)
+            sm = ShardedBatchSampler(n, bs, rank, world, seed=7, drop_last=(world > 1))
+            for ep in (0, 3):
+                dl.set_epoch(ep); sm.set_epoch(ep)
+                got = [(xb, yb, idx) for xb, yb, idx in dl]
+                want = list(sm)
+                assert len(got) == len(want) == len(dl)
+                for (xb, yb, idx), w in zip(got, want):
+                    assert idx.tolist() == w
+                    assert torch.equal(xb[:, 0, 0], idx.float()) and torch.equal(yb[:, 0, 0], -idx.float())
+                if ep == 0:
+                    seen += [i for _, _, idx in got for i in idx.tolist()]
+        assert len(seen) == len(set(seen))
+        assert len(seen) == (n if world == 1 else (n // world // bs) * bs * world)

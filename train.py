@@ -52,6 +52,9 @@ def build_parser():
     # build-side additions
     p.add_argument("--data-npz", default=None, help="npz with inputs (N,32,S) and outputs (N,32,27)")
     p.add_argument("--synthetic", default=0, type=int, help="train on N synthetic sequences")
+    p.add_argument("--host-loader", action="store_true",
+                   help="feed batches through torch's DataLoader from host memory (the reference's way) instead of keeping the "
+                        "dataset in HBM and gathering batches on the device")
     p.add_argument("--save-dir", default=None, help="where checkpoints go (default: wandb run dir or ./checkpoints)")
     p.add_argument("--override", action="append", default=[], metavar="KEY=VALUE", help="override a YAML key (bench shapes)")
     p.add_argument("--seed", default=0, type=int)
@@ -152,7 +155,10 @@ def main(argv=None):
             return self.tensors[0][i], self.tensors[1][i], i
 
     ds = _Triples(x, y)
-    if world > 1:
+    if not args.host_loader:
+        # the whole dataset in HBM, batches gathered on the device
+        sampler = loader = parallel.DeviceBatchLoader(x, y, hp["batch_size"], device, rank, world, seed=args.seed)
+    elif world > 1:
         sampler = parallel.ShardedBatchSampler(len(ds), hp["batch_size"], rank, world, seed=args.seed)
         loader = DataLoader(ds, batch_sampler=sampler, pin_memory=True)
     else:
@@ -172,7 +178,7 @@ def main(argv=None):
                        run_id=(wb.run.id if wb else "local"))
         torch.cuda.synchronize()
         if rank == 0:
-            n = len(loader) * hp["batch_size"] * world
+            n = min(len(loader) * hp["batch_size"], len(ds) // world) * world
             print("Epoch %d: loss %.5f  hit_acc %.4f  (%.0f sequences/s)" % (ep, m["train/loss"], m["train/hit_accuracy"],
                                                                            n / (time.perf_counter() - t0)))
             if wb:

@@ -81,3 +81,38 @@ class ShardedBatchSampler:
             b = mine[i * self.bs:(i + 1) * self.bs]
             if len(b):
                 yield b.tolist()
+
+
+class DeviceBatchLoader:
+    """The input pipeline on the device.  The reference's datasets are two dense fp32 tensors of tens of MB
+    (ref:dataset.py:263-264,355-356) fed through DataLoader(shuffle=True, pin_memory=True) (ref:train.py:156-158); at
+    0.3 ms per train step the collate + H2D copy of a host DataLoader would be several times the step.  Here both tensors
+    live in HBM; every epoch draws the SAME seeded permutation on every rank (the one ShardedBatchSampler draws), a rank
+    keeps indices rank, rank+world, ..., and a batch is two index_select gathers on the device.  Yields (x, y, idx) like
+    the reference's dataset.  Under DP ragged tails are dropped (matched collectives); single-process keeps the last
+    partial batch, as DataLoader's default does."""
+
+    def __init__(self, x, y, batch_size, device, rank=0, world=1, seed=0):
+        self.x = torch.as_tensor(x, dtype=torch.float32).to(device).contiguous()
+        self.y = torch.as_tensor(y, dtype=torch.float32).to(device).contiguous()
+        assert self.x.shape[0] == self.y.shape[0]
+        self.n, self.bs, self.rank, self.world, self.seed = int(self.x.shape[0]), int(batch_size), rank, world, seed
+        self.device, self.epoch = device, 0
+        self.batch_size = self.bs
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        per_rank = self.n // self.world
+        return per_rank // self.bs if self.world > 1 else (per_rank + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.seed * 1000003 + self.epoch)
+        perm = torch.randperm(self.n, generator=g)                      # host generator: identical on every rank and platform
+        per_rank = self.n // self.world
+        mine = perm[self.rank: per_rank * self.world: self.world].to(self.device)   # ONE small H2D copy per epoch
+        for i in range(len(self)):
+            idx = mine[i * self.bs:(i + 1) * self.bs]
+            yield self.x.index_select(0, idx), self.y.index_select(0, idx), idx
