@@ -154,9 +154,10 @@ int gt_profile_enable(int on);
  * the backward chain; recorded as fork/join edges when the call is being captured into a hipGraph.  off (default;
  * env GT_OVERLAP=1 switches the default): a single stream -- measured faster on ROCm 7.2, see DESIGN.md. */
 int gt_set_overlap(int on);
-/* on: encoder-only models with d_model <= 256 and dim_feedforward <= 512 run on the fused row-chain kernels (one launch
- * per layer and direction besides attention; wave-specialised loader / MFMA waves).  off (default; env GT_CHAIN=1
- * switches the default): one kernel per op -- currently the faster path at the headline size, see DESIGN.md. */
+/* Fused row-chain kernels (one launch per layer and direction besides attention; wave-specialised loader / MFMA waves) for
+ * encoder-only models with d_model <= 256 and dim_feedforward <= 512.  Default (neither this call nor env GT_CHAIN): used
+ * automatically only where they win -- d_model <= 64 and dim_feedforward <= 64.  on = 1 forces them wherever supported,
+ * on = 0 switches them off (env GT_CHAIN=1 / GT_CHAIN=0 do the same).  Results are the same on both paths. */
 int gt_set_chain(int on);
 int gt_profile_report(char* buf, size_t buf_len, int max_rows);
 

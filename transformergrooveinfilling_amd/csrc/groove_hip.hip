@@ -275,15 +275,16 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
 }
 
 // Row-chain kernels (gt_chain.h) can serve encoder-only models with d_model <= 256 and dim_feedforward <= 512 (every
-// shipped YAML and BASELINE configs[0..1]).  They are OPT-IN (GT_CHAIN=1 / gt_set_chain(1)): parity-green, but at the
-// headline size (128 row tiles on 256 CUs, 768 KB of weights streamed per workgroup) still slower than one kernel per op
-// -- 476 vs ~430 us per step, r01s in profiles/ -- because a CU's global->LDS rate (~140 cycles per 1 KB load
-// instruction) bounds a 16-row tile well below its MFMA rate.
-static int g_chain = -1;
+// shipped YAML and BASELINE configs[0..1]).  Parity-green, but they only pay where the weights a 16-row tile has to stream
+// are tiny: by default they serve d_model <= 64 with dim_feedforward <= 64 (the testing YAML: 0.366 -> 0.329 ms per step),
+// nothing else -- at the headline size (128 row tiles on 256 CUs, 768 KB of weights per workgroup) they are slower than
+// one kernel per op (0.404 vs 0.307 ms), because a CU's global->LDS rate bounds a 16-row tile well below its MFMA rate.
+// GT_CHAIN=1 / gt_set_chain(1) forces them wherever they are supported, GT_CHAIN=0 / gt_set_chain(0) switches them off.
+static int g_chain = -1;                            // -1: read GT_CHAIN; 0 off; 1 forced on; 2 automatic (by shape)
 extern "C" int gt_set_chain(int on) { g_chain = on != 0; return 0; }
-static int chain_enabled() {
-  if (g_chain < 0) { const char* e = getenv("GT_CHAIN"); g_chain = (e && e[0] == '1') ? 1 : 0; }
-  return g_chain;
+static bool chain_enabled(int d, int F) {
+  if (g_chain < 0) { const char* e = getenv("GT_CHAIN"); g_chain = (e && e[0] == '1') ? 1 : (e && e[0] == '0') ? 0 : 2; }
+  return g_chain == 1 || (g_chain == 2 && d <= 64 && F <= 64);
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
@@ -566,8 +567,10 @@ static int self_attn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const f
                        lsite(gl, GT_SITE_DROP1));
 }
 
-static bool use_chain(const Ctx& x) { return x.c.n_dec_layers == 0 && chain_supported(x.d, x.F) && chain_enabled(); }
-static bool chain_path_for(const gt_config& c) { return c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff) && chain_enabled(); }
+static bool use_chain(const Ctx& x) { return x.c.n_dec_layers == 0 && chain_supported(x.d, x.F) && chain_enabled(x.d, x.F); }
+static bool chain_path_for(const gt_config& c) {
+  return c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff) && chain_enabled(c.d_model, c.dim_ff);
+}
 
 template <typename Args>
 static void chain_launch(void (*k64)(Args), void (*k128)(Args), void (*k256)(Args), const Ctx& x, const Args& a) {
