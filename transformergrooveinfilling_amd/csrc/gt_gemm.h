@@ -593,6 +593,12 @@ struct GemmGroup {
 // TM = 2: 64x64 tiles -- large problems (d_model 512, thousands of tokens), where 32x32 tiles are bound by staged bytes
 // and atomics per flop (38 % of the C4 step before the split).  The two sizes go out as SEPARATE launches: sharing one,
 // the 70 KB of LDS of the large tiles halved the occupancy of the small ones.
+#ifndef GT_WGRAD_T32_BK
+#define GT_WGRAD_T32_BK 32      /* 18 KB of LDS -> 8 resident workgroups per CU: these short, staging-bound chains want occupancy (64: +3 % step time at C2, 16 and 128 worse) */
+#endif
+#ifndef GT_WGRAD_T128_BK
+#define GT_WGRAD_T128_BK 16      /* 34 KB of LDS: more resident workgroups (32: C3 +2.5 %, C4 bs512 +3.4 % step time) */
+#endif
 #ifndef GT_WGRAD_T64_BK
 #define GT_WGRAD_T64_BK 64
 #endif
@@ -601,7 +607,7 @@ struct GemmGroup {
 #endif
 template <int TM>
 __global__ __launch_bounds__(256, TM == 4 ? GT_T128_WAVES : 1) void wgrad_group_kernel(GemmGroup grp) {
-  constexpr int BK = TM == 4 ? 32 : TM == 2 ? GT_WGRAD_T64_BK : 64;   // 128x128 tiles: 32-token slabs (68 KB of LDS, two workgroups per CU)
+  constexpr int BK = TM == 4 ? GT_WGRAD_T128_BK : TM == 2 ? GT_WGRAD_T64_BK : GT_WGRAD_T32_BK;   // 128x128 tiles: 32-token slabs (68 KB of LDS, two workgroups per CU)
   typedef GemmCfg<2, 2, TM, TM, BK, true, true, EPI_ATOMIC> C;
   __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
   // XCD-aware placement: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one), each with its own
@@ -700,6 +706,9 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
 #ifndef GT_T64_MIN
 #define GT_T64_MIN 512
 #endif
+#ifndef GT_T32_BK
+#define GT_T32_BK 64
+#endif
 #ifndef GT_T64_BK
 #define GT_T64_BK 32
 #endif
@@ -722,7 +731,7 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   // 128x128x32 slabs need half of that per flop
   if (t128 >= GT_T128_MIN) { g.k_chunk = (g.K + 31) / 32 * 32; gemm_launch_cfg<2, 2, 4, 4, 32, AKM, BKM, EPI>(g, 1, s); }
   else if (t64 >= GT_T64_MIN) { g.k_chunk = (g.K + GT_T64_BK - 1) / GT_T64_BK * GT_T64_BK; gemm_launch_cfg<2, 2, 2, 2, GT_T64_BK, AKM, BKM, EPI>(g, 1, s); }
-  else            gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, 1, s);
+  else { g.k_chunk = (g.K + GT_T32_BK - 1) / GT_T32_BK * GT_T32_BK; gemm_launch_cfg<2, 2, 1, 1, GT_T32_BK, AKM, BKM, EPI>(g, 1, s); }
 }
 
 // row epilogues: BN = padded d_model.  16-row tiles while the problem is small (M = 2048 gives only 128 of them); 32-row
