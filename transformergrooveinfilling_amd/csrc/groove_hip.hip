@@ -459,23 +459,56 @@ static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float*
             x.prm + gamma_off, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
             x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d, rpw);
 }
-// x_out = LN(drop(in W^T + b) + res)
+// dz = LNbwd_inner(LNbwd_outer(dy)): the final encoder / decoder norm (outer) and the top layer's last norm (inner) sit back
+// to back; one pass over the rows instead of two launches.  Falls back to two passes when the partials table is full.
+static void ln_bwd2(const Ctx& x, const float* dy, const float* xhat_o, const float* rstd_o, int64_t gamma_o, float* mid,
+                    const float* xhat_i, const float* rstd_i, int64_t gamma_i, float* dz, float* dzm, int site) {
+  const int rpw = x.M <= 4096 ? 2 : GT_LNB_ROWS;
+  const int nblk = (x.M + 4 * rpw - 1) / (4 * rpw);
+  float* part_o = (x.ln && x.ln->n + 2 <= GT_LN_JOBS_MAX) ? ln_job(x, gamma_o, nblk) : nullptr;
+  float* part_i = part_o ? ln_job(x, gamma_i, nblk) : nullptr;
+  if (!part_o || !part_i) {
+    ln_bwd(x, dy, nullptr, xhat_o, rstd_o, gamma_o, mid, nullptr, 0);
+    ln_bwd(x, mid, nullptr, xhat_i, rstd_i, gamma_i, dz, dzm, site);
+    return;
+  }
+  gt_prof_tag("ln_bwd", 0, 20.0 * x.M * x.d);
+  gt_launch(ln_bwd2_kernel, dim3(nblk), dim3(256), x.s, dy, xhat_o, rstd_o, (const float*)(x.prm + gamma_o), part_o, xhat_i, rstd_i,
+            (const float*)(x.prm + gamma_i), part_i, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.M, x.d, rpw);
+}
+// second norm applied right after linear_res_ln's (the final encoder / decoder norm after the last layer)
+struct SecondNorm { int64_t gamma_off; float* y; float* xhat; float* rstd; };
+// x_out = LN(drop(in W^T + b) + res)   [; second->y = LN_second(x_out)]
 static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, int64_t b_off, const float* res, int64_t gamma_off,
-                         float* out, float* xhat, float* rstd, int site) {
+                         float* out, float* xhat, float* rstd, int site, const SecondNorm* second = nullptr) {
   GemmArgs g = mk_gemm(in, K, x.prm + w_off, K, out, x.d, x.M, x.d, K);
   g.bias = x.prm + b_off;
+  const int64_t bo = (x.d + 63) / 64 * 64;          // a norm's bias tensor follows its weight
   if (!row_fused(x)) {
     gemm_launch<false, false, EPI_STORE>(g, x.s);
+    if (second) {
+      gt_prof_tag("ln_fwd", 0, 24.0 * x.M * x.d);
+      gt_launch(ln_fwd2_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
+                x.prm + gamma_off + bo, out, xhat, rstd, (const float*)(x.prm + second->gamma_off),
+                (const float*)(x.prm + second->gamma_off + bo), second->y, second->xhat, second->rstd, x.M, x.d);
+      return 0;
+    }
     gt_prof_tag("ln_fwd", 0, 16.0 * x.M * x.d);
     gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
-              x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d);
+              x.prm + gamma_off + bo, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d);
     return 0;
   }
   g.res = res; g.ldres = x.d;
   g.gamma = x.prm + gamma_off; g.beta = x.prm + gamma_off + (x.d + 63) / 64 * 64;
   g.aux = xhat; g.aux2 = rstd;
   g.drop = mk_drop(x, site);
-  return gemm_launch_row<false, false, EPI_RES_LN>(g, x.s);
+  if (gemm_launch_row<false, false, EPI_RES_LN>(g, x.s)) return -1;
+  if (second) {                                     // fused row tile for the first norm: the second one is its own pass
+    gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
+    gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, (const float*)nullptr, no_drop(),
+              x.prm + second->gamma_off, x.prm + second->gamma_off + bo, second->y, second->xhat, second->rstd, x.M, x.d, x.d, x.d, x.d);
+  }
+  return 0;
 }
 // head dims served by the MFMA attention kernels (0: use the generic LDS/VALU kernels); GT_ATTN_MFMA=0 forces the generic ones
 static int attn_mfma_hd(const Ctx& x) {
@@ -549,13 +582,14 @@ static void input_layer_fwd(const Ctx& x, const float* in, int S, int64_t w, int
   gemm_launch<false, false, EPI_RELU_PE>(g, x.s);
 }
 // FFN block + last norm of a layer:  xout = LN(xin + drop(W2 drop(relu(W1 xin + b1)) + b2))
-static int ffn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int64_t norm_w, int gl) {
+static int ffn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int64_t norm_w, int gl,
+                   const SecondNorm* second = nullptr) {
   float* ws = x.ws;
   GemmArgs g = mk_gemm(xin, x.d, x.prm + p.w1, x.d, ws + w.hact, x.F, x.M, x.F, x.d);
   g.bias = x.prm + p.b1; g.drop = mk_drop(x, lsite(gl, GT_SITE_FFN));
   gemm_launch<false, false, EPI_RELU_DROP>(g, x.s);
   return linear_res_ln(x, ws + w.hact, x.F, p.w2, p.b2, xin, norm_w, ws + w.xout, ws + w.xhat2, ws + w.rstd2,
-                       lsite(gl, GT_SITE_DROPF));
+                       lsite(gl, GT_SITE_DROPF), second);
 }
 static int self_attn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int causal, int gl) {
   float* ws = x.ws;
@@ -624,12 +658,11 @@ static int encoder_fwd(const Ctx& x, const float* pe, const float* src) {
     const LayerP& p = x.P.enc[l];
     const LayerW& w = x.W.layers[l];
     if (self_attn_fwd(x, p, w, cur, 0, l)) return gt_fail("d_model %d unsupported by the row-LayerNorm kernels", x.d);
-    if (ffn_fwd(x, p, w, ws + w.x1, p.n2w, l)) return -1;
+    // the final encoder norm rides on the last layer's closing norm (one row pass for both)
+    const SecondNorm fin = {x.P.encn_w, ws + x.W.memory, ws + x.W.enc_xhat, ws + x.W.enc_rstd};
+    if (ffn_fwd(x, p, w, ws + w.x1, p.n2w, l, l == x.c.n_enc_layers - 1 ? &fin : nullptr)) return -1;
     cur = ws + w.xout;
   }
-  gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
-  gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, (const float*)nullptr, no_drop(), x.prm + x.P.encn_w,
-            x.prm + x.P.encn_b, ws + x.W.memory, ws + x.W.enc_xhat, ws + x.W.enc_rstd, x.M, x.d, x.d, x.d, x.d);
   return 0;
 }
 static int decoder_fwd(const Ctx& x, const float* pe, const float* tgt_in) {
@@ -648,12 +681,10 @@ static int decoder_fwd(const Ctx& x, const float* pe, const float* tgt_in) {
     attention_fwd(x, ws + w.qx, d, ws + w.kvx, ws + w.kvx + d, 2 * d, ws + w.Px, ws + w.ctxx, 0, lsite(gl, GT_SITE_XATTN));
     if (linear_res_ln(x, ws + w.ctxx, d, p.xa.out_w, p.xa.out_b, ws + w.x1, p.n2w, ws + w.x2, ws + w.xhatx, ws + w.rstdx,
                       lsite(gl, GT_SITE_DROP2))) return -1;
-    if (ffn_fwd(x, p, w, ws + w.x2, p.n3w, gl)) return -1;
+    const SecondNorm fin = {x.P.decn_w, ws + x.W.dec_final, ws + x.W.dec_xhat, ws + x.W.dec_rstd};
+    if (ffn_fwd(x, p, w, ws + w.x2, p.n3w, gl, l == x.c.n_dec_layers - 1 ? &fin : nullptr)) return -1;
     cur = ws + w.xout;
   }
-  gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
-  gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, cur, (const float*)nullptr, no_drop(), x.prm + x.P.decn_w,
-            x.prm + x.P.decn_b, ws + x.W.dec_final, ws + x.W.dec_xhat, ws + x.W.dec_rstd, x.M, x.d, x.d, x.d, x.d);
   return 0;
 }
 // ---- greedy decoding, one time step: every row-wise op of the decoder runs on row t of each sequence only (a GEMM with
@@ -906,6 +937,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     return launch_status("gt_backward");
   }
 
+  bool top_norm_done = false;                       // the top layer's closing norm was folded into the final norm's pass
   if (phase != 2) {
   // OutputLayer: dlogits, dW_out, then d(final) fused with the final norm's backward
   if (d_hvo != nullptr) {
@@ -914,17 +946,29 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   }
   const float* fin = ws + (Ld > 0 ? W.dec_final : W.memory);
   wgrad(x, ws + W.dlogits, GT_TGT, fin, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
+  // the final norm's backward and the top layer's closing norm's backward sit back to back: when the output-layer dgrad is
+  // an ordinary tiled GEMM (row_fused false) both run as ONE row pass (ln_bwd2); with fused row tiles the first one is the
+  // GEMM's epilogue and the second its own pass
   {
     const float* xh = ws + (Ld > 0 ? W.dec_xhat : W.enc_xhat);
     const float* rs = ws + (Ld > 0 ? W.dec_rstd : W.enc_rstd);
-    if (dgrad_lnbwd(x, ws + W.dlogits, GT_TGT, params + P.out_w, GT_TGT, nullptr, xh, rs, Ld > 0 ? P.decn_w : P.encn_w,
-                    ws + W.dctx, nullptr, 0))
+    const int64_t gfin = Ld > 0 ? P.decn_w : P.encn_w;
+    if (!row_fused(x)) {
+      const LayerW& w = W.layers[top];
+      Tmp t = tmp_set(x, top);
+      acquire_set(x, top);
+      dgrad_store(x, ws + W.dlogits, GT_TGT, params + P.out_w, d, ws + W.dctx, d, GT_TGT, 0);
+      ln_bwd2(x, ws + W.dctx, xh, rs, gfin, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, Ld > 0 ? P.dec[Ld - 1].n3w : P.enc[L - 1].n2w,
+              t.dzA, t.dzAm, lsite(top, GT_SITE_DROPF));
+      top_norm_done = true;
+    } else if (dgrad_lnbwd(x, ws + W.dlogits, GT_TGT, params + P.out_w, GT_TGT, nullptr, xh, rs, gfin, ws + W.dctx, nullptr, 0)) {
       return gt_fail("d_model %d unsupported by the row-LayerNorm kernels", d);
+    }
   }
-  // ws.dctx now holds the grad w.r.t. the last layer's output (the input of the final norm)
+  // ws.dctx now holds the grad w.r.t. the last layer's output (the input of the final norm) unless top_norm_done
   if (Ld > 0) {
     (void)hipMemsetAsync(ws + W.dmem, 0, (size_t)M * d * sizeof(float), x.s);
-    {
+    if (!top_norm_done) {
       const LayerW& w = W.layers[top];
       Tmp t = tmp_set(x, top);
       ln_bwd(x, ws + W.dctx, nullptr, ws + w.xhat2, ws + w.rstd2, P.dec[Ld - 1].n3w, t.dzA, t.dzAm, lsite(top, GT_SITE_DROPF));
@@ -967,10 +1011,13 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   }                                                 // phase != 2
   if (Ld > 0) {
     if (phase == 1) return finish();                // decoder half (bucket 0) done; ws.dmem holds the memory gradient
-    // encoder final norm backward (input: accumulated dmem) -> grad w.r.t. the last encoder layer's output
-    ln_bwd(x, ws + W.dmem, nullptr, ws + W.enc_xhat, ws + W.enc_rstd, P.encn_w, ws + W.dctx, nullptr, 0);
-  }
-  if (phase != 2 || Ld > 0) {
+    // encoder final norm backward (input: accumulated dmem) and the last encoder layer's closing norm: one row pass
+    const LayerW& w = W.layers[L - 1];
+    const Tmp t = tmp_set(x, L - 1);
+    acquire_set(x, L - 1);
+    ln_bwd2(x, ws + W.dmem, ws + W.enc_xhat, ws + W.enc_rstd, P.encn_w, ws + W.dctx, ws + w.xhat2, ws + w.rstd2, P.enc[L - 1].n2w,
+            t.dzA, t.dzAm, lsite(L - 1, GT_SITE_DROPF));
+  } else if (phase != 2 && !top_norm_done) {
     const LayerW& w = W.layers[L - 1];
     const Tmp t = tmp_set(x, L - 1);
     acquire_set(x, L - 1);

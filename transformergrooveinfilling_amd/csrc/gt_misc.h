@@ -125,6 +125,142 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
   }
 }
 
+// ---- two LayerNorms back to back in one pass (the top layer's last norm and the final encoder / decoder norm) -----------
+// forward:  z = x * dropmask + res;  y1 = LN_1(z);  y2 = LN_2(y1)      (xhat / rstd of both saved; all outputs dense (M, N))
+__global__ __launch_bounds__(256) void ln_fwd2_kernel(const float* x, const float* __restrict__ res, DropArgs drop,
+                                                      const float* __restrict__ gamma1, const float* __restrict__ beta1, float* y1,
+                                                      float* __restrict__ xhat1, float* __restrict__ rstd1,
+                                                      const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                      float* __restrict__ y2, float* __restrict__ xhat2, float* __restrict__ rstd2,
+                                                      int M, int N) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* const zp = gt_zero_ptr();
+  const uint32_t dkey = gt_drop_key(drop);
+  const float invN = 1.0f / (float)N;
+  float z[GT_MAX_D / 64], r[GT_MAX_D / 64], ga[GT_MAX_D / 64], be[GT_MAX_D / 64], gb[GT_MAX_D / 64], bb[GT_MAX_D / 64];
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) {            // all loads first, branch-free (address select)
+    const int c = lane + 64 * i;
+    const bool ok = c < N;
+    z[i] = *(ok ? x + (size_t)row * N + c : zp);
+    r[i] = *((ok && res != nullptr) ? res + (size_t)row * N + c : zp);
+    ga[i] = *(ok ? gamma1 + c : zp); be[i] = *(ok ? beta1 + c : zp);
+    gb[i] = *(ok ? gamma2 + c : zp); bb[i] = *(ok ? beta2 + c : zp);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) {
+    const int c = lane + 64 * i;
+    z[i] = (c < N) ? z[i] * gt_drop_mul(drop, dkey, (uint32_t)((size_t)row * N + c)) + r[i] : 0.f;
+    s += z[i];
+  }
+  float mean = gt_wave_sum(s) * invN, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) { if (lane + 64 * i < N) { const float d = z[i] - mean; q += d * d; } }
+  float rs = 1.0f / sqrtf(gt_wave_sum(q) * invN + GT_LN_EPS);
+  s = 0.f;
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) {
+    const int c = lane + 64 * i;
+    if (c < N) {
+      const float xh = (z[i] - mean) * rs;
+      xhat1[(size_t)row * N + c] = xh;
+      z[i] = xh * ga[i] + be[i];
+      y1[(size_t)row * N + c] = z[i];
+      s += z[i];
+    }
+  }
+  if (lane == 0) rstd1[row] = rs;
+  mean = gt_wave_sum(s) * invN; q = 0.f;
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) { if (lane + 64 * i < N) { const float d = z[i] - mean; q += d * d; } }
+  rs = 1.0f / sqrtf(gt_wave_sum(q) * invN + GT_LN_EPS);
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) {
+    const int c = lane + 64 * i;
+    if (c < N) {
+      const float xh = (z[i] - mean) * rs;
+      xhat2[(size_t)row * N + c] = xh;
+      y2[(size_t)row * N + c] = xh * gb[i] + bb[i];
+    }
+  }
+  if (lane == 0) rstd2[row] = rs;
+}
+
+// backward:  g = dy;  t = LNbwd_2(g)  (the OUTER norm, applied last in forward);  dz = LNbwd_1(t);  dz_masked = dz * dropmask.
+// Both norms leave their dgamma / dbeta as per-workgroup partials (part2 for the outer norm, part1 for the inner one).
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(const float* dy, const float* __restrict__ xhat2, const float* __restrict__ rstd2,
+                                                      const float* __restrict__ gamma2, float* __restrict__ part2,
+                                                      const float* __restrict__ xhat1, const float* __restrict__ rstd1,
+                                                      const float* __restrict__ gamma1, float* __restrict__ part1,
+                                                      float* dz, float* __restrict__ dz_masked, DropArgs drop, int M, int N,
+                                                      int rows_per_wave) {
+  __shared__ float sred[4][2][GT_MAX_D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + w) * rows_per_wave;
+  const float invN = 1.0f / (float)N;
+  const uint32_t dkey = gt_drop_key(drop);
+  const float* const zp = gt_zero_ptr();
+  float dg2[GT_MAX_D / 64], db2[GT_MAX_D / 64], dg1[GT_MAX_D / 64], db1[GT_MAX_D / 64];
+#pragma unroll
+  for (int i = 0; i < GT_MAX_D / 64; ++i) { dg2[i] = 0.f; db2[i] = 0.f; dg1[i] = 0.f; db1[i] = 0.f; }
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    float d[GT_MAX_D / 64], xa[GT_MAX_D / 64], gA[GT_MAX_D / 64], xb[GT_MAX_D / 64], gB[GT_MAX_D / 64];
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {          // all loads first, branch-free (address select)
+      const int c = lane + 64 * i;
+      const bool ok = c < N;
+      d[i] = *(ok ? dy + (size_t)row * N + c : zp);
+      xa[i] = *(ok ? xhat2 + (size_t)row * N + c : zp); gA[i] = *(ok ? gamma2 + c : zp);
+      xb[i] = *(ok ? xhat1 + (size_t)row * N + c : zp); gB[i] = *(ok ? gamma1 + c : zp);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const float gd = d[i] * gA[i];
+      s1 += gd; s2 += gd * xa[i]; dg2[i] += d[i] * xa[i]; db2[i] += d[i];
+    }
+    float m1 = gt_wave_sum(s1) * invN, m2 = gt_wave_sum(s2) * invN, rs = rstd2[row];
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      d[i] = (lane + 64 * i < N) ? rs * (d[i] * gA[i] - m1 - xa[i] * m2) : 0.f;        // gradient w.r.t. the inner norm's output
+      const float gd = d[i] * gB[i];
+      s1 += gd; s2 += gd * xb[i]; dg1[i] += d[i] * xb[i]; db1[i] += d[i];
+    }
+    m1 = gt_wave_sum(s1) * invN; m2 = gt_wave_sum(s2) * invN; rs = rstd1[row];
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      if (c < N) {
+        const size_t e = (size_t)row * N + c;
+        const float v = rs * (d[i] * gB[i] - m1 - xb[i] * m2);
+        dz[e] = v;
+        if (dz_masked) dz_masked[e] = v * gt_drop_mul(drop, dkey, (uint32_t)e);
+      }
+    }
+  }
+  // partials per workgroup [block][2][N], outer norm then inner norm (the LDS buffer is reused)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float* part = pass == 0 ? part2 : part1;
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      if (c < N) { sred[w][0][c] = pass == 0 ? dg2[i] : dg1[i]; sred[w][1][c] = pass == 0 ? db2[i] : db1[i]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+      part[((size_t)blockIdx.x * 2) * N + c] = sred[0][0][c] + sred[1][0][c] + sred[2][0][c] + sred[3][0][c];
+      part[((size_t)blockIdx.x * 2 + 1) * N + c] = sred[0][1][c] + sred[1][1][c] + sred[2][1][c] + sred[3][1][c];
+    }
+    __syncthreads();
+  }
+}
+
 // dgamma / dbeta of every LayerNorm of the step in ONE launch: job j sums its workgroup partials [nwg][2][N] in a fixed
 // order (deterministic) and adds them into the gradient buffer.  grid = (ceil(2N/64), jobs); 16 waves split the partials.
 #define GT_LN_JOBS_MAX 96
