@@ -22,6 +22,7 @@ SHAPES = [
     ("C3 enc-dec d256/H2/F512/L6+6 bs256", dict(d_model=256, n_heads=2, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=6, dropout=0.3), 256),
     ("C4 d512/H8/F512/L6 bs64 (per-GPU share of 512)", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3), 64),
     ("C4 d512/H8/F512/L6 bs512", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3), 512),
+    ("C5 shape in fp32: symbolic input S=27, d512/H8/F512/L6 bs64", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3, embedding_size_src=27), 64),
 ]
 
 
@@ -35,10 +36,10 @@ def main():
     for i, (name, dims, B) in enumerate(SHAPES):
         if args.only >= 0 and i != args.only:
             continue
-        dims = dict(dims, embedding_size_src=16)
+        dims = dict(dict(embedding_size_src=16), **dims)
         eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=1, use_graph=not args.no_graph, **dims)
         eng.load_named(ng.init_params(dims, seed=0))
-        x, y = ng.synthetic_batch(B, 16, seed=2)
+        x, y = ng.synthetic_batch(B, dims["embedding_size_src"], seed=2)
         eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))
         for _ in range(args.warmup):
             eng.train_step()
