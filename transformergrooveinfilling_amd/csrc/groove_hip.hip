@@ -360,9 +360,9 @@ static void wgrad(const Ctx& x, const float* dY, int ldy, const float* X, int ld
 // run on a second stream and overlap the dgrad chain, which alone cannot fill 256 CUs at these sizes.  The stream and
 // a pool of events are created once, on first use (outside any capture: the engine's warm-up call); under hipGraph
 // capture the record/wait pairs become fork/join edges of the captured graph.
-// Measured on MI355X / ROCm 7.2 (profiles/, r01f): captured into a hipGraph the fork/join did NOT buy concurrency --
-// the sum of kernel durations still equalled the wall time and the step got 7 % slower -- so the default is OFF
-// (GT_OVERLAP=1 or gt_set_overlap(1) turns it on for experiments).
+// Measured on MI355X / ROCm 7.2: captured into a hipGraph the fork/join did NOT buy concurrency -- the step got 7 % slower,
+// 14 % once the chain kernels had shrunk -- so the default is OFF (GT_OVERLAP=1 or gt_set_overlap(1) turns it on for
+// experiments; it only has an effect when the weight gradients leave layer by layer, see wgrad_deferred).
 static int g_overlap = -1;
 #ifndef GT_EMU
 static hipStream_t g_side = nullptr;
@@ -850,9 +850,10 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   const WLayout& W = x.W;
   const PLayout& P = x.P;
   if (!accumulate) (void)hipMemsetAsync(grads, 0, (size_t)P.total * sizeof(float), x.s);
-  // Weight gradients are queued and leave as ONE grouped dispatch per layer (wgrad_sync) on the side stream.  Layer gl
-  // keeps its temporaries in set gl&1; acquire_set() makes the main stream wait for the side-stream reader of a set
-  // right before the first kernel that writes into it again (two layers later).
+  // Weight gradients are queued and leave as ONE grouped dispatch per tile class at the end of the (phase of) backward
+  // (finish()); every layer keeps its own temporaries (W.set) for that.  Only with GT_WGRAD_DEFER_MAX_M lowered below the
+  // token count do they leave layer by layer (wgrad_sync; two alternating sets; optionally on the side stream, where
+  // acquire_set() orders the reuse of a set behind its side-stream reader).
   WgradBatch wbatch;
   x.wb = &wbatch;
   x.side = side_stream();
