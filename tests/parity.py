@@ -80,7 +80,11 @@ def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chai
     Gr = ng.backward(P, cfg, C, dpred, dtype=np.float64)
     assert set(G) == set(Gr)
     for k in Gr:
-        assert rel_err(G[k], Gr[k]) < GRAD_TOL, (k, rel_err(G[k], Gr[k]))
+        # relative to the tensor's largest entry, with an absolute floor: a tensor that is numerically zero (|g| < 1e-5
+        # everywhere -- e.g. LayerNorm gammas at d_model 2, where the normalised outputs are +-1 and the sum cancels; the
+        # oracle's own fp32 run is 10 % off its fp64 run there) is compared absolutely
+        err = float(np.abs(G[k] - Gr[k]).max() / max(np.abs(Gr[k]).max(), 1e-5))
+        assert err < GRAD_TOL, (k, err)
     return r, P, G, Gr
 
 
@@ -141,12 +145,19 @@ def check_predict(backend, cfg, B, use_thres=True, thres=0.5):
     if use_thres:
         sure = margin > 1e-4
         if cfg.get("num_decoder_layers", 0):
-            # a flipped low-margin hit changes every later step of that sequence: compare sequences
-            # whose decisions are all outside the margin
-            ok = sure.reshape(B, -1).all(1)
-            assert ok.any()
-            assert np.array_equal(hvo[ok][..., :9], h[ok])
-            assert np.abs(hvo[ok][..., 9:] - np.concatenate([v, o], -1)[ok]).max() < OUT_TOL
+            # greedy decoding: a flipped low-margin hit changes every LATER step of that sequence, so each sequence is
+            # compared up to (not including) its first step with a decision inside the margin -- bit-exact hits, v / o
+            # within tolerance; sequences that are sure everywhere are compared whole
+            vo = np.concatenate([v, o], -1)
+            compared = 0
+            for b in range(B):
+                unsure = np.flatnonzero(~sure[b].reshape(32, -1).all(1))
+                t_end = int(unsure[0]) if len(unsure) else 32
+                compared += t_end
+                assert np.array_equal(hvo[b, :t_end, :9], h[b, :t_end]), (b, t_end)
+                if t_end:
+                    assert np.abs(hvo[b, :t_end, 9:] - vo[b, :t_end]).max() < OUT_TOL, (b, t_end)
+            assert compared > 0, "no comparable decode step: every sequence has a low-margin decision at step 0"
             return
         assert np.array_equal(hvo[..., :9][sure], h[sure])                      # bit-exact hit mask
         assert set(np.unique(hvo[..., :9])) <= {0.0, 1.0}

@@ -136,3 +136,13 @@ def test_errors_are_reported():
     bad = _lib.make_config(2, 16, 48, 5, 16, 2)            # 48 % 5 != 0
     with pytest.raises(_lib.GrooveLibError, match="divisible"):
         r.lib.call("gt_forward", ctypes.byref(bad), r.pe.ptr, r.pe.ptr, r.hvo.ptr, None, r.hvo.ptr, r.ws.ptr, None, 0, r.stream)
+
+
+def test_random_odd_shapes():
+    """a fixed-seed slice of tools/fuzz_parity.py: odd widths / head counts / FFN sizes / batch sizes / input dims, encoder-only
+    and encoder-decoder, each through full step parity, predict and the bucketed backward"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    assert fuzz_parity.run(20, seed=11, verbose=False) == 0
