@@ -83,20 +83,28 @@ def test_predict(cfg, B, use_thres):
 
 
 # ---- properties at full size (BASELINE configs[1]: d128/H4/F512/L3, bs 64, dropout 0.24) ---------------
-def test_full_size_properties():
-    cfg = dict(C2, dropout=0.24)
-    B = 64
+FULL_SIZES = [(C2, 64, 0.24, 0.07),                                                      # BASELINE configs[1]
+              (cfg_dict(256, 2, 512, 6, 6), 256, 0.3, 0.02),                              # configs[2]: full encoder-decoder, bs 256
+              (cfg_dict(512, 8, 512, 6), 64, 0.3, 0.02)]                                  # configs[3]: d512 / 8 heads / 6 layers, 64 per GPU
+
+
+@pytest.mark.parametrize("cfg0,B,p,lr", FULL_SIZES)
+def test_full_size_properties(cfg0, B, p, lr):
+    """size-independent properties at BASELINE's full sizes (no oracle run needed)"""
+    cfg = dict(cfg0, dropout=p)
+    dec = cfg.get("num_decoder_layers", 0) > 0
     P = ng.init_params(cfg, seed=0)
     x, y = ng.synthetic_batch(B, 16, seed=1234)
-    r = Runner(cfg, B, "hip", rng=(5, 6, 0), lr=0.07)
+    tgt = parity.shift_right(y) if dec else None
+    r = Runner(cfg, B, "hip", rng=(5, 6, 0), lr=lr)
     r.set_params(P)
     # (1) eval forward is a pure function of (weights, inputs): bitwise repeatable
-    a = r.forward(x)
-    b = r.forward(x)
+    a = r.forward(x, tgt)
+    b = r.forward(x, tgt)
     assert np.array_equal(a, b)
     # (2) sequences are independent: permuting the batch permutes the outputs bit for bit
     perm = np.random.default_rng(0).permutation(B)
-    c = r.forward(x[perm])
+    c = r.forward(x[perm], tgt[perm] if dec else None)
     assert np.array_equal(c, a[perm])
     # (3) v in (0,1), o in (-0.5,0.5)
     assert (a[..., 9:18] > 0).all() and (a[..., 9:18] < 1).all() and (np.abs(a[..., 18:]) < 0.5).all()
@@ -112,15 +120,16 @@ def test_full_size_properties():
     for k in g1:
         assert parity.rel_err(g2[k], 2.0 * g1[k]) < 1e-5, k
     # (6) train-mode dropout: same (seed, step) -> same masks; next step -> different masks, same keep rate
-    t0 = r.forward(x, train=True)
+    t0 = r.forward(x, tgt, train=True)
     h0 = r.ws_get("hact", 0)
-    t1 = r.forward(x, train=True)
+    t1 = r.forward(x, tgt, train=True)
     assert np.array_equal(t0, t1)
     r.train_step(x, y, 0.38)
     assert r.step_state().step == 1
-    r.forward(x, train=True)
+    r.forward(x, tgt, train=True)
     h1 = r.ws_get("hact", 0)
     assert not np.array_equal(h0 == 0, h1 == 0)
+    assert abs((h0 == 0).mean() - (h1 == 0).mean()) < 0.01
     # (7) a few SGD steps on a fixed batch reduce the loss
     losses = [r.train_step(x, y, 0.38)[0] for _ in range(20)]
     assert losses[-1] < losses[0]
