@@ -71,8 +71,11 @@ def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chai
         assert rel_err(r.ws_get("memory").reshape(-1), C["memory"].reshape(-1)) < 1e-5
     stats, d_hvo = r.loss(y, penalty)
     rstats, dpred = ng.calculate_loss((h, v, o), y.astype(np.float64), penalty)
-    for i in (0, 1, 3, 4, 5):
+    for i in (0, 3, 4, 5):
         assert abs(stats[i] - rstats[i]) < 1e-5 * max(1.0, abs(rstats[i])), (i, stats[i], rstats[i])
+    # hit accuracy counts (h > 0) == y_h: a logit within 1e-4 of 0 may fall on the other side in fp32, one count each
+    near = int((np.abs(h) < 1e-4).sum())
+    assert abs(stats[1] - rstats[1]) <= (near + 0.01) / h.size + 1e-6, (stats[1], rstats[1], near)
     assert rel_err(d_hvo, np.concatenate(dpred, -1)) < 1e-5
     G = r.backward(train=p > 0)
     adopted = adopt_device_kinks(r, C, cfg)

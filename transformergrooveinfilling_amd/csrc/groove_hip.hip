@@ -514,7 +514,9 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
 static int attn_mfma_hd(const Ctx& x) {
   static const int enabled = [] { const char* e = getenv("GT_ATTN_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();
   const int hd = x.d / x.H;
-  return (enabled && (hd == 16 || hd == 32 || hd == 64 || hd == 128)) ? hd : 0;
+  if (!enabled) return 0;
+  if (hd == 16 || hd == 32 || hd == 64 || hd == 128) return hd;
+  return hd < 16 ? -16 : 0;                         // -16: the 16-wide kernels with zero-padded operands (head_dim 1..15)
 }
 static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, float* P, float* ctx,
                           int causal, int site) {
@@ -525,10 +527,11 @@ static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k,
   gt_prof_tag("attn_fwd", 4.0 * x.M * 32 * x.d, 4.0 * (4.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   const dim3 grid(x.c.batch * x.H);
   switch (attn_mfma_hd(x)) {
-    case 16:  gt_launch(attn_fwd_mfma_kernel<16>, grid, dim3(128), x.s, a); break;
-    case 32:  gt_launch(attn_fwd_mfma_kernel<32>, grid, dim3(128), x.s, a); break;
-    case 64:  gt_launch(attn_fwd_mfma_kernel<64>, grid, dim3(128), x.s, a); break;
-    case 128: gt_launch(attn_fwd_mfma_kernel<128>, grid, dim3(128), x.s, a); break;
+    case 16:  gt_launch(attn_fwd_mfma_kernel<16, false>, grid, dim3(128), x.s, a); break;
+    case 32:  gt_launch(attn_fwd_mfma_kernel<32, false>, grid, dim3(128), x.s, a); break;
+    case 64:  gt_launch(attn_fwd_mfma_kernel<64, false>, grid, dim3(128), x.s, a); break;
+    case 128: gt_launch(attn_fwd_mfma_kernel<128, false>, grid, dim3(128), x.s, a); break;
+    case -16: gt_launch(attn_fwd_mfma_kernel<16, true>, grid, dim3(128), x.s, a); break;
     default:  gt_launch(attn_fwd_kernel, grid, dim3(256), x.s, a);
   }
 }
@@ -542,10 +545,11 @@ static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k,
   gt_prof_tag("attn_bwd", 10.0 * x.M * 32 * x.d, 4.0 * (7.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   const dim3 grid(x.c.batch * x.H);
   switch (attn_mfma_hd(x)) {
-    case 16:  gt_launch(attn_bwd_mfma_kernel<16>, grid, dim3(128), x.s, a); break;
-    case 32:  gt_launch(attn_bwd_mfma_kernel<32>, grid, dim3(128), x.s, a); break;
-    case 64:  gt_launch(attn_bwd_mfma_kernel<64>, grid, dim3(128), x.s, a); break;
-    case 128: gt_launch(attn_bwd_mfma_kernel<128>, grid, dim3(128), x.s, a); break;
+    case 16:  gt_launch(attn_bwd_mfma_kernel<16, false>, grid, dim3(128), x.s, a); break;
+    case 32:  gt_launch(attn_bwd_mfma_kernel<32, false>, grid, dim3(128), x.s, a); break;
+    case 64:  gt_launch(attn_bwd_mfma_kernel<64, false>, grid, dim3(128), x.s, a); break;
+    case 128: gt_launch(attn_bwd_mfma_kernel<128, false>, grid, dim3(128), x.s, a); break;
+    case -16: gt_launch(attn_bwd_mfma_kernel<16, true>, grid, dim3(128), x.s, a); break;
     default:  gt_launch(attn_bwd_kernel, grid, dim3(256), x.s, a);
   }
 }

@@ -188,32 +188,46 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 // Q/K fragments use the k-permutation of gt_gemm.h: lane (l16, g) loads ONE float4 = columns 16q + 4g .. +3 of its row
 // and uses the components as four consecutive k-steps; A and B permute alike, so the contraction is unchanged.
 // ================================================================================================================
-template <int HD>
+// operand loads of the MFMA kernels: plain 16-byte / 4-byte loads, or (PAD: head_dim < 16 zero-padded to 16 columns) masked
+// 4-byte loads through the zero page -- column index `col` (of the first element) against the real head_dim
+template <bool PAD>
+__device__ __forceinline__ float4 attn_ld4(const float* p, int col, int hd, const float* zp) {
+  if (!PAD) return *reinterpret_cast<const float4*>(p);
+  return make_float4(*(col < hd ? p : zp), *(col + 1 < hd ? p + 1 : zp), *(col + 2 < hd ? p + 2 : zp), *(col + 3 < hd ? p + 3 : zp));
+}
+template <bool PAD>
+__device__ __forceinline__ float attn_ld1(const float* p, int col, int hd, const float* zp) {
+  if (!PAD) return *p;
+  return *(col < hd ? p : zp);
+}
+template <int HD, bool PAD>
 __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
   constexpr int NQ = HD / 16;
+  const int hdr = PAD ? a.hd : HD;               // real head_dim (PAD: < 16, operands zero-padded to 16 columns)
+  const float* const zp = gt_zero_ptr();
   const int lane = threadIdx.x & 63, ti = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int i = 16 * ti + l16;                                   // this lane's query row
-  const float* qrow = a.q + (size_t)(b * 32 + i) * a.ldq + h * HD + 4 * g;
-  const float* krow = a.k + (size_t)(b * 32 + l16) * a.ldk + h * HD + 4 * g;      // key tile 0; tile 1 = + 16 rows
+  const float* qrow = a.q + (size_t)(b * 32 + i) * a.ldq + h * hdr + 4 * g;
+  const float* krow = a.k + (size_t)(b * 32 + l16) * a.ldk + h * hdr + 4 * g;      // key tile 0; tile 1 = + 16 rows
   // Every operand of the kernel is requested up front (Q, K fragments and all of V: 40 registers at head_dim 32, 160 at
   // 128) so the loads are all in flight together; issued tile by tile each one would cost its own memory round trip.
   f32x4 st[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};           // S^T tiles [tj]
   float4 qf[NQ], k0[NQ], k1[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    qf[q] = *reinterpret_cast<const float4*>(qrow + 16 * q);
-    k0[q] = *reinterpret_cast<const float4*>(krow + 16 * q);
-    k1[q] = *reinterpret_cast<const float4*>(krow + (size_t)16 * a.ldk + 16 * q);
+    qf[q] = attn_ld4<PAD>(qrow + 16 * q, 16 * q + 4 * g, hdr, zp);
+    k0[q] = attn_ld4<PAD>(krow + 16 * q, 16 * q + 4 * g, hdr, zp);
+    k1[q] = attn_ld4<PAD>(krow + (size_t)16 * a.ldk + 16 * q, 16 * q + 4 * g, hdr, zp);
   }
-  const float* __restrict__ vcol = a.v + (size_t)(b * 32 + 4 * g) * a.ldv + h * HD + l16;     // V[4g + c + 16 tj][16 ct + l16]
+  const float* __restrict__ vcol = a.v + (size_t)(b * 32 + 4 * g) * a.ldv + h * hdr + l16;     // V[4g + c + 16 tj][16 ct + l16]
   float vb[NQ][2][4];
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) vb[ct][tj][c] = vcol[(size_t)(16 * tj + c) * a.ldv + 16 * ct];
+      for (int c = 0; c < 4; ++c) vb[ct][tj][c] = attn_ld1<PAD>(vcol + (size_t)(16 * tj + c) * a.ldv + 16 * ct, 16 * ct + l16, hdr, zp);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     st[0] = GT_MFMA16(k0[q].x, qf[q].x, st[0]); st[1] = GT_MFMA16(k1[q].x, qf[q].x, st[1]);
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
   }
   // all V loads and MFMAs first, stores last: a store between two column tiles would pin the next tile's loads behind it
   // (the pointers may alias as far as the compiler knows) and every tile would pay a full memory round trip
-  float* __restrict__ orow = a.ctx + (size_t)(b * 32 + 16 * ti + 4 * g) * a.ldc + h * HD + l16;
+  float* __restrict__ orow = a.ctx + (size_t)(b * 32 + 16 * ti + 4 * g) * a.ldc + h * hdr + l16;
   f32x4 o[NQ];
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct) {
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) orow[(size_t)r * a.ldc + 16 * ct] = o[ct][r];
+    for (int r = 0; r < 4; ++r) { if (!PAD || 16 * ct + l16 < hdr) orow[(size_t)r * a.ldc + 16 * ct] = o[ct][r]; }
 }
 
 // Backward.  Each wave plays two roles, because dq contracts over keys and dk / dv contract over queries:
@@ -274,15 +288,17 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
 //           rd[i] = sum_j dP P go through 32 floats of LDS so that role 2 can read the other wave's rows;
 //   role 2 (key tile w, S layout: lane holds X[i = 16 ti + 4g + r][j = l16]): dPd = dO V^T, P reloaded in this layout,
 //           (P*mask) and dS are then the A operands (A[m = j][k = i]) of  dv = (P*mask)^T dO  and  dk = dS^T q.
-template <int HD>
+template <int HD, bool PAD>
 __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
   constexpr int NQ = HD / 16;
+  const int hdr = PAD ? a.hd : HD;
+  const float* const zp = gt_zero_ptr();
   __shared__ float srd[32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const uint32_t dkey = gt_drop_key(a.drop);
   const size_t row0 = (size_t)b * 32;
-  const int hc = h * HD;
+  const int hc = h * hdr;
   f32x4 dq_out[NQ];
 
   // ---------------------------------------------------------------- role 1: query tile w
@@ -294,9 +310,9 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
     float4 df[NQ], v0[NQ], v1[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {                       // all loads of this role first (see the forward kernel)
-      df[q] = *reinterpret_cast<const float4*>(dorow + 16 * q);
-      v0[q] = *reinterpret_cast<const float4*>(vrow + 16 * q);
-      v1[q] = *reinterpret_cast<const float4*>(vrow + (size_t)16 * a.ldv + 16 * q);
+      df[q] = attn_ld4<PAD>(dorow + 16 * q, 16 * q + 4 * g, hdr, zp);
+      v0[q] = attn_ld4<PAD>(vrow + 16 * q, 16 * q + 4 * g, hdr, zp);
+      v1[q] = attn_ld4<PAD>(vrow + (size_t)16 * a.ldv + 16 * q, 16 * q + 4 * g, hdr, zp);
     }
     const float* __restrict__ kcol = a.k + (row0 + 4 * g) * a.ldk + hc + l16;
     float kb[NQ][2][4];
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) kb[ct][tj][c] = kcol[(size_t)(16 * tj + c) * a.ldk + 16 * ct];
+        for (int c = 0; c < 4; ++c) kb[ct][tj][c] = attn_ld1<PAD>(kcol + (size_t)(16 * tj + c) * a.ldk + 16 * ct, 16 * ct + l16, hdr, zp);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       dt[0] = GT_MFMA16(v0[q].x, df[q].x, dt[0]); dt[1] = GT_MFMA16(v1[q].x, df[q].x, dt[1]);
@@ -357,9 +373,9 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
     float4 vf[NQ], d0[NQ], d1[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      vf[q] = *reinterpret_cast<const float4*>(vrow + 16 * q);
-      d0[q] = *reinterpret_cast<const float4*>(dorow + 16 * q);
-      d1[q] = *reinterpret_cast<const float4*>(dorow + (size_t)16 * a.lddc + 16 * q);
+      vf[q] = attn_ld4<PAD>(vrow + 16 * q, 16 * q + 4 * g, hdr, zp);
+      d0[q] = attn_ld4<PAD>(dorow + 16 * q, 16 * q + 4 * g, hdr, zp);
+      d1[q] = attn_ld4<PAD>(dorow + (size_t)16 * a.lddc + 16 * q, 16 * q + 4 * g, hdr, zp);
     }
     const float* __restrict__ docol = a.dctx + (row0 + 4 * g) * a.lddc + hc + l16;
     const float* __restrict__ qcol = a.q + (row0 + 4 * g) * a.ldq + hc + l16;
@@ -370,8 +386,8 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          db[ct][ti][c] = docol[(size_t)(16 * ti + c) * a.lddc + 16 * ct];
-          qb[ct][ti][c] = qcol[(size_t)(16 * ti + c) * a.ldq + 16 * ct];
+          db[ct][ti][c] = attn_ld1<PAD>(docol + (size_t)(16 * ti + c) * a.lddc + 16 * ct, 16 * ct + l16, hdr, zp);
+          qb[ct][ti][c] = attn_ld1<PAD>(qcol + (size_t)(16 * ti + c) * a.ldq + 16 * ct, 16 * ct + l16, hdr, zp);
         }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -411,6 +427,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
     for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (PAD && 16 * ct + l16 >= hdr) continue;
         dqrow[(size_t)r * a.lddq + 16 * ct] = dq_out[ct][r];
         dvrow[(size_t)r * a.lddv + 16 * ct] = ov[ct][r];
         dkrow[(size_t)r * a.lddk + 16 * ct] = ok[ct][r];
