@@ -88,3 +88,19 @@ def test_workspace_lookup(lib):
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_lib.GrooveLibError, match="no CPU fallback"):
         _lib.GrooveLib(str(tmp_path / "libgroove_hip.so"))
+
+
+def test_too_many_layernorm_instances_are_rejected_up_front():
+    """a config whose LayerNorm count exceeds the backward's partials table must fail in the config check (before any
+    launch), not after forward and loss have run"""
+    import ctypes
+    from harness import emu_lib
+    from transformergrooveinfilling_amd import _lib
+    lib = emu_lib()
+    ok = _lib.make_config(1, 16, 32, 4, 16, 47)
+    assert lib.cdll.gt_workspace_bytes(ctypes.byref(ok)) > 0
+    bad = _lib.make_config(1, 16, 32, 4, 16, 48)
+    assert lib.cdll.gt_workspace_bytes(ctypes.byref(bad)) == 0
+    assert b"LayerNorm" in lib.cdll.gt_last_error()
+    bad2 = _lib.make_config(1, 16, 32, 4, 16, 20, 20)
+    assert lib.cdll.gt_workspace_bytes(ctypes.byref(bad2)) == 0

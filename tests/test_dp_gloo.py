@@ -75,3 +75,62 @@ def test_dp2_matches_single_process(tmp_path):
     for k in ref:
         assert np.array_equal(a[k], b[k]), k                                # replicas stay identical
         assert np.abs(a[k] - ref[k]).max() < 1e-6, k                         # == one process on the whole batch
+
+
+def _engine_worker(rank, world, port, out, overlap):
+    """the PRODUCT's data-parallel step sequence (StepEngine.train_step: fwd+loss+bwd, all-reduce(s) of the flat gradient
+    buffer, fused update averaging by grad_scale) on host memory: explicit emulator library + gloo"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      GT_DP_OVERLAP="1" if overlap else "0")
+    from harness import emu_lib
+    from transformergrooveinfilling_amd import layout, parallel
+    from transformergrooveinfilling_amd.engine import StepEngine
+    parallel.init_distributed("gloo")
+    dims = dict(d_model=32, n_heads=4, dim_feedforward=16, num_encoder_layers=2, num_decoder_layers=0, dropout=0.0, embedding_size_src=16)
+    B = 4
+    eng = StepEngine(batch_size=B // world, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3 | (rank << 32),
+                     device="cpu", world_size=world, lib=emu_lib(), **dims)
+    assert eng.overlap_allreduce == bool(overlap)
+    eng.load_named(layout.init_params(dims, seed=5))
+    x, y = layout.synthetic_batch(B, 16, seed=9)
+    sl = slice(rank * (B // world), (rank + 1) * (B // world))
+    for _ in range(2):
+        eng.train_step(torch.from_numpy(x[sl]), torch.from_numpy(y[sl]))
+    mean = eng.mean_stats(eng.slot(B // world)).clone()
+    torch.save({"params": eng.params.clone(), "stats": eng.stats.clone(), "mean_stats": mean}, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_engine_dp2_matches_single_process(tmp_path, overlap):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "eng%d.pt")
+    mp.start_processes(_engine_worker, args=(world, port, out, overlap), nprocs=world, join=True, start_method="spawn")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from harness import emu_lib
+    from transformergrooveinfilling_amd import layout
+    from transformergrooveinfilling_amd.engine import StepEngine
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    dims = dict(d_model=32, n_heads=4, dim_feedforward=16, num_encoder_layers=2, num_decoder_layers=0, dropout=0.0, embedding_size_src=16)
+    eng = StepEngine(batch_size=4, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3, device="cpu", lib=emu_lib(), **dims)
+    eng.load_named(layout.init_params(dims, seed=5))
+    x, y = layout.synthetic_batch(4, 16, seed=9)
+    for _ in range(2):
+        eng.train_step(torch.from_numpy(x), torch.from_numpy(y))
+    assert torch.equal(a["params"], b["params"])                              # replicas stay identical
+    assert (a["params"] - eng.params).abs().max() < 1e-6                      # == one process on the whole batch
+    assert torch.allclose(a["mean_stats"], b["mean_stats"])                   # logged stats are the all-rank mean ...
+    assert abs(float(a["mean_stats"][0]) - float(eng.stats[0])) < 1e-5        # ... = the loss of the whole batch
+    assert abs(float(a["stats"][0]) - float(b["stats"][0])) > 1e-6            # (rank-local values differ)
+
+
+def test_engine_refuses_host_memory_without_an_explicit_library():
+    from transformergrooveinfilling_amd.engine import StepEngine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        StepEngine(32, 4, 16, 2, device="cpu")

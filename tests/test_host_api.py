@@ -127,3 +127,13 @@ def test_device_batch_loader_matches_sharded_sampler():
                     seen += [i for _, _, idx in got for i in idx.tolist()]
         assert len(seen) == len(set(seen))
         assert len(seen) == (n if world == 1 else (n // world // bs) * bs * world)
+
+
+def test_reference_evaluator_flags_are_accepted():
+    """ref:train.py:18-24: --eval_train / --eval_test / --eval_validation / --dump_eval must parse (command lines and sweep
+    programs written for the reference pass them)"""
+    a = train_cli.build_parser().parse_args(["--experiment", "InfillingClosedHH", "--eval_train", "0", "--eval_test", "1",
+                                             "--eval_validation", "0", "--dump_eval", "0", "--only_final_eval", "1"])
+    assert (a.eval_train, a.eval_test, a.eval_validation, a.dump_eval) == ("0", "1", "0", "0")
+    d = train_cli.build_parser().parse_args(["--experiment", "x"])
+    assert (d.eval_train, d.eval_test, d.eval_validation, d.dump_eval) == (True, False, True, True)     # the reference's defaults

@@ -33,6 +33,13 @@ def build_parser():
     p.add_argument("--testing", default=False, help="testing mode (1 epoch)")
     p.add_argument("--wandb", default=True, help="log to wandb (when installed)")
     p.add_argument("--only_final_eval", default=False)
+    # which sets the reference's GrooveEvaluator scores and whether it dumps them (ref:train.py:18-24).  The evaluator is
+    # host-side and outside the hot path: the flags are accepted so that sweep YAMLs / command lines written
+    # for the reference run unchanged; the device-side per-voice metrics it consumes come from `transformergrooveinfilling_amd.metrics`.
+    p.add_argument("--eval_train", default=True, help="evaluator train set")
+    p.add_argument("--eval_test", default=False, help="evaluator test set")
+    p.add_argument("--eval_validation", default=True, help="evaluator validation set")
+    p.add_argument("--dump_eval", default=True, help="dump evaluator file")
     p.add_argument("--load_model", default=None)
     p.add_argument("--notes", default=None)
     p.add_argument("--tags", default=None)
@@ -146,6 +153,7 @@ def main(argv=None):
         except Exception:
             wb = None
     params = model_params(hp, device)
+    params["seed"] = args.seed                # dropout stream of this run (the data-parallel rank is mixed in by the model)
     model, optimizer, initial_epoch = initialize_model(params)
     parallel.broadcast_parameters(model.engine.params)
     x, y = load_data(args, hp, params["model"]["embedding_size_src"])

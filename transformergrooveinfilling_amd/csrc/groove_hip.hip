@@ -101,6 +101,12 @@ static int check_cfg(const gt_config* c) {
   if (!(c->dropout >= 0.f && c->dropout < 1.f)) return gt_fail("dropout %f outside [0,1)", (double)c->dropout);
   if ((int64_t)c->batch * 32 * (c->dim_ff > 3 * c->d_model ? c->dim_ff : 3 * c->d_model) >= (1ll << 31))
     return gt_fail("batch %d too large for 32-bit element indices", c->batch);
+  // every LayerNorm instance gets one row of the dgamma/dbeta partials table (LnJobs): refuse here, before any launch,
+  // what backward could not finish
+  const int n_ln = 2 * c->n_enc_layers + 3 * c->n_dec_layers + (c->n_dec_layers > 0 ? 2 : 1);
+  if (n_ln > GT_LN_JOBS_MAX)
+    return gt_fail("%d LayerNorm instances (enc %d, dec %d layers) exceed the %d the backward's partials table holds",
+                   n_ln, c->n_enc_layers, c->n_dec_layers, GT_LN_JOBS_MAX);
   return 0;
 }
 

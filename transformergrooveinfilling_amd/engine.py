@@ -21,6 +21,8 @@ import torch
 from . import _lib, layout
 
 ALGO = {"sgd": 0, "adam": 1}
+OVERLAP_MIN_BYTES = 16 << 20
+PREDICT_CHUNK = 512                    # sequences per gt_predict call (workspace of one chunk is reused; C4: 3 GB)
 
 
 def _ptr(t):
@@ -42,31 +44,45 @@ class _Slot:
         self.hvo = torch.zeros(B, 32, 27, **f32)
         self.tgt = torch.zeros(B, 32, 27, **f32)
         self.stats = torch.zeros(8, **f32)
-        self.graph = None
         self.graphs = {}               # step recipe -> captured hipGraph
+        self.fwd_id = 0                # bumped by every call that overwrites the saved activations (see StepEngine.forward)
+
+
+class _LossSlot:
+    """Buffers of one calculate_loss call size (no activation workspace: an evaluation set of thousands of sequences only
+    needs its (N,32,27) predictions and targets here)."""
+
+    def __init__(self, eng, B):
+        f32 = dict(dtype=torch.float32, device=eng.device)
+        d = eng.dims
+        self.B = B
+        self.cfg = _lib.make_config(B, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
+                                    d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"])
+        self.hvo = torch.zeros(B, 32, 27, **f32)
+        self.y = torch.zeros(B, 32, 27, **f32)
+        self.stats = torch.zeros(8, **f32)
 
 
 class StepEngine:
     def __init__(self, d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_layers=0,
                  dropout=0.0, embedding_size_src=16, batch_size=None, optimizer="sgd", learning_rate=0.05,
                  hit_loss_penalty=1.0, seed=0, device="cuda", world_size=1, use_graph=True, lib=None):
-        if not torch.cuda.is_available():
+        self.device = torch.device(device)
+        # The only way onto host memory is an EXPLICITLY passed library object (tests hand in the host-emulator build of
+        # the same kernel sources to cover the multi-rank step sequence over gloo); nothing in the package does that.
+        self.on_host = self.device.type == "cpu"
+        if (self.on_host and lib is None) or (not self.on_host and not torch.cuda.is_available()):
             raise RuntimeError("StepEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback for the hot path")
         self.lib = lib or _lib.get_lib()
-        self.device = torch.device(device)
-        if self.device.index is None:
+        if not self.on_host and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.encoder_only = num_decoder_layers == 0
         self.algo = ALGO[optimizer.lower()]
         self.penalty = float(hit_loss_penalty)
         self.world_size = int(world_size)
         self.force_dp = False          # measurement aid: take the data-parallel step sequence even with one rank
-        # Two gradient buckets, the first all-reduced under the rest of backward.  Opt-in: splitting the step into two graphs
-        # costs ~90 us per step on one GPU (0.434 vs 0.344 ms at the C2 shape, bench.py --force-dp), more than a 2.4 MB
-        # all-reduce takes; it can only pay for models whose all-reduce is several hundred microseconds.
-        self.overlap_allreduce = os.environ.get("GT_DP_OVERLAP", "0") == "1"
-        self.use_graph = use_graph
+        self.use_graph = use_graph and not self.on_host
         self.dims = dict(d_model=int(d_model), n_heads=int(n_heads), dim_feedforward=int(dim_feedforward),
                          num_encoder_layers=int(num_encoder_layers), num_decoder_layers=int(num_decoder_layers),
                          dropout=float(dropout), embedding_size_src=int(embedding_size_src))
@@ -83,7 +99,16 @@ class StepEngine:
         st = _lib.GtStepState(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, 0, 0, learning_rate,
                               1.0 / self.world_size, 0.9, 0.999, 1e-8)
         self.state = torch.from_numpy(np.frombuffer(bytes(st), dtype=np.uint8).copy()).to(self.device)
+        # Two gradient buckets, the first all-reduced under the rest of backward.  Splitting the step into two graphs costs
+        # ~90 us per step on one GPU (0.434 vs 0.344 ms at the C2 shape, bench.py --force-dp), more than a 2.4 MB all-reduce
+        # takes, so it is chosen by gradient bytes: from 16 MB (C3 31.7 MB, C4 38 MB) the all-reduce is several hundred
+        # microseconds and worth hiding.  GT_DP_OVERLAP=0 / 1 forces it off / on.
+        env = os.environ.get("GT_DP_OVERLAP")
+        self.overlap_allreduce = (env == "1") if env in ("0", "1") else (4 * self.total >= OVERLAP_MIN_BYTES)
+        self.reduce_stats = True       # data-parallel: the logged 8-float stats are averaged over ranks (one tiny all-reduce)
         self._slots = {}
+        self._loss_slots = {}
+        self._predict_ws = {}          # chunk size -> (cfg, workspace, tgt scratch) of predict()
         self.B = int(batch_size) if batch_size else None
         if self.B:
             self.slot(self.B)
@@ -94,6 +119,16 @@ class StepEngine:
         if B not in self._slots:
             self._slots[B] = _Slot(self, B)
         return self._slots[B]
+
+    def loss_slot(self, B):
+        """Buffers for a stand-alone calculate_loss over B sequences (kept apart from the train slots: the loss of an
+        evaluation forward must not touch the activations a pending backward still needs)."""
+        B = int(B)
+        if B not in self._loss_slots:
+            if len(self._loss_slots) >= 4:
+                self._loss_slots.pop(next(iter(self._loss_slots)))
+            self._loss_slots[B] = _LossSlot(self, B)
+        return self._loss_slots[B]
 
     # convenience views of the default slot (bench / tests)
     x = property(lambda self: self.slot(self.B).x)
@@ -139,6 +174,8 @@ class StepEngine:
 
     @property
     def stream(self):
+        if self.on_host:
+            return ctypes.c_void_p(0)
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- the hot path ----------------------------------------------------------------------------
@@ -186,6 +223,7 @@ class StepEngine:
         """One optimisation step on (x, y) (device or host tensors; None = reuse the static buffers).
         Returns the device stats tensor [loss, hit_acc, -, bce, mse_v, mse_o, -, -] without syncing."""
         s = self.slot(x.shape[0] if x is not None else self.B)
+        s.fwd_id += 1
         if x is not None:
             s.x.copy_(x, non_blocking=True)
         if y is not None:
@@ -213,9 +251,21 @@ class StepEngine:
             self.enqueue_update()
         return s.stats
 
+    def forward_eval_chunked(self, x, tgt_in=None, chunk=PREDICT_CHUNK):
+        """Eval forward of a large set (the reference hands the whole test / validation set to the model at once,
+        ref:train.py:195-215) in chunks of `chunk` sequences through ONE reusable slot: the activation workspace of N = 4096
+        sequences would be 18.7 GiB at d512 / F2048.  Returns a fresh (N,32,27) tensor; no saved activations (not differentiable)."""
+        n = x.shape[0]
+        out = torch.empty(n, 32, 27, dtype=torch.float32, device=self.device)
+        for i in range(0, n, chunk):
+            j = min(n, i + chunk)
+            out[i:j].copy_(self.forward(x[i:j], None if tgt_in is None else tgt_in[i:j], train=False))
+        return out
+
     def forward(self, x, tgt_in=None, train=False):
         """Eval/train forward for any batch size -> (B,32,27) [h logits | v | o] buffer of that slot."""
         s = self.slot(x.shape[0])
+        s.fwd_id += 1
         s.x.copy_(x)
         if tgt_in is not None:
             s.tgt.copy_(tgt_in)
@@ -237,26 +287,46 @@ class StepEngine:
                       None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(d_hvo), _ptr(s.ws), _ptr(self.state),
                       int(train), int(accumulate), self.stream)
 
-    def predict(self, x, use_thres=True, thres=0.5):
+    def predict(self, x, use_thres=True, thres=0.5, chunk=PREDICT_CHUNK):
         """model.predict for ANY batch size (ref:evaluator.py:173 passes the whole evaluation set at once):
-        returns a (N,32,27) HVO tensor on the device ([h | v | o], one D2H for the evaluator)."""
+        returns a (N,32,27) HVO tensor on the device ([h | v | o], one D2H for the evaluator).  The set is walked in chunks
+        of `chunk` sequences over one cached workspace (sized for a chunk, not for N)."""
         x = torch.as_tensor(x, dtype=torch.float32).to(self.device).contiguous()
         n = x.shape[0]
         d = self.dims
-        cfg = _lib.make_config(n, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
-                               d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"])
-        ws = torch.empty(self.lib.workspace_floats(cfg), dtype=torch.float32, device=self.device)
         out = torch.empty(n, 32, 27, dtype=torch.float32, device=self.device)
-        tgt = torch.empty(n, 32, 27, dtype=torch.float32, device=self.device) if not self.encoder_only else None
-        self.lib.call("gt_predict", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x), _ptr(out),
-                      ctypes.c_float(thres), int(use_thres), _ptr(tgt), _ptr(ws), self.stream)
+        for i in range(0, n, chunk):
+            m = min(chunk, n - i)
+            if m not in self._predict_ws:
+                if len(self._predict_ws) >= 2:             # the full chunk + one remainder size at most
+                    self._predict_ws.pop(next(k for k in self._predict_ws if k != chunk), None)
+                cfg = _lib.make_config(m, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
+                                       d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"])
+                ws = torch.empty(self.lib.workspace_floats(cfg), dtype=torch.float32, device=self.device)
+                tgt = torch.empty(m, 32, 27, dtype=torch.float32, device=self.device) if not self.encoder_only else None
+                self._predict_ws[m] = (cfg, ws, tgt)
+            cfg, ws, tgt = self._predict_ws[m]
+            self.lib.call("gt_predict", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x[i:i + m]), _ptr(out[i:i + m]),
+                          ctypes.c_float(thres), int(use_thres), _ptr(tgt), _ptr(ws), self.stream)
         return out
+
+    def mean_stats(self, s):
+        """The slot's 8-float stats averaged over the data-parallel ranks (one tiny all-reduce; every rank must call it).
+        Single process: the stats tensor itself."""
+        if self.world_size == 1 or not self.reduce_stats:
+            return s.stats
+        import torch.distributed as dist
+        t = s.stats.clone()
+        dist.all_reduce(t)
+        return t / self.world_size
 
     def profile(self, steps):
         """Eager (no graph) pass of `steps` train steps with HIP events around every launch.
         -> {kernel class: (launches, total_ms, total_flops, total_bytes)}.  Measurement aid for bench.py."""
+        if self.on_host:
+            return {}
         s = self.slot(self.B)
-        snap = (self.params.clone(), self.state.clone())
+        snap = (self.params.clone(), self.state.clone(), None if self.m is None else (self.m.clone(), self.v.clone()))
         torch.cuda.synchronize(self.device)
         self.lib.cdll.gt_profile_enable(1)
         try:
@@ -267,6 +337,8 @@ class StepEngine:
         finally:
             self.lib.cdll.gt_profile_enable(0)
         self.params.copy_(snap[0]); self.state.copy_(snap[1]); self.grads.zero_()
+        if snap[2] is not None:
+            self.m.copy_(snap[2][0]); self.v.copy_(snap[2][1])
         out = {}
         for line in buf.value.decode().splitlines():
             lab, cnt, ms, fl, by = line.split()

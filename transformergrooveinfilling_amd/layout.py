@@ -47,3 +47,40 @@ def positional_encoding(d_model, max_len=32):
     pe[:, 0::2] = np.sin(pos * div)
     pe[:, 1::2] = np.cos(pos * div)
     return pe
+
+
+def init_params(dims, seed=0):
+    """{state-dict name: fp32 array}: torch-default-style initial weights from a seeded numpy generator, so every rank
+    (and every run) starts from the same replica without a broadcast.  Same distributions as
+    ``_GrooveBase.reset_parameters``: xavier-uniform packed in-proj, zero attention biases, U(+-1/sqrt(fan_in)) linears,
+    LayerNorm 1/0, IO layers U(+-0.1) with zero bias (ckpt: InputLayer weight range +-0.0995)."""
+    d, F = dims["d_model"], dims["dim_feedforward"]
+    r = np.random.default_rng(seed)
+    out = {}
+    for name, shape in param_names(d, F, dims["embedding_size_src"], dims["num_encoder_layers"], dims.get("num_decoder_layers", 0)):
+        if name.endswith("in_proj_weight"):
+            bnd = math.sqrt(6.0 / (shape[0] + shape[1]))
+            a = r.uniform(-bnd, bnd, shape)
+        elif name.startswith(("InputLayer", "OutputLayer")):
+            a = r.uniform(-0.1, 0.1, shape) if name.endswith("weight") else np.zeros(shape)
+        elif "norm" in name:
+            a = np.ones(shape) if name.endswith("weight") else np.zeros(shape)
+        elif name.endswith(("in_proj_bias", "out_proj.bias")):
+            a = np.zeros(shape)
+        elif name.endswith("weight"):
+            a = r.uniform(-1, 1, shape) / math.sqrt(shape[1])
+        else:
+            a = r.uniform(-1, 1, shape) / math.sqrt(d if "linear1" in name else F)
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def synthetic_batch(B, src_dim, seed=1234):
+    """SURVEY 8(d) synthetic HVO batch: x ~ U[0,1) (B,32,src_dim); hits ~ Bernoulli(0.15), velocities = U*h,
+    offsets = (U-0.5)*h -> y (B,32,27) = [h | v | o] (ref:utils.py:38-47 column order)."""
+    r = np.random.default_rng(seed)
+    x = r.random((B, 32, src_dim), dtype=np.float32)
+    h = (r.random((B, 32, 9), dtype=np.float32) < 0.15).astype(np.float32)
+    v = r.random((B, 32, 9), dtype=np.float32) * h
+    o = (r.random((B, 32, 9), dtype=np.float32) - 0.5) * h
+    return x, np.concatenate([h, v, o], -1)

@@ -9,7 +9,10 @@ Every parameter is a VIEW into the engine's flat HBM buffer (and ``.grad`` a vie
 buffer), so the fused kernels, the single RCCL all-reduce and ``wandb.watch``/``state_dict`` all see the same
 memory.  There is no CPU implementation: constructing a model without a ROCm GPU raises.
 """
+import collections
 import math
+import os
+import weakref
 
 import torch
 from torch import nn
@@ -36,6 +39,33 @@ def _attach(root, dotted, tensor, buffer=False):
     return m
 
 
+# predictions -> the engine (and slot stamp) that produced them, keyed by the storage of the (B,32,27) tensor forward returned
+# (h, v, o are views of it): calculate_loss finds ITS model's engine from the prediction, so two models in one process
+# (train + a second evaluator model) never compute each other's loss.  Bounded; entries are overwritten per forward.
+_PRODUCERS = collections.OrderedDict()
+
+
+def _register_producer(hvo, engine):
+    key = hvo.untyped_storage().data_ptr()
+    _PRODUCERS.pop(key, None)
+    _PRODUCERS[key] = weakref.ref(engine)
+    while len(_PRODUCERS) > 64:
+        _PRODUCERS.popitem(last=False)
+
+
+def engine_of(tensor):
+    """The StepEngine whose forward produced `tensor` (any view of its output), or None."""
+    ref = _PRODUCERS.get(tensor.untyped_storage().data_ptr())
+    return ref() if ref is not None else None
+
+
+def default_seed_hi():
+    """Data-parallel ranks must draw DIFFERENT dropout masks: the high seed word is the rank."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank()
+    return int(os.environ.get("RANK", "0"))
+
+
 class _GrooveFn(torch.autograd.Function):
     """autograd bridge: forward = gt_forward, backward = gt_backward accumulating into the flat .grad buffer."""
 
@@ -46,19 +76,33 @@ class _GrooveFn(torch.autograd.Function):
         if train:
             model._train_forwards += 1
             eng.set_step_async(model._train_forwards)      # fresh dropout masks per training forward
+        from .engine import PREDICT_CHUNK
+        if not train and src.shape[0] > PREDICT_CHUNK:
+            # evaluation sets come in one call (ref:train.py:195-215 test / validation inputs): chunked, nothing saved
+            ctx.slot = None
+            return eng.forward_eval_chunked(src, tgt)
         hvo = eng.forward(src, tgt, train)
         ctx.model, ctx.slot, ctx.train = model, eng.slot(src.shape[0]), train
+        ctx.fwd_id = ctx.slot.fwd_id
         return hvo.clone()
 
     @staticmethod
     def backward(ctx, d_hvo):
+        if ctx.slot is None:
+            raise RuntimeError("backward through a chunked evaluation forward (more than %d sequences in eval mode): "
+                               "no activations were saved" % d_hvo.shape[0])
+        if ctx.slot.fwd_id != ctx.fwd_id:
+            # the saved activations live in the per-batch-size workspace; a later forward / predict / train_step at the same
+            # batch size has overwritten them -- gradients from them would be silently wrong
+            raise RuntimeError("backward() after another forward at the same batch size (%d): the activations saved by this "
+                               "forward were overwritten; call backward before the next forward of that size" % ctx.slot.B)
         ctx.model.engine.backward(ctx.slot, d_hvo.contiguous(), ctx.train, accumulate=True)
         return None, None, None, None
 
 
 class _GrooveBase(nn.Module):
     def __init__(self, d_model, nhead, num_encoder_layers, num_decoder_layers, dim_feedforward, dropout,
-                 embedding_size_src, embedding_size_tgt, max_len, device):
+                 embedding_size_src, embedding_size_tgt, max_len, device, seed=0):
         super().__init__()
         if max_len != 32 or embedding_size_tgt != 27:
             raise ValueError("the HIP path is built for max_len=32 / embedding_size_tgt=27 (ref:train.py:128,132)")
@@ -66,8 +110,10 @@ class _GrooveBase(nn.Module):
         self.num_encoder_layers, self.num_decoder_layers = num_encoder_layers, num_decoder_layers
         self.embedding_size_src, self.embedding_size_tgt, self.max_len = embedding_size_src, embedding_size_tgt, max_len
         self.device = device if device is not None else "cuda"
+        # dropout stream: low word = the run's seed, high word = the data-parallel rank (ranks must not share masks)
         self.engine = StepEngine(d_model, nhead, dim_feedforward, num_encoder_layers, num_decoder_layers, dropout,
-                                 embedding_size_src, device=self.device)
+                                 embedding_size_src, device=self.device,
+                                 seed=(int(seed) & 0xFFFFFFFF) | (default_seed_hi() << 32))
         eng = self.engine
         grads = eng.views(eng.grads)
         for name, view in eng.views().items():
@@ -112,19 +158,24 @@ class _GrooveBase(nn.Module):
         if tgt is not None:
             tgt = tgt.to(self.engine.device, torch.float32)
         hvo = _GrooveFn.apply(self._hook, self, src, tgt)
-        from . import training
-        training.calculate_loss._engine = self.engine          # the loss of these predictions runs on this engine
+        _register_producer(hvo, self.engine)                   # calculate_loss(prediction, ...) runs on the engine that made it
         n = self.embedding_size_tgt // 3
         return hvo[..., :n], hvo[..., n:2 * n], hvo[..., 2 * n:]
 
     def predict(self, src, use_thres=True, thres=0.5, use_pd=False):
         """eval-mode, no-grad inference (ref:evaluator.py:173): h thresholded to {0,1} (or probabilities)."""
-        if use_pd:
-            raise NotImplementedError("use_pd (sampling hits from the probability) is not part of the HIP path")
         self.eval()
+        n = self.embedding_size_tgt // 3
+        if use_pd:
+            # hits sampled from the predicted probability: h = 1 iff p > U[0,1) drawn per (step, voice)
+            if self.num_decoder_layers:
+                raise NotImplementedError("use_pd with the encoder-decoder's greedy decode is not part of the HIP path")
+            with torch.no_grad():
+                hvo = self.engine.predict(src, use_thres=False)
+                hvo[..., :n] = (hvo[..., :n] > torch.rand_like(hvo[..., :n])).float()
+            return hvo[..., :n], hvo[..., n:2 * n], hvo[..., 2 * n:]
         with torch.no_grad():
             hvo = self.engine.predict(src, use_thres=use_thres, thres=thres)
-        n = self.embedding_size_tgt // 3
         return hvo[..., :n], hvo[..., n:2 * n], hvo[..., 2 * n:]
 
     def predict_hvo(self, src, use_thres=True, thres=0.5):
@@ -138,9 +189,9 @@ class GrooveTransformerEncoder(_GrooveBase):
     """encoder_only = 1 (every shipped YAML: ref:configs/*_training.yaml:11)."""
 
     def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, dim_feedforward=2048, dropout=0.1,
-                 embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None):
+                 embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None, seed=0):
         super().__init__(d_model, nhead, num_encoder_layers, 0, dim_feedforward, dropout, embedding_size_src,
-                         embedding_size_tgt, max_len, device)
+                         embedding_size_tgt, max_len, device, seed)
 
     def forward(self, src):
         return self._run(src, None)
@@ -150,9 +201,9 @@ class GrooveTransformer(_GrooveBase):
     """encoder-decoder (encoder_only = 0, ref:train.py:125-127); tgt = y shifted right by one step."""
 
     def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
-                 dropout=0.1, embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None):
+                 dropout=0.1, embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None, seed=0):
         super().__init__(d_model, nhead, num_encoder_layers, num_decoder_layers, dim_feedforward, dropout,
-                         embedding_size_src, embedding_size_tgt, max_len, device)
+                         embedding_size_src, embedding_size_tgt, max_len, device, seed)
 
     def forward(self, src, tgt):
         return self._run(src, tgt)

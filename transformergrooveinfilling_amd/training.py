@@ -13,7 +13,7 @@ import re
 
 import torch
 
-from .model import GrooveTransformer, GrooveTransformerEncoder, _GrooveBase
+from .model import GrooveTransformer, GrooveTransformerEncoder, _GrooveBase, engine_of
 
 try:                                    # Weights & Biases is optional here (ref:train.py:106-113,150,252)
     import wandb
@@ -104,8 +104,14 @@ FILE_PATTERN = "transformer_run_{}_Epoch_{}.Model"
 
 
 def save_checkpoint(path, epoch, model, optimizer, loss):
-    torch.save({"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                "optimizer_state_dict": optimizer.state_dict(), "loss": float(loss)}, path)
+    """The reference's four keys (ckpt) plus ``dropout_step``: the position of this replica's dropout stream, so a resumed
+    run continues with fresh masks instead of replaying the ones of step 0 (readers of the reference format ignore it)."""
+    ck = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+          "optimizer_state_dict": optimizer.state_dict(), "loss": float(loss)}
+    eng = getattr(model, "engine", None)
+    if eng is not None:
+        ck["dropout_step"] = max(int(eng.state_struct().step), int(getattr(model, "_train_forwards", 0)))
+    torch.save(ck, path)
     return path
 
 
@@ -143,7 +149,8 @@ def initialize_model(params):
     mp, tp = params["model"], params["training"]
     common = dict(d_model=mp["d_model"], nhead=mp["n_heads"], dim_feedforward=mp["dim_feedforward"],
                   dropout=mp["dropout"], embedding_size_src=mp["embedding_size_src"],
-                  embedding_size_tgt=mp["embedding_size_tgt"], max_len=mp["max_len"], device=mp.get("device", "cuda"))
+                  embedding_size_tgt=mp["embedding_size_tgt"], max_len=mp["max_len"], device=mp.get("device", "cuda"),
+                  seed=int(params.get("seed", tp.get("seed", 0)) or 0))      # dropout stream (train.py --seed); rank mixed in by the model
     if mp["encoder_only"]:
         model = GrooveTransformerEncoder(num_encoder_layers=mp["num_encoder_layers"], **common)
     else:
@@ -167,6 +174,11 @@ def initialize_model(params):
         optimizer.load_state_dict(ck["optimizer_state_dict"])
         optimizer._lr_on_device = None
         initial_epoch = int(ck["epoch"]) + 1          # resume after the stored epoch (payload, not file name: SURVEY 5)
+        # continue the dropout stream where the stored run stopped (a reference-written checkpoint has no position: start
+        # far from the masks of the first epochs)
+        step = int(ck.get("dropout_step", initial_epoch << 20)) & 0x7FFFFFFF
+        model.engine.set_state(step=step)
+        model._train_forwards = step
     return model, optimizer, initial_epoch
 
 
@@ -176,7 +188,7 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hvo, y, penalty, engine):
-        s = engine.slot(hvo.shape[0])
+        s = engine.loss_slot(hvo.shape[0])
         s.hvo.copy_(hvo)
         stats, d_hvo = engine.loss(s, y, penalty, want_grad=True)
         ctx.save_for_backward(d_hvo)
@@ -198,13 +210,15 @@ def calculate_loss(prediction, y, bce_fn, mse_fn, hit_loss_penalty):
     h, v, o = prediction
     if not h.is_cuda:
         raise RuntimeError("calculate_loss runs on the GPU path only (predictions must be CUDA tensors)")
-    engine = calculate_loss._engine
+    # the engine that produced these predictions (model._run registers its output); predictions built elsewhere fall back to
+    # the engine of the last initialised model
+    engine = engine_of(h) or calculate_loss._engine
     if engine is None:
         raise RuntimeError("no model initialised: call initialize_model() (or bind calculate_loss._engine) first")
     hvo = torch.cat([h, v, o], dim=-1).contiguous()
     y = y.to(hvo.device, torch.float32)
     loss = _LossFn.apply(hvo, y, float(hit_loss_penalty), engine)
-    st = engine.slot(hvo.shape[0]).stats.tolist()            # ONE D2H of the stats struct (no 5-6 .item() syncs)
+    st = engine.loss_slot(hvo.shape[0]).stats.tolist()       # ONE D2H of the stats struct (no 5-6 .item() syncs)
     return loss, st[1], math.exp(st[3]), st[3], st[4], st[5]
 
 
@@ -257,14 +271,16 @@ def train_loop(dataloader, groove_transformer, encoder_only, opt, epoch, loss_fn
     world = 1
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         world = torch.distributed.get_world_size()
+    fused_opt = isinstance(opt, _FusedMixin) and opt.engine is eng
+    if eng is not None and eng.world_size != world:
+        eng.world_size = world
+    if fused_opt:                              # the fused update averages by grad_scale on the device: keep it = 1/world on BOTH paths
+        eng.set_state(grad_scale=1.0 / world)
     if fast:
         eng.grads.zero_()                      # gt_train_step precondition; every fused update re-zeroes them
         eng.penalty = float(hit_loss_penalty)
         eng.algo = opt._algo
         opt._push_lr()
-        if eng.world_size != world:
-            eng.world_size = world
-            eng.set_state(grad_scale=1.0 / world)
     last, stats = None, None
     n_batches = 0
     for batch, (X, y, _idx) in enumerate(dataloader):
@@ -274,16 +290,21 @@ def train_loop(dataloader, groove_transformer, encoder_only, opt, epoch, loss_fn
         if fast:
             stats = eng.train_step(X, y)
             if (batch + 1) % log_every == 0:
-                last = _metrics_dict("train/", stats.tolist())
+                last = _metrics_dict("train/", eng.mean_stats(eng.slot(X.shape[0])).tolist())
         else:
             opt.zero_grad()
             pred = model(X) if encoder_only else model(X, shift_right(y))
             out = loss_fn(pred, y, bce_fn, mse_fn, hit_loss_penalty)
             out[0].backward()
             if world > 1:
-                for p in model.parameters():
-                    torch.distributed.all_reduce(p.grad)
-                    p.grad /= world
+                if eng is not None:            # every .grad is a view of ONE flat buffer: one collective, not one per tensor
+                    torch.distributed.all_reduce(eng.grads)
+                    if not fused_opt:          # a foreign optimizer knows nothing of grad_scale: average here
+                        eng.grads /= world
+                else:
+                    for p in model.parameters():
+                        torch.distributed.all_reduce(p.grad)
+                        p.grad /= world
             opt.step()
             last = {"train/loss": float(out[0]), "train/hit_accuracy": out[1], "train/hit_perplexity": out[2],
                     "train/bce_h": out[3], "train/mse_v": out[4], "train/mse_o": out[5]}
@@ -294,7 +315,7 @@ def train_loop(dataloader, groove_transformer, encoder_only, opt, epoch, loss_fn
             if on_log:
                 on_log(rec)
     if fast and stats is not None:
-        last = _metrics_dict("train/", stats.tolist())
+        last = _metrics_dict("train/", eng.mean_stats(eng.slot(X.shape[0])).tolist())
     if isinstance(opt, GrooveAdam) and fast:
         for st in opt.state.values():
             st["step"] += n_batches
