@@ -47,6 +47,11 @@ typedef struct gt_config {
   int32_t n_enc_layers;
   int32_t n_dec_layers;   /* 0 = encoder_only (ref:train.py:125-127) */
   float dropout;
+  int32_t precision;      /* 0 = fp32 everywhere (the parity path).  1 = BASELINE configs[4]: the operands of every Linear's
+                           * forward / dgrad / wgrad GEMM are rounded to bf16 (round-to-nearest-even) on their way into the
+                           * matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulate); master weights, activations in HBM,
+                           * attention core, LayerNorm, softmax, loss and optimizer stay fp32.  Bias gradients are column sums
+                           * of the bf16-rounded output gradient. */
 } gt_config;
 
 /* device-resident per-step state, so that a captured hipGraph replays with fresh dropout masks,

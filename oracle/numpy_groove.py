@@ -116,6 +116,44 @@ def positional_encoding(d, max_len=T, dtype=np.float32):
     return pe.astype(dtype)
 
 
+# ---- bf16 operand mode (gt_config.precision = 1; BASELINE configs[4]) ---------------------------------------------------
+# Every Linear's forward / dgrad / wgrad matmul takes its two operands rounded to bf16 (round to nearest even, from their
+# fp32 values -- the device converts fp32 tensors on the way into the matrix cores) and accumulates exactly (fp32 on the
+# device, the oracle's dtype here); bias gradients are column sums of the ROUNDED output gradient (the device sums the
+# staged bf16 slab).  Attention core, LayerNorm, softmax, loss, optimizer: unchanged.  cfg["precision"] switches it on.
+_BF16 = [False]
+
+
+def round_bf16(a):
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32).astype(np.uint64)
+    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)) << np.uint64(16)
+    return r.astype(np.uint32).view(np.float32).astype(np.asarray(a).dtype).reshape(np.shape(a))
+
+
+def _mm(a, b):
+    """a @ b of a Linear (forward, dgrad or wgrad)."""
+    if _BF16[0]:
+        return round_bf16(a) @ round_bf16(b)
+    return a @ b
+
+
+def _cs(dy):
+    """bias gradient: column sums of the output gradient."""
+    return (round_bf16(dy) if _BF16[0] else dy).sum(0)
+
+
+class _precision:
+    def __init__(self, cfg):
+        self.on = bool(cfg.get("precision", 0))
+
+    def __enter__(self):
+        self.prev, _BF16[0] = _BF16[0], self.on
+
+    def __exit__(self, *a):
+        _BF16[0] = self.prev
+
+
 # ---- primitive ops ---------------------------------------------------------------------------
 def _ln_fwd(z, g, b, eps=1e-5):
     mu = z.mean(-1, keepdims=True)
@@ -144,9 +182,9 @@ def _attn_fwd(q_in, kv_in, Win, bin_, Wo, bo, H, causal, rng, site, p):
     """q_in (M,d) supplies queries, kv_in (M,d) keys/values.  Returns out (M,d) and cache."""
     M, d = q_in.shape
     B, hd = M // T, d // H
-    q = q_in @ Win[:d].T + bin_[:d]
-    k = kv_in @ Win[d:2 * d].T + bin_[d:2 * d]
-    v = kv_in @ Win[2 * d:].T + bin_[2 * d:]
+    q = _mm(q_in, Win[:d].T) + bin_[:d]
+    k = _mm(kv_in, Win[d:2 * d].T) + bin_[d:2 * d]
+    v = _mm(kv_in, Win[2 * d:].T) + bin_[2 * d:]
     qh = q.reshape(B, T, H, hd).transpose(0, 2, 1, 3)
     kh = k.reshape(B, T, H, hd).transpose(0, 2, 1, 3)
     vh = v.reshape(B, T, H, hd).transpose(0, 2, 1, 3)
@@ -158,7 +196,7 @@ def _attn_fwd(q_in, kv_in, Win, bin_, Wo, bo, H, causal, rng, site, p):
     P = E / E.sum(-1, keepdims=True)                      # (B,H,T,T); idx = ((b*H+h)*T+i)*T+j
     Pd, mask = _drop(P, rng, site, p)
     ctx = (Pd @ vh).transpose(0, 2, 1, 3).reshape(M, d)
-    out = ctx @ Wo.T + bo
+    out = _mm(ctx, Wo.T) + bo
     return out, dict(q_in=q_in, kv_in=kv_in, qh=qh, kh=kh, vh=vh, P=P, Pd=Pd, mask=mask, ctx=ctx,
                      q=q, k=k, v=v)
 
@@ -168,9 +206,9 @@ def _attn_bwd(dout, c, Win, Wo, H):
     B, hd = M // T, d // H
     scale = dout.dtype.type(1.0 / math.sqrt(hd))
     g = {}
-    g["out_w"] = dout.T @ c["ctx"]
-    g["out_b"] = dout.sum(0)
-    dctx = dout @ Wo
+    g["out_w"] = _mm(dout.T, c["ctx"])
+    g["out_b"] = _cs(dout)
+    dctx = _mm(dout, Wo)
     dch = dctx.reshape(B, T, H, hd).transpose(0, 2, 1, 3)
     dPd = dch @ c["vh"].transpose(0, 1, 3, 2)
     dvh = c["Pd"].transpose(0, 1, 3, 2) @ dch
@@ -182,16 +220,16 @@ def _attn_bwd(dout, c, Win, Wo, H):
     dq = dqh.transpose(0, 2, 1, 3).reshape(M, d)
     dk = dkh.transpose(0, 2, 1, 3).reshape(M, d)
     dv = dvh.transpose(0, 2, 1, 3).reshape(M, d)
-    dW = np.concatenate([dq.T @ c["q_in"], dk.T @ c["kv_in"], dv.T @ c["kv_in"]], 0)
-    db = np.concatenate([dq.sum(0), dk.sum(0), dv.sum(0)])
+    dW = np.concatenate([_mm(dq.T, c["q_in"]), _mm(dk.T, c["kv_in"]), _mm(dv.T, c["kv_in"])], 0)
+    db = np.concatenate([_cs(dq), _cs(dk), _cs(dv)])
     g["in_w"], g["in_b"] = dW, db
-    d_q_in = dq @ Win[:d]
-    d_kv_in = dk @ Win[d:2 * d] + dv @ Win[2 * d:]
+    d_q_in = _mm(dq, Win[:d])
+    d_kv_in = _mm(dk, Win[d:2 * d]) + _mm(dv, Win[2 * d:])
     return d_q_in, d_kv_in, g, dict(dq=dq, dk=dk, dv=dv, dctx=dctx)
 
 
 def _input_fwd(x, W, b, pe, rng, site, p):
-    a = x @ W.T + b
+    a = _mm(x, W.T) + b
     r = np.maximum(a, 0)
     e = r + np.tile(pe, (x.shape[0] // T, 1))
     out, mask = _drop(e, rng, site, p)
@@ -201,11 +239,16 @@ def _input_fwd(x, W, b, pe, rng, site, p):
 def _input_bwd(dout, c):
     de = dout * c["mask"] if c["mask"] is not None else dout
     da = de * (c["a"] > 0)
-    return da.T @ c["x"], da.sum(0)
+    return _mm(da.T, c["x"]), _cs(da)
 
 
 # ---- model ------------------------------------------------------------------------------------
 def forward(P, cfg, x, tgt=None, rng=None, dtype=np.float32):
+    with _precision(cfg):
+        return _forward(P, cfg, x, tgt, rng, dtype)
+
+
+def _forward(P, cfg, x, tgt=None, rng=None, dtype=np.float32):
     """P: dict name->array.  x (B,T,S); tgt (B,T,27) for the encoder-decoder.  rng=(lo,hi,step)
     enables dropout with p=cfg['dropout'].  Returns (h,v,o) each (B,T,9) and the cache."""
     P = {k: np.asarray(v, dtype) for k, v in P.items()}
@@ -228,10 +271,10 @@ def forward(P, cfg, x, tgt=None, rng=None, dtype=np.float32):
         ao, c["m1"] = _drop(ao, rng, layer_site(l, S_DROP1), p)
         x1, c["xhat1"], c["rstd1"] = _ln_fwd(xcur + ao, P[n + "norm1.weight"], P[n + "norm1.bias"])
         c["x1"] = x1
-        c["hpre"] = x1 @ P[n + "linear1.weight"].T + P[n + "linear1.bias"]
+        c["hpre"] = _mm(x1, P[n + "linear1.weight"].T) + P[n + "linear1.bias"]
         hact, c["mf"] = _drop(np.maximum(c["hpre"], 0), rng, layer_site(l, S_FFN), p)
         c["hact"] = hact
-        f = hact @ P[n + "linear2.weight"].T + P[n + "linear2.bias"]
+        f = _mm(hact, P[n + "linear2.weight"].T) + P[n + "linear2.bias"]
         f, c["m2"] = _drop(f, rng, layer_site(l, S_DROPF), p)
         xcur, c["xhat2"], c["rstd2"] = _ln_fwd(x1 + f, P[n + "norm2.weight"], P[n + "norm2.bias"])
         c["x_out"] = xcur
@@ -258,17 +301,17 @@ def forward(P, cfg, x, tgt=None, rng=None, dtype=np.float32):
             ca, c["mx"] = _drop(ca, rng, layer_site(gl, S_DROP2), p)
             y2, c["xhatx"], c["rstdx"] = _ln_fwd(y1 + ca, P[n + "norm2.weight"], P[n + "norm2.bias"])
             c["x2"] = y2
-            c["hpre"] = y2 @ P[n + "linear1.weight"].T + P[n + "linear1.bias"]
+            c["hpre"] = _mm(y2, P[n + "linear1.weight"].T) + P[n + "linear1.bias"]
             hact, c["mf"] = _drop(np.maximum(c["hpre"], 0), rng, layer_site(gl, S_FFN), p)
             c["hact"] = hact
-            f = hact @ P[n + "linear2.weight"].T + P[n + "linear2.bias"]
+            f = _mm(hact, P[n + "linear2.weight"].T) + P[n + "linear2.bias"]
             f, c["m2"] = _drop(f, rng, layer_site(gl, S_DROPF), p)
             ycur, c["xhat2"], c["rstd2"] = _ln_fwd(y2 + f, P[n + "norm3.weight"], P[n + "norm3.bias"])
             c["x_out"] = ycur
             C["dec"].append(c)
         final, C["dec_xhat"], C["dec_rstd"] = _ln_fwd(ycur, P["Decoder.Decoder.norm.weight"], P["Decoder.Decoder.norm.bias"])
     C["final"] = final
-    logits = final @ P["OutputLayer.Linear.weight"].T + P["OutputLayer.Linear.bias"]
+    logits = _mm(final, P["OutputLayer.Linear.weight"].T) + P["OutputLayer.Linear.bias"]
     C["logits"] = logits
     h = logits[:, :NV]
     v = 1.0 / (1.0 + np.exp(-logits[:, NV:2 * NV]))
@@ -302,16 +345,21 @@ def calculate_loss(pred, y, penalty):
 def _ffn_bwd(dz, c, W1, W2, xin):
     """dz: grad of the pre-LN sum (residual + dropped ffn out).  Returns dx_in_from_ffn, grads."""
     df = dz * c["m2"] if c["m2"] is not None else dz
-    g = {"w2": df.T @ c["hact"], "b2": df.sum(0)}
-    dh = df @ W2
+    g = {"w2": _mm(df.T, c["hact"]), "b2": _cs(df)}
+    dh = _mm(df, W2)
     if c["mf"] is not None:
         dh = dh * c["mf"]
     dh = dh * (c["hpre"] > 0)
-    g["w1"], g["b1"] = dh.T @ xin, dh.sum(0)
-    return dh @ W1, g, dict(dhid=dh)
+    g["w1"], g["b1"] = _mm(dh.T, xin), _cs(dh)
+    return _mm(dh, W1), g, dict(dhid=dh)
 
 
 def backward(P, cfg, C, dpred, dtype=np.float32):
+    with _precision(cfg):
+        return _backward(P, cfg, C, dpred, dtype)
+
+
+def _backward(P, cfg, C, dpred, dtype=np.float32):
     """Manual backward of ``forward``.  dpred = (dh, dv, do).  Returns dict name->grad."""
     P = {k: np.asarray(v, dtype) for k, v in P.items()}
     H = cfg["n_heads"]
@@ -321,9 +369,9 @@ def backward(P, cfg, C, dpred, dtype=np.float32):
     v, o = C["v"], C["o"]
     dlog = np.concatenate([dh, dv * v * (1 - v), do * (0.5 - 2 * o * o)], 1)
     C["dlogits"] = dlog
-    G["OutputLayer.Linear.weight"] = dlog.T @ C["final"]
-    G["OutputLayer.Linear.bias"] = dlog.sum(0)
-    dfin = dlog @ P["OutputLayer.Linear.weight"]
+    G["OutputLayer.Linear.weight"] = _mm(dlog.T, C["final"])
+    G["OutputLayer.Linear.bias"] = _cs(dlog)
+    dfin = _mm(dlog, P["OutputLayer.Linear.weight"])
     dmem = 0.0
     if Ld:
         dy, G["Decoder.Decoder.norm.weight"], G["Decoder.Decoder.norm.bias"] = \

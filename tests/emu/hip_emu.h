@@ -29,6 +29,7 @@ struct dim3 {
 };
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
+struct uint2 { uint32_t x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 typedef float f32x4 __attribute__((vector_size(16)));
 typedef int hipStream_t_dummy;
@@ -70,6 +71,16 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 static inline void __threadfence() {}
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #define GT_MFMA16(a, b, c) emu::mfma16((a), (b), (c))
+// bf16 operands (gt_config.precision = 1): 8 bf16 per lane, fp32 accumulate
+struct bf16x8 { uint16_t v[8]; };
+namespace emu { f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c); }
+#define GT_MFMA16_BF16(a, b, c) emu::mfma16_bf16((a), (b), (c))
+static inline uint16_t gt_f2bf(float f) {          // round to nearest even; NaN stays NaN (what v_cvt_pk_bf16_f32 does)
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
 
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
@@ -188,6 +199,31 @@ f32x4 mfma16(float a, float b, f32x4 c) {
     float acc = c[r];
     for (int k = 0; k < 4; ++k) acc = fmaf(scratchA[w][row + 16 * k], scratchB[w][col + 16 * k], acc);
     c[r] = acc;
+  }
+  wave_sync();
+  return c;
+}
+
+// v_mfma_f32_16x16x32_bf16: A[i=l&15][k=8(l>>4)+j], B[k=8(l>>4)+j][col l&15]; products of two bf16 are exact in fp32, the
+// 32-term sum is taken in double and rounded once (the hardware's internal accumulation order is not specified: tests
+// compare within a tolerance)
+static uint16_t scratchHA[16][64][8], scratchHB[16][64][8];
+f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  int w = cur / 64, l = cur % 64;
+  for (int j = 0; j < 8; ++j) { scratchHA[w][l][j] = a.v[j]; scratchHB[w][l][j] = b.v[j]; }
+  wave_sync();
+  int col = l & 15, g = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * g + r;
+    double acc = c[r];
+    for (int kg = 0; kg < 4; ++kg)
+      for (int j = 0; j < 8; ++j) {
+        uint32_t ua = (uint32_t)scratchHA[w][row + 16 * kg][j] << 16, ub = (uint32_t)scratchHB[w][col + 16 * kg][j] << 16;
+        float fa, fb;
+        memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+        acc += (double)fa * (double)fb;
+      }
+    c[r] = (float)acc;
   }
   wave_sync();
   return c;

@@ -46,10 +46,13 @@ class CudaBuf:
 
 
 def cfg_dict(d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_layers=0, embedding_size_src=16,
-             dropout=0.0):
-    return dict(d_model=d_model, n_heads=n_heads, dim_feedforward=dim_feedforward,
-                num_encoder_layers=num_encoder_layers, num_decoder_layers=num_decoder_layers,
-                embedding_size_src=embedding_size_src, dropout=dropout)
+             dropout=0.0, precision=0):
+    d = dict(d_model=d_model, n_heads=n_heads, dim_feedforward=dim_feedforward,
+             num_encoder_layers=num_encoder_layers, num_decoder_layers=num_decoder_layers,
+             embedding_size_src=embedding_size_src, dropout=dropout)
+    if precision:
+        d["precision"] = precision                 # 1 = bf16 GEMM operands (gt_config.precision)
+    return d
 
 
 class Runner:
@@ -61,7 +64,8 @@ class Runner:
         self.lib.cdll.gt_set_chain(int(chain))          # process-global switch: fused row-chain kernels on / off
         self.Buf = NpBuf if backend == "emu" else CudaBuf
         self.c = _lib.make_config(B, cfg["embedding_size_src"], cfg["d_model"], cfg["n_heads"], cfg["dim_feedforward"],
-                                  cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0), cfg.get("dropout", 0.0))
+                                  cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0), cfg.get("dropout", 0.0),
+                                  cfg.get("precision", 0))
         self.total, self.entries = self.lib.param_layout(self.c)
         self.names = layout.param_names(cfg["d_model"], cfg["dim_feedforward"], cfg["embedding_size_src"],
                                         cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0))

@@ -63,3 +63,22 @@ def test_demo_checkpoint():
                                         (cfg_dict(32, 4, 16, 1), 2, 0.1, 1)])
 def test_bucketed_backward(cfg, B, p, nb):
     parity.check_bucketed_backward("emu", cfg, B, p, nb, exact=True)
+
+
+# ---- bf16 operand path (gt_config.precision = 1) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 2, 0.0), (ENCDEC, 3, 0.25), (cfg_dict(64, 16, 64, 2, embedding_size_src=27), 3, 0.1),
+                                     (cfg_dict(128, 4, 48, 1), 1, 0.2), (cfg_dict(48, 3, 40, 1, 1), 2, 0.0)])
+def test_step_parity_bf16_operands(cfg, B, p):
+    parity.check_step_bf16("emu", cfg, B, p)
+
+
+def test_train_step_bf16_operands():
+    parity.check_train_step_bf16("emu", ENC, 2, 0.2)
+
+
+def test_bucketed_backward_bf16_operands():
+    parity.check_bucketed_backward("emu", dict(ENC, precision=1), 2, 0.25, 2, exact=True)
+
+
+def test_predict_bf16_operands():
+    parity.check_predict("emu", dict(ENCDEC, precision=1), 2, True, out_tol=1e-2, margin_tol=5e-3)

@@ -104,9 +104,11 @@ def test_train_loop_fast_path_checkpoint_and_resume(tmp_path):
     assert ck.exists()
     payload = torch.load(ck, weights_only=True)
     assert set(payload) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"} and payload["epoch"] == 2
+    assert payload["optimizer_state_dict"]["param_groups"][0]["dropout_step"] == 3 * 8       # position of the dropout stream
     lm = {"location": "local", "dir": str(tmp_path), "file_pattern": "transformer_run_{}_Epoch_{}.Model", "run": "abc"}
     model2, opt2, ep1 = initialize_model(dict(p, load_model=lm))
     assert ep1 == 3
+    assert model2.engine.state_struct().step == 3 * 8                                       # resumed, not replayed from step 0
     for (n, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert torch.equal(a, b), n
     h, v, o = model2.predict(x[:10].cuda())

@@ -85,7 +85,9 @@ def test_predict(cfg, B, use_thres):
 # ---- properties at full size (BASELINE configs[1]: d128/H4/F512/L3, bs 64, dropout 0.24) ---------------
 FULL_SIZES = [(C2, 64, 0.24, 0.07),                                                      # BASELINE configs[1]
               (cfg_dict(256, 2, 512, 6, 6), 256, 0.3, 0.02),                              # configs[2]: full encoder-decoder, bs 256
-              (cfg_dict(512, 8, 512, 6), 64, 0.3, 0.02)]                                  # configs[3]: d512 / 8 heads / 6 layers, 64 per GPU
+              (cfg_dict(512, 8, 512, 6), 64, 0.3, 0.02),                                  # configs[3]: d512 / 8 heads / 6 layers, 64 per GPU
+              (cfg_dict(512, 8, 512, 6, embedding_size_src=27, precision=1), 64, 0.24, 0.02),   # configs[4]: symbolic input, bf16 operands
+              (cfg_dict(512, 8, 512, 6, precision=1), 64, 0.24, 0.02)]                    # configs[4]: audio (MSO) input, bf16 operands
 
 
 @pytest.mark.parametrize("cfg0,B,p,lr", FULL_SIZES)
@@ -94,7 +96,7 @@ def test_full_size_properties(cfg0, B, p, lr):
     cfg = dict(cfg0, dropout=p)
     dec = cfg.get("num_decoder_layers", 0) > 0
     P = ng.init_params(cfg, seed=0)
-    x, y = ng.synthetic_batch(B, 16, seed=1234)
+    x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=1234)
     tgt = parity.shift_right(y) if dec else None
     r = Runner(cfg, B, "hip", rng=(5, 6, 0), lr=lr)
     r.set_params(P)
@@ -118,6 +120,7 @@ def test_full_size_properties(cfg0, B, p, lr):
     g1 = r.backward(d_hvo=d)
     g2 = r.backward(d_hvo=2.0 * d)
     for k in g1:
+        # (bf16 operands: 2 x is exact in bf16, so the rounded operands scale exactly too; only fp32 accumulation differs)
         assert parity.rel_err(g2[k], 2.0 * g1[k]) < 1e-5, k
     # (6) train-mode dropout: same (seed, step) -> same masks; next step -> different masks, same keep rate
     t0 = r.forward(x, tgt, train=True)
@@ -134,6 +137,39 @@ def test_full_size_properties(cfg0, B, p, lr):
     losses = [r.train_step(x, y, 0.38)[0] for _ in range(20)]
     assert losses[-1] < losses[0]
     assert np.isfinite(r.params.numpy()).all()
+
+
+# ---- bf16 operand path (gt_config.precision = 1; BASELINE configs[4]: InfillingClosedHH_Symbolic (S=27) vs audio input (S=16),
+# d_model 512 / 8 heads / F 512).  Bars and their derivation: parity.check_step_bf16 ------------------------------------------
+C5_SYM = cfg_dict(512, 8, 512, 2, embedding_size_src=27)     # layers reduced for oracle time; 6 layers in FULL_SIZES above
+C5_MSO = cfg_dict(512, 8, 512, 2)
+
+
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 2, 0.0), (ENCDEC, 3, 0.25), (SYM, 3, 0.1), (C2, 8, 0.24), (C5_SYM, 4, 0.24), (C5_MSO, 3, 0.0),
+                                     (C3, 3, 0.3), (cfg_dict(48, 3, 40, 1, 1), 2, 0.0)])
+def test_step_parity_bf16_operands(cfg, B, p):
+    parity.check_step_bf16("hip", cfg, B, p)
+
+
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(512, 8, 512, 1, embedding_size_src=27), 256, 0.24), (cfg_dict(128, 4, 512, 1), 256, 0.24),
+                                     (cfg_dict(256, 2, 512, 1, 1), 256, 0.1)])
+def test_step_parity_bf16_operands_large_batches(cfg, B, p):
+    """8192 tokens: 128x128 / 64x64 bf16 tiles and the 64- and 128-tile weight-gradient groups"""
+    parity.check_step_bf16("hip", cfg, B, p)
+
+
+def test_train_step_bf16_operands():
+    parity.check_train_step_bf16("hip", ENC, 4, 0.2)
+    parity.check_train_step_bf16("hip", cfg_dict(128, 4, 512, 2), 8, 0.24)
+
+
+def test_bucketed_backward_bf16_operands():
+    parity.check_bucketed_backward("hip", dict(C2, precision=1), 16, 0.24, 2, exact=False)
+
+
+def test_predict_bf16_operands():
+    parity.check_predict("hip", dict(C2, precision=1), 16, True, out_tol=1e-2, margin_tol=5e-3)
+    parity.check_predict("hip", dict(ENCDEC, precision=1), 4, True, out_tol=1e-2, margin_tol=5e-3)
 
 
 def test_errors_are_reported():

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from oracle import numpy_groove as ng  # noqa: E402
+from transformergrooveinfilling_amd import layout as ng  # noqa: E402
 from transformergrooveinfilling_amd.engine import StepEngine  # noqa: E402
 
 SHAPES = [

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from oracle import numpy_groove as ng  # noqa: E402
+from transformergrooveinfilling_amd import layout  # noqa: E402
 from transformergrooveinfilling_amd.engine import StepEngine  # noqa: E402
 
 SHAPES = [
@@ -38,8 +38,8 @@ def main():
             continue
         dims = dict(dict(embedding_size_src=16), **dims)
         eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=1, use_graph=not args.no_graph, **dims)
-        eng.load_named(ng.init_params(dims, seed=0))
-        x, y = ng.synthetic_batch(B, dims["embedding_size_src"], seed=2)
+        eng.load_named(layout.init_params(dims, seed=0))
+        x, y = layout.synthetic_batch(B, dims["embedding_size_src"], seed=2)
         eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))
         for _ in range(args.warmup):
             eng.train_step()

@@ -18,7 +18,7 @@ GT_VOICES = 9
 class GtConfig(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int32), ("src_dim", ctypes.c_int32), ("d_model", ctypes.c_int32),
                 ("n_heads", ctypes.c_int32), ("dim_ff", ctypes.c_int32), ("n_enc_layers", ctypes.c_int32),
-                ("n_dec_layers", ctypes.c_int32), ("dropout", ctypes.c_float)]
+                ("n_dec_layers", ctypes.c_int32), ("dropout", ctypes.c_float), ("precision", ctypes.c_int32)]
 
 
 class GtStepState(ctypes.Structure):
@@ -129,6 +129,9 @@ def get_lib():
     return _default
 
 
-def make_config(batch, src_dim, d_model, n_heads, dim_ff, n_enc_layers, n_dec_layers=0, dropout=0.0):
+PRECISION = {"fp32": 0, "f32": 0, "float32": 0, 0: 0, None: 0, "bf16": 1, "bfloat16": 1, 1: 1}
+
+
+def make_config(batch, src_dim, d_model, n_heads, dim_ff, n_enc_layers, n_dec_layers=0, dropout=0.0, precision=0):
     return GtConfig(int(batch), int(src_dim), int(d_model), int(n_heads), int(dim_ff), int(n_enc_layers),
-                    int(n_dec_layers), float(dropout))
+                    int(n_dec_layers), float(dropout), PRECISION[precision])

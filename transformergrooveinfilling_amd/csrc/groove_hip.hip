@@ -99,6 +99,7 @@ static int check_cfg(const gt_config* c) {
   if (c->n_enc_layers <= 0 || c->n_enc_layers > 64 || c->n_dec_layers < 0 || c->n_dec_layers > 64)
     return gt_fail("layer counts out of range (enc %d, dec %d)", c->n_enc_layers, c->n_dec_layers);
   if (!(c->dropout >= 0.f && c->dropout < 1.f)) return gt_fail("dropout %f outside [0,1)", (double)c->dropout);
+  if (c->precision != 0 && c->precision != 1) return gt_fail("precision %d unknown (0 = fp32, 1 = bf16 GEMM operands)", c->precision);
   if ((int64_t)c->batch * 32 * (c->dim_ff > 3 * c->d_model ? c->dim_ff : 3 * c->d_model) >= (1ll << 31))
     return gt_fail("batch %d too large for 32-bit element indices", c->batch);
   // every LayerNorm instance gets one row of the dgamma/dbeta partials table (LnJobs): refuse here, before any launch,
@@ -214,7 +215,7 @@ static WLayout ws_layout(const gt_config& c) {
       w.qx = w.kvx = w.Px = w.ctxx = w.xhatx = w.rstdx = w.x2 = -1;
     }
     w.hact = add(M * F); w.xhat2 = add(M * d); w.rstd2 = add(M); w.xout = add(M * d);
-    if (c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff)) {
+    if (c.n_dec_layers == 0 && c.precision == 0 && chain_supported(c.d_model, c.dim_ff)) {
       w.c_dz2m = add(M * d); w.c_dz1 = add(M * d); w.c_dz1m = add(M * d); w.c_dhid = add(M * F); w.c_dqkv = add(M * 3 * d);
     } else {
       w.c_dz2m = w.c_dz1 = w.c_dz1m = w.c_dhid = w.c_dqkv = -1;
@@ -288,7 +289,9 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
 // GT_CHAIN=1 / gt_set_chain(1) forces them wherever they are supported, GT_CHAIN=0 / gt_set_chain(0) switches them off.
 static int g_chain = -1;                            // -1: read GT_CHAIN; 0 off; 1 forced on; 2 automatic (by shape)
 extern "C" int gt_set_chain(int on) { g_chain = on != 0; return 0; }
+static thread_local int g_bf16 = 0;                  // precision of the call being enqueued (set by make_ctx / the entry points)
 static bool chain_enabled(int d, int F) {
+  if (g_bf16) return false;                         // the row-chain kernels are fp32 only
   if (g_chain < 0) { const char* e = getenv("GT_CHAIN"); g_chain = (e && e[0] == '1') ? 1 : (e && e[0] == '0') ? 0 : 2; }
   return g_chain == 1 || (g_chain == 2 && d <= 64 && F <= 64);
 }
@@ -345,6 +348,7 @@ static GemmArgs mk_gemm(const float* A, int lda, const float* B, int ldb, float*
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.mask_scale = 1.0f;
   g.drop.scale = 1.0f;
+  g.bf16 = g_bf16;
   return g;
 }
 // y = x W^T + b  (forward "NT")
@@ -432,7 +436,8 @@ static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, 
 #ifndef GT_ROW_FUSE_MIN_M
 #define GT_ROW_FUSE_MIN_M 8192
 #endif
-static bool row_fused(const Ctx& x) { return x.d <= GT_ROW_FUSE_MAX_D || x.M >= GT_ROW_FUSE_MIN_M; }
+// (bf16 operands: always the tiled GEMM + row pass -- the row-owning tiles exist in fp32 only)
+static bool row_fused(const Ctx& x) { return !x.c.precision && (x.d <= GT_ROW_FUSE_MAX_D || x.M >= GT_ROW_FUSE_MIN_M); }
 static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float* xhat, const float* rstd, int64_t gamma_off, float* dz,
                    float* dzm, int site);
 static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, int K, const float* res, const float* xhat,
@@ -564,6 +569,7 @@ static int make_ctx(Ctx& x, const gt_config* cfg, const float* params, float* gr
                     int train, gt_stream_t stream) {
   if (check_cfg(cfg)) return -1;
   if (!params || !ws) return gt_fail("params / ws must not be NULL");
+  g_bf16 = cfg->precision;
   x.c = *cfg;
   x.P = param_layout(*cfg);
   x.W = ws_layout(*cfg);
@@ -613,7 +619,7 @@ static int self_attn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const f
 
 static bool use_chain(const Ctx& x) { return x.c.n_dec_layers == 0 && chain_supported(x.d, x.F) && chain_enabled(x.d, x.F); }
 static bool chain_path_for(const gt_config& c) {
-  return c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff) && chain_enabled(c.d_model, c.dim_ff);
+  return c.precision == 0 && c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff) && chain_enabled(c.d_model, c.dim_ff);
 }
 
 template <typename Args>

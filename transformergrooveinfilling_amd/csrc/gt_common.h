@@ -13,7 +13,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15];
 // D[row=4*(l>>4)+reg][col=l&15].  Exact f32 fmaf chain (cdna_hip_programming.md section 3).
 #define GT_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_16x16x32_bf16 (gt_config.precision = 1): lane l supplies A[i=l&15][k=8(l>>4)+j] and B[k=8(l>>4)+j][col l&15], j = 0..7
+// (cdna_hip_programming.md 3, "A/B operand lane maps, bf16"); C/D as the f32 form above.  fp32 accumulate.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define GT_MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// f32 -> bf16, round to nearest even, NaN stays NaN: the plain cast lowers to v_cvt_pk_bf16_f32 (MI355X_MICROARCH.md,
+// "Correctness boundaries")
+__device__ __forceinline__ uint16_t gt_f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 #endif
+__host__ __device__ static inline float gt_bf2f(uint16_t h) {
+  union { uint32_t u; float f; } c;
+  c.u = (uint32_t)h << 16;
+  return c.f;
+}
 
 #include "../../include/groove_hip.h"
 

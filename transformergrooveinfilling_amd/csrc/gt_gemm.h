@@ -61,6 +61,7 @@ struct GemmArgs {
   int pe_fixed;              // EPI_RELU_PE: 0 = row m uses pe[m & 31]; 1 = every row uses pe[0] (caller points pe at one time step)
   float* dbias;              // EPI_ATOMIC: column sums of A over k (grad of the bias), or nullptr
   float mask_scale;
+  int bf16;                  // gt_config.precision: 1 = the operands go through the matrix cores as bf16 (fp32 accumulate)
   DropArgs drop;
 };
 
@@ -130,11 +131,45 @@ struct TileStage {
       }
     }
   }
+  // bf16 operand path: the LDS image is ALWAYS [tile row][k] in bf16 (row stride str16 elements), whatever the source's
+  // orientation, so the fragment of 8 consecutive k is one ds_read_b128.  Conversion happens here, on the way into LDS.
+  //   source k-contiguous (this tile = [rows][BK]): chunk (r, k = c..c+3) -> one 8-byte store
+  __device__ __forceinline__ void store_bf16_kc(uint16_t* s, int str16, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int ch = tid + i * NT;
+      if (CH % NT == 0 || ch < CH) {
+        int r = ch / CPR, c = (ch % CPR) * 4;
+        uint2 pk;
+        pk.x = (uint32_t)gt_f2bf(v[i].x) | ((uint32_t)gt_f2bf(v[i].y) << 16);
+        pk.y = (uint32_t)gt_f2bf(v[i].z) | ((uint32_t)gt_f2bf(v[i].w) << 16);
+        *reinterpret_cast<uint2*>(&s[r * str16 + c]) = pk;
+      }
+    }
+  }
+  //   source row-contiguous (this tile = [BK k-rows][rows]): chunk (k = r, rows c..c+3) -> transposed, four 2-byte stores
+  __device__ __forceinline__ void store_bf16_tr(uint16_t* s, int str16, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int ch = tid + i * NT;
+      if (CH % NT == 0 || ch < CH) {
+        int r = ch / CPR, c = (ch % CPR) * 4;
+        s[(c + 0) * str16 + r] = gt_f2bf(v[i].x);
+        s[(c + 1) * str16 + r] = gt_f2bf(v[i].y);
+        s[(c + 2) * str16 + r] = gt_f2bf(v[i].z);
+        s[(c + 3) * str16 + r] = gt_f2bf(v[i].w);
+      }
+    }
+  }
 };
 
-template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
+template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI, int PREC = 0>
 struct GemmCfg {
   static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = BK_, NT = WM * WN * 64;
+  // bf16 operand path (PREC = 1): [tile row][k] bf16 images; row stride BK + 16 elements = (2 mod 4) 16-byte slots, the
+  // conflict-free condition of ds_read_b128 derived below for the fp32 tiles
+  static constexpr int STR16 = BK + 16;
+  static_assert(PREC == 0 || (BK % 32 == 0), "bf16 MFMA contracts 32 k per instruction");
   // k-contiguous tiles are read with ds_read_b128, which the LDS services in four NON-contiguous 16-lane groups
   // ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md "LDS"), each mixing all 16 rows at two neighbouring k-offsets: the row
   // stride must be == 8 (mod 16) floats for the 16 slots of a group to be distinct.  BK+4 (an odd number of 16-byte slots)
@@ -142,7 +177,7 @@ struct GemmCfg {
   // Row-contiguous tiles (ds_read_b32, two 32-lane groups, banks mod 32) are conflict-free at +4.
   static constexpr int SA_STR = AKM ? BM + 4 : BK + 8, SA_ROWS = AKM ? BK : BM;
   static constexpr int SB_STR = BKM ? BN + 4 : BK + 8, SB_ROWS = BKM ? BK : BN;
-  static constexpr int SA_SZ = SA_ROWS * SA_STR, SB_SZ = SB_ROWS * SB_STR;
+  static constexpr int SA_SZ = PREC ? BM * STR16 / 2 : SA_ROWS * SA_STR, SB_SZ = PREC ? BN * STR16 / 2 : SB_ROWS * SB_STR;   // dwords
   static constexpr bool ROW = (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD);
   static constexpr int CSTR = BN + 4;
   static constexpr int NG = WM * WN * 4;                       // 16-lane row groups per workgroup
@@ -158,9 +193,9 @@ __device__ static inline float gt_red16(float v) {
   return v;
 }
 
-template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
+template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI, int PREC = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, float* smem) {
-  typedef GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI> Cfg;
+  typedef GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI, PREC> Cfg;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::NT;
   constexpr int SA_STR = Cfg::SA_STR, SB_STR = Cfg::SB_STR, SA_SZ = Cfg::SA_SZ, SB_SZ = Cfg::SB_SZ;
 
@@ -273,7 +308,67 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
       __syncthreads();
     }
   };
-  if (fast) main_loop(std::true_type{}); else main_loop(std::false_type{});
+  // bf16 operands: same staging loads (fp32 from global), conversion on the way into LDS, one ds_read_b128 per fragment,
+  // v_mfma_f32_16x16x32_bf16.  The accumulator layout equals the fp32 form's, so every epilogue below is shared.
+  auto main_loop_bf16 = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    constexpr int STR16 = Cfg::STR16, SA16 = BM * STR16, SB16 = BN * STR16;
+    uint16_t* const s16 = reinterpret_cast<uint16_t*>(smem);
+    if (FAST) { la.prep(g.lda, tid); lb.prep(g.ldb, tid); }
+    auto load_tiles = [&](int k0) {
+      if (FAST) {
+        la.load_fast(AKM ? g.A + ((size_t)k0 * g.lda + m0) : g.A + ((size_t)m0 * g.lda + k0));
+        lb.load_fast(BKM ? g.B + ((size_t)k0 * g.ldb + n0) : g.B + ((size_t)n0 * g.ldb + k0));
+      } else {
+        if (AKM) la.load(g.A, g.lda, k0, m0, kend, g.M, vecA, tid);
+        else     la.load(g.A, g.lda, m0, k0, g.M, kend, vecA, tid);
+        if (BKM) lb.load(g.B, g.ldb, k0, n0, kend, g.N, vecB, tid);
+        else     lb.load(g.B, g.ldb, n0, k0, g.N, kend, vecB, tid);
+      }
+    };
+    auto store_tiles = [&](int buf) {
+      uint16_t* a = s16 + buf * SA16;
+      uint16_t* b = s16 + 2 * SA16 + buf * SB16;
+      if (AKM) la.store_bf16_tr(a, STR16, tid); else la.store_bf16_kc(a, STR16, tid);
+      if (BKM) lb.store_bf16_tr(b, STR16, tid); else lb.store_bf16_kc(b, STR16, tid);
+    };
+    if (nk > 0) { load_tiles(kbeg); store_tiles(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const uint16_t* sA = s16 + cur * SA16;
+      const uint16_t* sB = s16 + 2 * SA16 + cur * SB16;
+      if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        bf16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(&sA[((wm * TM + i) * 16 + l16) * STR16 + kk * 32 + 8 * lg]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          bf[i] = *reinterpret_cast<const bf16x8*>(&sB[((wn * TN + i) * 16 + l16) * STR16 + kk * 32 + 8 * lg]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)        // transposed tile except for the atomic epilogue, as in the fp32 loop
+            acc[a][b] = (EPI != EPI_ATOMIC) ? GT_MFMA16_BF16(bf[b], af[a], acc[a][b]) : GT_MFMA16_BF16(af[a], bf[b], acc[a][b]);
+      }
+      if (EPI == EPI_ATOMIC && AKM) {           // bias gradient: column sums of the staged (bf16) dY slab
+        if (g.dbias != nullptr && bx == 0 && tid < BM) {
+#pragma unroll 8
+          for (int kk = 0; kk < BK; ++kk) bsum += gt_bf2f(sA[tid * STR16 + kk]);
+        }
+      }
+      if (kt + 1 < nk) store_tiles(cur ^ 1);
+      __syncthreads();
+    }
+  };
+  if constexpr (PREC == 1) {
+    if (fast) main_loop_bf16(std::true_type{}); else main_loop_bf16(std::false_type{});
+  } else {
+    if (fast) main_loop(std::true_type{}); else main_loop(std::false_type{});
+  }
 
   // ------------------------------------------------------------------------------- epilogues
   // Two-phase everywhere: (1) every global input of the epilogue is loaded UNCONDITIONALLY (address-select
@@ -559,9 +654,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #ifndef GT_T128_WAVES
 #define GT_T128_WAVES 2
 #endif
-template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN >= 16 && TN == 4) ? GT_T128_WAVES : 1) void gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI>::SMEM];
+template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI, int PREC = 0>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN >= 16 && TN == 4 && EPI != EPI_ADD_RELUMASK_DROP && EPI != EPI_RELU_PE)
+                                              ? GT_T128_WAVES : 1) void gemm_kernel(GemmArgs g) {
+  // (the two input-layer epilogues hold a second and third 64-register operand set next to the accumulators: under the
+  //  256-register cap of two waves per SIMD they spilled 380 / 12 bytes per lane -- they run once per step, one wave is fine)
+  __shared__ __attribute__((aligned(16))) float smem[GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI, PREC>::SMEM];
 #ifndef GT_NO_XCD_REMAP
   if (gridDim.z == 1) {
     // XCD-aware placement (as in wgrad_group_kernel): workgroups are dealt round-robin over the 8 XCDs in dispatch order
@@ -571,11 +669,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN >= 16 && TN 
     const int gx = gridDim.x, nb = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
     const int xcd = lin & 7, q = nb >> 3, r = nb & 7;
     const int b = xcd * q + (xcd < r ? xcd : r) + (lin >> 3);
-    gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(g, b % gx, b / gx, 0, smem);
+    gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI, PREC>(g, b % gx, b / gx, 0, smem);
     return;
   }
 #endif
-  gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  gemm_body<WM, WN, TM, TN, BK_, AKM, BKM, EPI, PREC>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // Grouped launch: up to GT_GROUP_MAX independent GEMMs of one kind in ONE dispatch (all weight gradients of a
@@ -605,10 +703,12 @@ struct GemmGroup {
 #ifndef GT_WGRAD_T64_MIN
 #define GT_WGRAD_T64_MIN 512
 #endif
-template <int TM>
+template <int TM, int PREC = 0>
 __global__ __launch_bounds__(256, TM == 4 ? GT_T128_WAVES : 1) void wgrad_group_kernel(GemmGroup grp) {
-  constexpr int BK = TM == 4 ? GT_WGRAD_T128_BK : TM == 2 ? GT_WGRAD_T64_BK : GT_WGRAD_T32_BK;   // 128x128 tiles: 32-token slabs (68 KB of LDS, two workgroups per CU)
-  typedef GemmCfg<2, 2, TM, TM, BK, true, true, EPI_ATOMIC> C;
+  // token slab per step; the bf16 MFMA contracts 32 tokens per instruction, so its slabs are at least that long
+  constexpr int BK0 = TM == 4 ? GT_WGRAD_T128_BK : TM == 2 ? GT_WGRAD_T64_BK : GT_WGRAD_T32_BK;
+  constexpr int BK = (PREC == 1 && BK0 < 32) ? 32 : BK0;
+  typedef GemmCfg<2, 2, TM, TM, BK, true, true, EPI_ATOMIC, PREC> C;
   __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
   // XCD-aware placement: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one), each with its own
   // L2.  Give every XCD a CONTIGUOUS range of the logical tile space (tiles of one problem / one token chunk share their
@@ -620,7 +720,7 @@ __global__ __launch_bounds__(256, TM == 4 ? GT_T128_WAVES : 1) void wgrad_group_
   while (i + 1 < grp.n && b >= grp.start[i + 1]) ++i;
   const int local = b - grp.start[i];
   const int bx = local % grp.gx[i], t = local / grp.gx[i];
-  gemm_body<2, 2, TM, TM, BK, true, true, EPI_ATOMIC>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i], smem);
+  gemm_body<2, 2, TM, TM, BK, true, true, EPI_ATOMIC, PREC>(grp.p[i], bx, t % grp.gy[i], t / grp.gy[i], smem);
 }
 
 // --------------------------------------------------------------------------------- host dispatch
@@ -631,13 +731,13 @@ static inline const char* gemm_label() {
        : EPI == EPI_MASK_NZ ? "gemm_dgrad_ffn2" : EPI == EPI_ADD_RELUMASK_DROP ? "gemm_dgrad_input"
        : BKM ? "gemm_dgrad" : "gemm_fwd_bias";
 }
-template <int WM, int WN, int TM, int TN, int BK, bool AKM, bool BKM, int EPI>
+template <int WM, int WN, int TM, int TN, int BK, bool AKM, bool BKM, int EPI, int PREC = 0>
 static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s) {
-  typedef GemmCfg<WM, WN, TM, TN, BK, AKM, BKM, EPI> Cfg;
+  typedef GemmCfg<WM, WN, TM, TN, BK, AKM, BKM, EPI, PREC> Cfg;
   static_assert(!Cfg::ROW || (Cfg::BM % Cfg::NG) == 0, "row epilogue: BM must be a multiple of the row-group count");
   gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
   dim3 grid((g.N + Cfg::BN - 1) / Cfg::BN, (g.M + Cfg::BM - 1) / Cfg::BM, splitk);
-  gt_launch(gemm_kernel<WM, WN, TM, TN, BK, AKM, BKM, EPI>, grid, dim3(Cfg::NT), s, g);
+  gt_launch(gemm_kernel<WM, WN, TM, TN, BK, AKM, BKM, EPI, PREC>, grid, dim3(Cfg::NT), s, g);
 }
 
 // wgrad: the output (N_w x K_w) is small, the contraction (tokens) is long -> split it over z so that the
@@ -671,16 +771,23 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
 struct WgradBatch {
   GemmGroup grp[3];            // [0]: 32x32-tile problems, [1]: 64x64, [2]: 128x128
   double flops[3], bytes[3];
-  WgradBatch() { for (int k = 0; k < 3; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
+  int bf16;                    // every problem of a batch shares the step's precision
+  WgradBatch() : bf16(0) { for (int k = 0; k < 3; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
   bool empty() const { return grp[0].n == 0 && grp[1].n == 0 && grp[2].n == 0; }
 };
 static inline void wgrad_flush_one(WgradBatch& wb, int k, hipStream_t s) {
   GemmGroup& G = wb.grp[k];
   if (G.n == 0) return;
   gt_prof_tag("gemm_wgrad", wb.flops[k], wb.bytes[k]);
-  if (k == 0)      gt_launch(wgrad_group_kernel<1>, dim3(G.start[G.n]), dim3(256), s, G);
-  else if (k == 1) gt_launch(wgrad_group_kernel<2>, dim3(G.start[G.n]), dim3(256), s, G);
-  else             gt_launch(wgrad_group_kernel<4>, dim3(G.start[G.n]), dim3(256), s, G);
+  if (wb.bf16) {
+    if (k == 0)      gt_launch(wgrad_group_kernel<1, 1>, dim3(G.start[G.n]), dim3(256), s, G);
+    else if (k == 1) gt_launch(wgrad_group_kernel<2, 1>, dim3(G.start[G.n]), dim3(256), s, G);
+    else             gt_launch(wgrad_group_kernel<4, 1>, dim3(G.start[G.n]), dim3(256), s, G);
+  } else {
+    if (k == 0)      gt_launch(wgrad_group_kernel<1>, dim3(G.start[G.n]), dim3(256), s, G);
+    else if (k == 1) gt_launch(wgrad_group_kernel<2>, dim3(G.start[G.n]), dim3(256), s, G);
+    else             gt_launch(wgrad_group_kernel<4>, dim3(G.start[G.n]), dim3(256), s, G);
+  }
   G.n = 0; wb.flops[k] = wb.bytes[k] = 0;
 }
 static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) { for (int k = 0; k < 3; ++k) wgrad_flush_one(wb, k, s); }
@@ -691,6 +798,7 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   const int cls = (g.M >= 128 && g.N >= 128 && t128 * ((g.K + 511) / 512) >= GT_WGRAD_T128_MIN) ? 2
                 : (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= GT_WGRAD_T64_MIN) ? 1 : 0;
   const int tile = 32 << cls;
+  wb.bf16 = g.bf16;
   if (wb.grp[cls].n == GT_GROUP_MAX) wgrad_flush_one(wb, cls, s);
   const int splitk = wgrad_split(g, cls ? GT_WGRAD_SPLIT_BIG : GT_WGRAD_SPLIT_SMALL, tile);
   GemmGroup& G = wb.grp[cls];
@@ -721,7 +829,17 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   g.k_chunk = (g.K + 63) / 64 * 64;
   if (EPI == EPI_ATOMIC) {
     const int splitk = wgrad_split(g, 1024);
-    gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, splitk, s);
+    if (g.bf16) gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI, 1>(g, splitk, s);
+    else        gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, splitk, s);
+    return;
+  }
+  if (g.bf16) {
+    // bf16 operands: the same three tile classes; slabs of 64 k (two MFMA k-steps per barrier) except on the 128x128 tile,
+    // where 32 keeps two workgroups per CU resident (49 KB of LDS each)
+    const long u64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), u128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (u128 >= GT_T128_MIN) { g.k_chunk = (g.K + 31) / 32 * 32; gemm_launch_cfg<2, 2, 4, 4, 32, AKM, BKM, EPI, 1>(g, 1, s); }
+    else if (u64 >= GT_T64_MIN) { g.k_chunk = (g.K + 63) / 64 * 64; gemm_launch_cfg<2, 2, 2, 2, 64, AKM, BKM, EPI, 1>(g, 1, s); }
+    else { g.k_chunk = (g.K + 63) / 64 * 64; gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI, 1>(g, 1, s); }
     return;
   }
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);

@@ -37,7 +37,7 @@ class _Slot:
         d = eng.dims
         self.B = B
         self.cfg = _lib.make_config(B, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
-                                    d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"])
+                                    d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
         self.ws = torch.empty(eng.lib.workspace_floats(self.cfg), **f32)
         self.x = torch.zeros(B, 32, d["embedding_size_src"], **f32)
         self.y = torch.zeros(B, 32, 27, **f32)
@@ -57,7 +57,7 @@ class _LossSlot:
         d = eng.dims
         self.B = B
         self.cfg = _lib.make_config(B, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
-                                    d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"])
+                                    d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
         self.hvo = torch.zeros(B, 32, 27, **f32)
         self.y = torch.zeros(B, 32, 27, **f32)
         self.stats = torch.zeros(8, **f32)
@@ -66,7 +66,7 @@ class _LossSlot:
 class StepEngine:
     def __init__(self, d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_layers=0,
                  dropout=0.0, embedding_size_src=16, batch_size=None, optimizer="sgd", learning_rate=0.05,
-                 hit_loss_penalty=1.0, seed=0, device="cuda", world_size=1, use_graph=True, lib=None):
+                 hit_loss_penalty=1.0, seed=0, device="cuda", world_size=1, use_graph=True, lib=None, precision="fp32"):
         self.device = torch.device(device)
         # The only way onto host memory is an EXPLICITLY passed library object (tests hand in the host-emulator build of
         # the same kernel sources to cover the multi-rank step sequence over gloo); nothing in the package does that.
@@ -85,7 +85,8 @@ class StepEngine:
         self.use_graph = use_graph and not self.on_host
         self.dims = dict(d_model=int(d_model), n_heads=int(n_heads), dim_feedforward=int(dim_feedforward),
                          num_encoder_layers=int(num_encoder_layers), num_decoder_layers=int(num_decoder_layers),
-                         dropout=float(dropout), embedding_size_src=int(embedding_size_src))
+                         dropout=float(dropout), embedding_size_src=int(embedding_size_src),
+                         precision=_lib.PRECISION[precision])     # 0 fp32 | 1 bf16 GEMM operands (BASELINE configs[4])
         probe = _lib.make_config(1, embedding_size_src, d_model, n_heads, dim_feedforward, num_encoder_layers,
                                  num_decoder_layers, dropout)
         self.total, self.entries = self.lib.param_layout(probe)
@@ -301,7 +302,7 @@ class StepEngine:
                 if len(self._predict_ws) >= 2:             # the full chunk + one remainder size at most
                     self._predict_ws.pop(next(k for k in self._predict_ws if k != chunk), None)
                 cfg = _lib.make_config(m, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
-                                       d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"])
+                                       d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
                 ws = torch.empty(self.lib.workspace_floats(cfg), dtype=torch.float32, device=self.device)
                 tgt = torch.empty(m, 32, 27, dtype=torch.float32, device=self.device) if not self.encoder_only else None
                 self._predict_ws[m] = (cfg, ws, tgt)

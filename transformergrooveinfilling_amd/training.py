@@ -104,14 +104,15 @@ FILE_PATTERN = "transformer_run_{}_Epoch_{}.Model"
 
 
 def save_checkpoint(path, epoch, model, optimizer, loss):
-    """The reference's four keys (ckpt) plus ``dropout_step``: the position of this replica's dropout stream, so a resumed
-    run continues with fresh masks instead of replaying the ones of step 0 (readers of the reference format ignore it)."""
-    ck = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-          "optimizer_state_dict": optimizer.state_dict(), "loss": float(loss)}
+    """Exactly the reference's four keys (ckpt).  The position of this replica's dropout stream rides in
+    ``optimizer_state_dict["param_groups"][0]["dropout_step"]`` (torch optimizers keep unknown group keys), so a resumed
+    run continues with fresh masks instead of replaying the ones of step 0."""
+    osd = optimizer.state_dict()
     eng = getattr(model, "engine", None)
-    if eng is not None:
-        ck["dropout_step"] = max(int(eng.state_struct().step), int(getattr(model, "_train_forwards", 0)))
-    torch.save(ck, path)
+    if eng is not None and osd.get("param_groups"):
+        osd["param_groups"][0]["dropout_step"] = max(int(eng.state_struct().step), int(getattr(model, "_train_forwards", 0)))
+    torch.save({"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "optimizer_state_dict": osd, "loss": float(loss)}, path)
     return path
 
 
@@ -176,7 +177,8 @@ def initialize_model(params):
         initial_epoch = int(ck["epoch"]) + 1          # resume after the stored epoch (payload, not file name: SURVEY 5)
         # continue the dropout stream where the stored run stopped (a reference-written checkpoint has no position: start
         # far from the masks of the first epochs)
-        step = int(ck.get("dropout_step", initial_epoch << 20)) & 0x7FFFFFFF
+        groups = ck["optimizer_state_dict"].get("param_groups") or [{}]
+        step = int(groups[0].get("dropout_step", initial_epoch << 20)) & 0x7FFFFFFF
         model.engine.set_state(step=step)
         model._train_forwards = step
     return model, optimizer, initial_epoch
