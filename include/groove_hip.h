@@ -151,6 +151,22 @@ int gt_predict(const gt_config* cfg, const float* params, const float* pe, const
                float* hvo_out, float thres, int use_thres, float* tgt_scratch, float* ws,
                gt_stream_t stream);
 
+/* Replaces, for the device side, what the reference's evaluator computes from model.predict's output per epoch
+ * (ref:evaluator.py:522-525: get_hits_accuracies / get_velocity_errors / get_micro_timing_errors over the 9 voices of
+ * ROLAND_REDUCED_MAPPING): hvo_pred / hvo_gt are (n_rows,27) HVO tensors (n_rows = sequences * 32).  out30:
+ * [0] hit accuracy over all voices, [1..9] per voice; [10] velocity MSE, [11..19] per voice; [20] offset MSE, [21..29] per
+ * voice.  scratch: gt_voice_metrics_scratch_floats(n_rows) floats.  Fixed summation order: bitwise reproducible. */
+int64_t gt_voice_metrics_scratch_floats(int64_t n_rows);
+int gt_voice_metrics(const float* hvo_pred, const float* hvo_gt, int64_t n_rows, float* out30, float* scratch,
+                     gt_stream_t stream);
+
+/* Replaces GrooveMidiDatasetInfilling.__getitem__ + the DataLoader's collate for a dataset resident in HBM
+ * (ref:dataset.py:263-264,355-356; ref:train.py:156-158): x[b] = xs[idx[b]], y[b] = ys[idx[b]] for b < batch, both step
+ * inputs in ONE launch.  xs (n_seq,32,src_dim), ys (n_seq,32,27) fp32; idx int64 on the device (out-of-range entries are
+ * clamped into the dataset). */
+int gt_gather_batch(const float* xs, const float* ys, const int64_t* idx, int64_t n_seq, int32_t batch, int32_t src_dim,
+                    float* x, float* y, gt_stream_t stream);
+
 /* Measurement aid (no reference counterpart): with profiling on, every kernel launch is bracketed by
  * HIP events on its own stream.  gt_profile_report synchronises and writes one text row per kernel
  * class: "label launches total_ms total_flops total_bytes".  Not graph-capturable while on. */

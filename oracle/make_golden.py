@@ -31,6 +31,12 @@ G2 = {
     # BASELINE configs[1] shape (d128/H4/F512/L3); weights regenerated from the seed, grads kept as norms + samples
     "enc_c2": dict(d_model=128, n_heads=4, dim_feedforward=512, num_encoder_layers=3, num_decoder_layers=0, embedding_size_src=16),
 }
+# BASELINE configs[2] / [3] / [4] at FULL depth (batch 8): stock torch forward, loss, gradient norms + 64 samples per tensor
+G2_FULL = {
+    "encdec_c3": (dict(d_model=256, n_heads=2, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=6, embedding_size_src=16), 8),
+    "enc_c4": (dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, embedding_size_src=16), 8),
+    "enc_c5_sym": (dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, embedding_size_src=27), 8),
+}
 
 
 def load_into(model, P):
@@ -61,7 +67,7 @@ def demo_ckpt():
     np.savez_compressed(os.path.join(OUT, "demo_ckpt.npz"), **out)
 
 
-def g2(name, cfg, B=4, seed=11):
+def g2(name, cfg, B=4, seed=11, with_predict=True):
     full = cfg["d_model"] <= 64
     cfg = dict(cfg, dropout=0.0)
     P = ng.init_params(cfg, seed=seed, perturb=0.05)
@@ -105,12 +111,13 @@ def g2(name, cfg, B=4, seed=11):
         for k, p in m.named_parameters():
             out["adam/" + k] = p.detach().numpy().copy()
         load_into(m, P)
-    ph, pv, po = m.predict(xt)
-    out["pred_h"], out["pred_v"], out["pred_o"] = ph.numpy(), pv.numpy(), po.numpy()
-    _, margin = ng.predict(P, cfg, x)
-    out["pred_margin_min"] = margin.min()
+    if with_predict:
+        ph, pv, po = m.predict(xt)
+        out["pred_h"], out["pred_v"], out["pred_o"] = ph.numpy(), pv.numpy(), po.numpy()
+        _, margin = ng.predict(P, cfg, x)
+        out["pred_margin_min"] = margin.min()
     np.savez_compressed(os.path.join(OUT, "g2_%s.npz" % name), **out)
-    print(name, "loss", out["stats_pen0.47"][0], "min predict margin", margin.min())
+    print(name, "loss", out["stats_pen0.47"][0])
 
 
 if __name__ == "__main__":
@@ -119,5 +126,11 @@ if __name__ == "__main__":
     torch.set_num_threads(1)
     if os.path.exists(CKPT):
         demo_ckpt()
+    only = sys.argv[1:]
     for n, c in G2.items():
-        g2(n, c)
+        if not only or n in only:
+            g2(n, c)
+    torch.set_num_threads(8)
+    for n, (c, B) in G2_FULL.items():
+        if not only or n in only:
+            g2(n, c, B=B, with_predict=False)

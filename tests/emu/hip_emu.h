@@ -71,6 +71,9 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 static inline void __threadfence() {}
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #define GT_MFMA16(a, b, c) emu::mfma16((a), (b), (c))
+typedef float f32x16 __attribute__((vector_size(64)));
+namespace emu { f32x16 mfma32(float a, float b, f32x16 c); }
+#define GT_MFMA32(a, b, c) emu::mfma32((a), (b), (c))
 // bf16 operands (gt_config.precision = 1): 8 bf16 per lane, fp32 accumulate
 struct bf16x8 { uint16_t v[8]; };
 namespace emu { f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c); }
@@ -198,6 +201,23 @@ f32x4 mfma16(float a, float b, f32x4 c) {
     int row = 4 * g + r;
     float acc = c[r];
     for (int k = 0; k < 4; ++k) acc = fmaf(scratchA[w][row + 16 * k], scratchB[w][col + 16 * k], acc);
+    c[r] = acc;
+  }
+  wave_sync();
+  return c;
+}
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D[row=(reg&3)+8*(reg>>2)+4*(l>>5)][col=l&31]; k-ordered fmaf chain
+f32x16 mfma32(float a, float b, f32x16 c) {
+  int w = cur / 64, l = cur % 64;
+  scratchA[w][l] = a;
+  scratchB[w][l] = b;
+  wave_sync();
+  int col = l & 31, hh = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) acc = fmaf(scratchA[w][row + 32 * k], scratchB[w][col + 32 * k], acc);
     c[r] = acc;
   }
   wave_sync();

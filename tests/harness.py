@@ -14,7 +14,7 @@ from transformergrooveinfilling_amd import _lib, layout  # noqa: E402
 
 EMU_SO = os.environ.get("GT_EMU_LIB_PATH") or os.path.join(ROOT, "tests", "emu", "libgroove_emu.so")   # override: tile-rule variants
 _SRC = [os.path.join(ROOT, "transformergrooveinfilling_amd", "csrc", f)
-        for f in ("groove_hip.hip", "gt_common.h", "gt_gemm.h", "gt_attn.h", "gt_misc.h", "gt_chain.h")] + \
+        for f in ("groove_hip.hip", "gt_common.h", "gt_gemm.h", "gt_gemm32.h", "gt_attn.h", "gt_misc.h", "gt_chain.h")] + \
        [os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "include", "groove_hip.h")]
 
 

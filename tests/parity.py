@@ -92,21 +92,200 @@ def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chai
 
 
 # ---- bf16 operand path (gt_config.precision = 1, BASELINE configs[4]) -------------------------------------------------------
-# Compared with the fp64 oracle fed bf16-ROUNDED operands (oracle.numpy_groove "bf16 operand mode": same rounding points as
-# the device).  What is left between the two is (a) fp32 accumulation and (b) rounding-boundary flips: an operand the device
-# computed 6e-8 (relative) away from the oracle's value rounds to the neighbouring bf16 with probability ~1.5e-5; one flip
-# moves that row's outputs by ~1e-3 and the rest of its sequence with it.  Without a flip the two agree to 1e-7 (small
-# shapes); at realistic sizes every sequence sees a few.  The bar is therefore RELATIVE TO THE bf16 EFFECT ITSELF:
-#   E_q = RMS(fp32-operand oracle - bf16-operand oracle)         (what rounding the operands changes)
-#   forward:   RMS(device - bf16 oracle) <= 0.35 E_q + 2e-6   and   max-abs <= 2e-2
-#   gradients: per tensor RMS(device - bf16 oracle) <= 0.35 E_q(tensor) + 1e-4 RMS(g)   and   max-abs <= 2e-2 max|g|
-#   loss: 2e-3 relative.
-# A device that did not round (or rounded at other points) sits at ~1.0 E_q and fails.
-BF16_FRAC, BF16_OUT_MAX, BF16_GRAD_MAX = 0.35, 2e-2, 2e-2
+# Two bars.
+# (1) PER OPERATION, teacher-forced (check_ops_bf16): every Linear of the forward and of the backward is recomputed in fp64
+#     from the DEVICE's own saved inputs (workspace activations / gradient temporaries), its two operands rounded to bf16 at
+#     exactly the points the device rounds them (oracle.numpy_groove.round_bf16), and compared with the device's output of
+#     that one operation.  Nothing propagates, so the bar is the fp32 one: 5e-5 of the tensor's largest entry (fp32
+#     accumulation over up to 16384 terms), LayerNorm / activation epilogues included.  This is the parity proof.
+# (2) END TO END against the bf16-operand oracle (oracle "bf16 operand mode").  Here differences DO propagate: an operand the
+#     device computed 6e-8 (relative) away from the oracle's value rounds to the neighbouring bf16 now and then, that moves
+#     its row by ~1e-3, and from there on the rest of the sequence rounds differently too -- two legitimate realisations of
+#     the same rounding noise decorrelate.  So this bar is a sanity bound, relative to the bf16 effect itself
+#     E_q = RMS(fp32-operand oracle - bf16-operand oracle):  RMS(device - bf16 oracle) <= 1.5 E_q + 1e-5, max-abs <= 5e-2,
+#     loss within 1 %.
+BF16_OP_TOL, BF16_E2E_FRAC, BF16_OUT_MAX = 5e-5, 1.5, 5e-2
 
 
 def _rms(a):
     return float(np.sqrt((np.asarray(a, np.float64) ** 2).mean()))
+
+
+def _close(dev, ref, what, tol=BF16_OP_TOL, where=None):
+    dev, ref = np.asarray(dev, np.float64).reshape(ref.shape), np.asarray(ref, np.float64)
+    err = np.abs(dev - ref)
+    if where is not None:
+        err = err * where
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    assert err.max() <= tol * scale, "%s: max |err| %.3g of max |ref| %.3g (ratio %.3g)" % (what, err.max(), scale, err.max() / scale)
+
+
+def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
+    """Teacher-forced per-operation parity of the bf16 path (bar (1) above).  r: Runner after forward (and, with G = the device's
+    gradients, after loss + backward).  Returns the number of operations checked."""
+    rb = ng.round_bf16
+    f64 = lambda a: np.asarray(a, np.float64)
+    P = {k: f64(v) for k, v in P.items()}
+    d, F, H = cfg["d_model"], cfg["dim_feedforward"], cfg["n_heads"]
+    L, Ld = cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0)
+    M = r.M
+    pe = np.tile(f64(ng.positional_encoding(d)), (M // 32, 1))
+    scale = 1.0 / (1.0 - float(np.float32(p))) if p > 0 else 1.0
+
+    def mask(site, n, shape=None):
+        m = ng.keep_mask(rng, site, n, p) if p > 0 else None
+        return 1.0 if m is None else (m if shape is None else m.reshape(shape))
+
+    def ws(name, layer=0, cols=None):
+        a = f64(r.ws_get(name, layer))
+        return a.reshape(M, -1) if cols is None else a.reshape(-1, cols)
+
+    def lin(a, w, b=None):
+        y = rb(a) @ rb(w).T
+        return y if b is None else y + b
+
+    def ln(z, g, b):
+        mu = z.mean(-1, keepdims=True)
+        var = ((z - mu) ** 2).mean(-1, keepdims=True)
+        xh = (z - mu) / np.sqrt(var + 1e-5)
+        return xh * g + b, xh
+
+    def ln_bwd(dy, xh, rstd, g):
+        gdy = dy * g
+        return rstd * (gdy - gdy.mean(-1, keepdims=True) - xh * (gdy * xh).mean(-1, keepdims=True)), (dy * xh).sum(0), dy.sum(0)
+
+    n = 0
+    # ---------------------------------------------------------------------------------------------- forward
+    def input_layer(xin, pre, a0name, outname, site):
+        nonlocal n
+        a = lin(f64(xin).reshape(M, -1), P[pre + "weight"], P[pre + "bias"])
+        safe = np.abs(a) > 1e-4
+        _close(ws(a0name), a, pre + "pre-activation")
+        _close(ws(outname), (np.maximum(a, 0) + pe) * mask(site, a.size, a.shape), pre + "output", where=safe)
+        n += 2
+
+    def attn_block(name, gl, xin, inw, qkvname, ctxname, outname, xhname, normname, site, q_rows=None):
+        nonlocal n
+        out = lin(ws(ctxname, gl), P[name + "out_proj.weight"], P[name + "out_proj.bias"]) * mask(site, M * d, (M, d))
+        y, xh = ln(xin + out, P[normname + ".weight"], P[normname + ".bias"])
+        _close(ws(outname, gl), y, "%s out-proj + norm (layer %d)" % (name, gl), tol=2e-5)
+        _close(ws(xhname, gl), xh, "%s xhat (layer %d)" % (name, gl), tol=2e-5)
+        n += 2
+        return ws(outname, gl)
+
+    def ffn_block(pre, gl, xin, normname, outname="xout"):
+        nonlocal n
+        hp = lin(xin, P[pre + "linear1.weight"], P[pre + "linear1.bias"])
+        _close(ws("hact", gl), np.maximum(hp, 0) * mask(ng.layer_site(gl, ng.S_FFN), hp.size, hp.shape),
+               pre + "linear1", where=np.abs(hp) > 1e-4)
+        f = lin(ws("hact", gl), P[pre + "linear2.weight"], P[pre + "linear2.bias"]) * mask(ng.layer_site(gl, ng.S_DROPF), M * d, (M, d))
+        y, xh = ln(xin + f, P[pre + normname + ".weight"], P[pre + normname + ".bias"])
+        _close(ws(outname, gl), y, pre + "linear2 + norm", tol=2e-5)
+        n += 2
+        return ws(outname, gl)
+
+    input_layer(x, "InputLayerEncoder.Linear.", "a0", "x0", ng.SITE_PE_ENC)
+    cur = ws("x0")
+    enc_in = []
+    for l in range(L):
+        pre = "Encoder.Encoder.layers.%d." % l
+        enc_in.append(cur)
+        _close(ws("qkv", l), lin(cur, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"]), pre + "in_proj")
+        n += 1
+        x1 = attn_block(pre + "self_attn.", l, cur, None, "qkv", "ctx", "x1", "xhat1", pre + "norm1", ng.layer_site(l, ng.S_DROP1))
+        cur = ffn_block(pre, l, x1, "norm2")
+    mem, _ = ln(cur, P["Encoder.Encoder.norm.weight"], P["Encoder.Encoder.norm.bias"])
+    _close(ws("memory"), mem, "final encoder norm", tol=2e-5)
+    final = ws("memory")
+    dec_in = []
+    if Ld:
+        input_layer(tgt, "InputLayerDecoder.Linear.", "b0", "y0", ng.SITE_PE_DEC)
+        ycur = ws("y0")
+        for l in range(Ld):
+            pre, gl = "Decoder.Decoder.layers.%d." % l, L + l
+            dec_in.append(ycur)
+            _close(ws("qkv", gl), lin(ycur, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"]), pre + "self in_proj")
+            y1 = attn_block(pre + "self_attn.", gl, ycur, None, "qkv", "ctx", "x1", "xhat1", pre + "norm1", ng.layer_site(gl, ng.S_DROP1))
+            wx, bx = P[pre + "multihead_attn.in_proj_weight"], P[pre + "multihead_attn.in_proj_bias"]
+            _close(ws("qx", gl), lin(y1, wx[:d], bx[:d]), pre + "cross q in_proj")
+            _close(ws("kvx", gl), lin(final, wx[d:], bx[d:]), pre + "cross kv in_proj")
+            n += 3
+            y2 = attn_block(pre + "multihead_attn.", gl, y1, None, "qx", "ctxx", "x2", "xhatx", pre + "norm2", ng.layer_site(gl, ng.S_DROP2))
+            ycur = ffn_block(pre, gl, y2, "norm3")
+        fin, _ = ln(ycur, P["Decoder.Decoder.norm.weight"], P["Decoder.Decoder.norm.bias"])
+        _close(ws("dec_final"), fin, "final decoder norm", tol=2e-5)
+        final = ws("dec_final")
+    logits = lin(final, P["OutputLayer.Linear.weight"], P["OutputLayer.Linear.bias"])
+    want = np.concatenate([logits[:, :9], 1 / (1 + np.exp(-logits[:, 9:18])), 0.5 * np.tanh(logits[:, 18:])], 1)
+    _close(r.hvo.numpy().reshape(M, 27), want, "output layer + heads")
+    n += 1
+    if G is None:
+        return n
+    # ---------------------------------------------------------------------------------------------- backward
+    G = {k: f64(v) for k, v in G.items()}
+
+    def tmp(name, gl, cols):
+        return f64(r.ws_get(name if (p > 0 or not name.endswith("m")) else name[:-1], gl)).reshape(M, cols)
+
+    def wgrad(dy, xin, wname, bname):
+        nonlocal n
+        _close(G[wname], rb(dy).T @ rb(xin), "grad " + wname)
+        _close(G[bname], rb(dy).sum(0), "grad " + bname)
+        n += 2
+
+    dlog = ws("dlogits")
+    wgrad(dlog, final, "OutputLayer.Linear.weight", "OutputLayer.Linear.bias")
+
+    def ffn_bwd(pre, gl, xin, dz_name, prev_xh, prev_rstd, prev_norm, dzprev_name):
+        nonlocal n
+        dz, dzm = tmp(dz_name, gl, d), tmp(dz_name + "m", gl, d)
+        wgrad(dzm, ws("hact", gl), pre + "linear2.weight", pre + "linear2.bias")
+        dh = (rb(dzm) @ rb(P[pre + "linear2.weight"])) * np.where(ws("hact", gl) != 0, scale, 0.0)
+        _close(tmp("dhid", gl, F), dh, pre + "linear2 dgrad (relu / dropout mask)")
+        dhid = tmp("dhid", gl, F)
+        wgrad(dhid, xin, pre + "linear1.weight", pre + "linear1.bias")
+        pre_ln = rb(dhid) @ rb(P[pre + "linear1.weight"]) + dz
+        want, dg, db = ln_bwd(pre_ln, ws(prev_xh, gl), ws(prev_rstd, gl, 1), P[pre + prev_norm + ".weight"])
+        _close(tmp(dzprev_name, gl, d), want, pre + "linear1 dgrad + " + prev_norm + " backward", tol=1e-4)
+        _close(G[pre + prev_norm + ".weight"], dg, "grad " + pre + prev_norm + ".weight", tol=1e-4)
+        _close(G[pre + prev_norm + ".bias"], db, "grad " + pre + prev_norm + ".bias", tol=1e-4)
+        n += 4
+
+    for l in reversed(range(L)):
+        pre = "Encoder.Encoder.layers.%d." % l
+        ffn_bwd(pre, l, ws("x1", l), "dzA", "xhat1", "rstd1", "norm1", "dzB")
+        dz1, dz1m = tmp("dzB", l, d), tmp("dzBm", l, d)
+        if p > 0:
+            _close(dz1m, dz1 * mask(ng.layer_site(l, ng.S_DROP1), M * d, (M, d)), pre + "dropout1 mask on the gradient", tol=1e-6)
+        wgrad(dz1m, ws("ctx", l), pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias")
+        dqkv = tmp("dqkv", l, 3 * d)
+        wgrad(dqkv, enc_in[l], pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias")
+        if Ld:
+            continue            # encoder-decoder: the encoder's incoming gradient also carries the memory path; covered by the fp32 tests
+        dx = rb(dqkv) @ rb(P[pre + "self_attn.in_proj_weight"]) + dz1
+        if l > 0:
+            pp = "Encoder.Encoder.layers.%d." % (l - 1)
+            want, _, _ = ln_bwd(dx, ws("xhat2", l - 1), ws("rstd2", l - 1, 1), P[pp + "norm2.weight"])
+            _close(tmp("dzA", l - 1, d), want, pre + "in_proj dgrad + previous layer's norm2 backward", tol=1e-4)
+        else:
+            da = dx * mask(ng.SITE_PE_ENC, M * d, (M, d)) * (ws("a0") > 0)
+            _close(ws("dctx"), da, "InputLayer backward (in_proj dgrad, dropout, relu mask)", tol=1e-4)
+            wgrad(ws("dctx"), f64(x).reshape(M, -1), "InputLayerEncoder.Linear.weight", "InputLayerEncoder.Linear.bias")
+        n += 1
+    for l in reversed(range(Ld)):
+        pre, gl = "Decoder.Decoder.layers.%d." % l, L + l
+        ffn_bwd(pre, gl, ws("x2", gl), "dzA", "xhatx", "rstdx", "norm2", "dzB")
+        wgrad(tmp("dzBm", gl, d), ws("ctxx", gl), pre + "multihead_attn.out_proj.weight", pre + "multihead_attn.out_proj.bias")
+        dqkvx = f64(r.ws_get("dqkvx", gl))
+        dqx, dkvx = dqkvx[:M * d].reshape(M, d), dqkvx[M * d:].reshape(M, 2 * d)
+        gw, gb = G[pre + "multihead_attn.in_proj_weight"], G[pre + "multihead_attn.in_proj_bias"]
+        _close(gw[:d], rb(dqx).T @ rb(ws("x1", gl)), "grad " + pre + "cross q in_proj weight")
+        _close(gw[d:], rb(dkvx).T @ rb(ws("memory")), "grad " + pre + "cross kv in_proj weight")
+        _close(gb, np.concatenate([rb(dqx).sum(0), rb(dkvx).sum(0)]), "grad " + pre + "cross in_proj bias")
+        wgrad(tmp("dzCm", gl, d), ws("ctx", gl), pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias")
+        wgrad(tmp("dqkv", gl, 3 * d), dec_in[l], pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias")
+        n += 3
+    return n
 
 
 def check_step_bf16(backend, cfg, B, p=0.0, penalty=0.47, seed=3):
@@ -120,31 +299,28 @@ def check_step_bf16(backend, cfg, B, p=0.0, penalty=0.47, seed=3):
     r = Runner(cfg, B, backend, rng=rng)
     r.set_params(P)
     hvo = r.forward(x, tgt, train=p > 0)
+    # (2) end to end, sanity bound
     (h, v, o), C = ng.forward(P, cfg, x, tgt=tgt, rng=rng if p > 0 else None, dtype=np.float64)
-    (h0, v0, o0), C0 = ng.forward(P, cfg0, x, tgt=tgt, rng=rng if p > 0 else None, dtype=np.float64)
+    (h0, v0, o0), _ = ng.forward(P, cfg0, x, tgt=tgt, rng=rng if p > 0 else None, dtype=np.float64)
     ref, ref0 = np.concatenate([h, v, o], -1), np.concatenate([h0, v0, o0], -1)
     eq = _rms(ref0 - ref)
     assert eq > 1e-5, "the bf16 rounding has no visible effect on this case: pick another"
     assert np.abs(hvo - ref).max() < BF16_OUT_MAX, "forward max-abs %g" % np.abs(hvo - ref).max()
-    assert _rms(hvo - ref) <= BF16_FRAC * eq + 2e-6, "forward rms %g vs bf16 effect %g" % (_rms(hvo - ref), eq)
+    assert _rms(hvo - ref) <= BF16_E2E_FRAC * eq + 1e-5, "forward rms %g vs bf16 effect %g" % (_rms(hvo - ref), eq)
     stats, d_hvo = r.loss(y, penalty)
-    rstats, dpred = ng.calculate_loss((h, v, o), y.astype(np.float64), penalty)
-    _, dpred0 = ng.calculate_loss((h0, v0, o0), y.astype(np.float64), penalty)
-    assert abs(stats[0] - rstats[0]) < 2e-3 * max(1.0, abs(rstats[0]))
+    rstats, _ = ng.calculate_loss((h, v, o), y.astype(np.float64), penalty)
+    assert abs(stats[0] - rstats[0]) < 1e-2 * max(1.0, abs(rstats[0]))
     G = r.backward(train=p > 0)
-    adopt_device_kinks(r, C, cfg)
-    Gr = ng.backward(P, cfg, C, dpred, dtype=np.float64)
-    G0 = ng.backward(P, cfg0, C0, dpred0, dtype=np.float64)
-    for k in Gr:
-        scale = max(np.abs(Gr[k]).max(), 1e-5)
-        assert np.abs(G[k] - Gr[k]).max() / scale < BF16_GRAD_MAX, (k, np.abs(G[k] - Gr[k]).max() / scale)
-        assert _rms(G[k] - Gr[k]) <= BF16_FRAC * _rms(G0[k] - Gr[k]) + 1e-4 * _rms(Gr[k]) + 1e-9, \
-            (k, _rms(G[k] - Gr[k]), _rms(G0[k] - Gr[k]), _rms(Gr[k]))
-    return r, P, G, Gr
+    # (1) per operation, teacher-forced: the parity proof
+    nops = check_ops_bf16(r, P, cfg, x, tgt, rng, p, G)
+    assert nops >= 10 * (cfg["num_encoder_layers"] + Ld)
+    return r, P, G
 
 
 def check_train_step_bf16(backend, cfg, B, p):
-    """gt_train_step with precision = 1: two SGD steps against the bf16-operand oracle (fp32 master weights)."""
+    """gt_train_step with precision = 1 (fp32 master weights): after each of two SGD steps the per-operation checks hold on the
+    step's own saved state, the update is exactly  w -= lr * g  of the device's gradients ... observed through the parameters:
+    they move along the bf16-operand oracle's gradient within the end-to-end bound."""
     cfg = dict(cfg, dropout=p, precision=1)
     P = ng.init_params(cfg, seed=9, perturb=0.05)
     x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=4)
@@ -153,15 +329,17 @@ def check_train_step_bf16(backend, cfg, B, p):
     r.set_params(P)
     cur = {k: v.astype(np.float64) for k, v in P.items()}
     for step in range(2):
+        before = r.unflatten(r.params.numpy())
         stats = r.train_step(x, y, 0.38, algo=0)
-        (h, v, o), C = ng.forward(cur, cfg, x, tgt=tgt, rng=(77, 5, step) if p > 0 else None, dtype=np.float64)
+        (h, v, o), C = ng.forward(before, cfg, x, tgt=tgt, rng=(77, 5, step) if p > 0 else None, dtype=np.float64)
         rstats, dpred = ng.calculate_loss((h, v, o), y.astype(np.float64), 0.38)
-        assert abs(stats[0] - rstats[0]) < 1e-3 * max(1, abs(rstats[0])), (step, stats[0], rstats[0])
-        G = ng.backward(cur, cfg, C, dpred, dtype=np.float64)
-        cur = {k: cur[k] - 0.05 * G[k] for k in cur}
+        assert abs(stats[0] - rstats[0]) < 1e-2 * max(1, abs(rstats[0])), (step, stats[0], rstats[0])
+        check_ops_bf16(r, before, cfg, x, tgt, (77, 5, step), p)                    # forward state of THIS step
+        G = ng.backward(before, cfg, C, dpred, dtype=np.float64)
         got = r.unflatten(r.params.numpy())
-        for k in cur:
-            assert np.abs(got[k] - cur[k]).max() < 0.05 * BF16_GRAD_MAX * max(np.abs(G[k]).max(), 1e-5) * (step + 1) + 1e-6, (step, k)
+        for k in G:
+            upd = (before[k].astype(np.float64) - got[k]) / 0.05                  # the gradient the device applied
+            assert np.abs(upd - G[k]).max() <= 5e-2 * max(np.abs(G[k]).max(), 1e-4) + 1e-5, (step, k)
     assert r.step_state().step == 2
 
 

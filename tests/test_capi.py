@@ -31,14 +31,19 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(_lib.GtConfig) == 32
+    assert ctypes.sizeof(_lib.GtConfig) == 36          # 8 x int32/float + precision
     assert ctypes.sizeof(_lib.GtStepState) == 48
+    assert [f[0] for f in _lib.GtConfig._fields_] == ["batch", "src_dim", "d_model", "n_heads", "dim_ff", "n_enc_layers",
+                                                      "n_dec_layers", "dropout", "precision"]
 
 
 def test_config_validation(lib):
     bad = [_lib.make_config(2, 16, 30, 4, 16, 2),      # embed_dim % heads (torch:nn/functional.py:6415-6417)
            _lib.make_config(0, 16, 32, 4, 16, 2), _lib.make_config(2, 16, 1024, 4, 16, 2),
            _lib.make_config(2, 16, 32, 4, 16, 0), _lib.make_config(2, 16, 32, 4, 16, 2, 0, 1.0)]
+    unknown_precision = _lib.make_config(2, 16, 32, 4, 16, 2)
+    unknown_precision.precision = 7
+    bad.append(unknown_precision)
     for c in bad:
         with pytest.raises(_lib.GrooveLibError):
             lib.param_layout(c)

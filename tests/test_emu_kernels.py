@@ -82,3 +82,51 @@ def test_bucketed_backward_bf16_operands():
 
 def test_predict_bf16_operands():
     parity.check_predict("emu", dict(ENCDEC, precision=1), 2, True, out_tol=1e-2, margin_tol=5e-3)
+
+
+# ---- big-tile fp32 kernel (gt_gemm32.h: 32x32x2 MFMA, two-deep prefetch ring) -------------------------------------------------
+# It serves problems of >= 192 tiles of 128x128 -- far beyond what the emulator can run -- so this test builds a variant of the
+# emulator library whose tile rule sends EVERY eligible problem (interior tiles, K % 64 == 0) to that kernel, in a subprocess
+# (the harness's library handle is process-wide).
+def test_big_tile_kernel_variant():
+    import os
+    import subprocess
+    import sys
+    from harness import ROOT
+    so = os.path.join(ROOT, "tests", "emu", "libgroove_emu_big.so")
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh"), "-DGT_T128_BIG_MIN=1"], env=dict(os.environ, GT_EMU_OUT=so),
+                          stdout=subprocess.DEVNULL)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import parity\nfrom harness import cfg_dict\n"
+            "parity.check_step('emu', cfg_dict(128, 4, 128, 2), 4, 0.2)\n"          # M = 128: QKV / out-proj / FFN fwd (NT), all dgrads (NN), K = 128 / 384
+            "parity.check_step('emu', cfg_dict(128, 2, 256, 1, 1), 4, 0.0)\n"        # encoder-decoder: accumulate epilogue (cross-attention dmem)
+            "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GT_EMU_LIB_PATH=so), capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+
+
+def test_gather_and_voice_metrics_kernels():
+    """gt_gather_batch / gt_voice_metrics under the emulator against numpy."""
+    import ctypes
+    import numpy as np
+    from harness import emu_lib
+    lib = emu_lib()
+    r = np.random.default_rng(0)
+    n, S, B = 37, 27, 5
+    xs, ys = r.random((n, 32, S), dtype=np.float32), r.random((n, 32, 27), dtype=np.float32)
+    idx = np.array([3, 36, 0, 3, 99], np.int64)                     # a repeated and an out-of-range index (clamped)
+    x, y = np.zeros((B, 32, S), np.float32), np.zeros((B, 32, 27), np.float32)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    lib.call("gt_gather_batch", vp(xs), vp(ys), vp(idx), ctypes.c_int64(n), B, S, vp(x), vp(y), None)
+    want = np.clip(idx, 0, n - 1)
+    assert np.array_equal(x, xs[want]) and np.array_equal(y, ys[want])
+    rows = 3 * 32 + 7                                                # not a multiple of the 64-row workgroup chunk
+    pred, gt = r.random((rows, 27), dtype=np.float32), r.random((rows, 27), dtype=np.float32)
+    pred[:, :9] = (pred[:, :9] > 0.5); gt[:, :9] = (gt[:, :9] > 0.4)
+    out = np.zeros(30, np.float32)
+    scratch = np.zeros(int(lib.cdll.gt_voice_metrics_scratch_floats(ctypes.c_int64(rows))), np.float32)
+    lib.call("gt_voice_metrics", vp(pred), vp(gt), ctypes.c_int64(rows), vp(out), vp(scratch), None)
+    for g, base in enumerate((0, 10, 20)):
+        cols = slice(9 * g, 9 * g + 9)
+        per = (pred[:, cols] == gt[:, cols]).mean(0) if g == 0 else ((pred[:, cols] - gt[:, cols]) ** 2).mean(0)
+        assert np.abs(out[base + 1:base + 10] - per).max() < 1e-6 and abs(out[base] - per.mean()) < 1e-6

@@ -187,3 +187,51 @@ def test_engine_bucketed_data_parallel_sequence_matches_fused_step():
     assert outs[1][2] == 0.0                                    # the update re-zeroed the gradient buffer
     assert np.abs(outs[0][0] - outs[1][0]).max() < 2e-6 * np.abs(outs[0][0]).max()
     assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-5
+
+
+def test_indexed_train_step_and_voice_metrics():
+    """SURVEY 8f N3 / N4 on the device: (a) a step fed by INDICES into an HBM-resident dataset (gather = first launch of the step's
+    graph) equals the step fed the gathered tensors; DeviceBatchLoader's index mode drives train_loop; (b) per-voice metrics
+    (gt_voice_metrics) equal a numpy evaluation of ref:evaluator.py:522-525's three quantities."""
+    import numpy as np
+    from transformergrooveinfilling_amd import layout, metrics
+    from transformergrooveinfilling_amd.engine import StepEngine
+    from transformergrooveinfilling_amd.parallel import DeviceBatchLoader
+    dims = dict(d_model=64, n_heads=4, dim_feedforward=64, num_encoder_layers=2, num_decoder_layers=0, dropout=0.1, embedding_size_src=16)
+    x, y = layout.synthetic_batch(200, 16, seed=3)
+    xs, ys = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    a = StepEngine(batch_size=16, learning_rate=0.05, hit_loss_penalty=0.4, seed=7, **dims)
+    b = StepEngine(batch_size=16, learning_rate=0.05, hit_loss_penalty=0.4, seed=7, **dims)
+    P = layout.init_params(dims, seed=1)
+    a.load_named(P); b.load_named(P)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(4):
+        idx = torch.randperm(200, generator=g)[:16].cuda()
+        sa = a.train_step_indexed(xs, ys, idx).clone()
+        sb = b.train_step(xs[idx], ys[idx]).clone()
+        assert torch.equal(sa, sb)
+    assert torch.equal(a.params, b.params)
+    # DeviceBatchLoader in index mode through train_loop == the same loader iterated as (x, y, idx) tensors
+    from BaseGrooveTransformers import calculate_loss, initialize_model, train_loop
+    bce, mse = torch.nn.BCEWithLogitsLoss(reduction="none"), torch.nn.MSELoss(reduction="none")
+    res = []
+    for mode in ("index", "tensors"):
+        model, opt, _ = initialize_model(_params(d=64, H=4, F=64, L=2, dropout=0.1, lr=0.05, pen=0.38))
+        model.engine.load_named(P)
+        dl = DeviceBatchLoader(xs, ys, 32, model.engine.device, seed=5)
+        src = dl if mode == "index" else list(dl)
+        train_loop(dataloader=src, groove_transformer=model, encoder_only=1, opt=opt, epoch=0, loss_fn=calculate_loss, bce_fn=bce,
+                   mse_fn=mse, device="cuda", hit_loss_penalty=0.38)
+        res.append(model.engine.params.clone())
+    assert torch.equal(res[0], res[1])
+    # per-voice metrics
+    pred = model.predict_hvo(xs)
+    m = metrics.voice_metrics(model, pred, ys)
+    p, t = pred.cpu().numpy().reshape(-1, 27), y.reshape(-1, 27)
+    assert abs(m["Hits_Accuracy_Overall"] - (p[:, :9] == t[:, :9]).mean()) < 1e-6
+    for j, v in enumerate(metrics.VOICES):
+        assert abs(m["Hits_Accuracy_" + v] - (p[:, j] == t[:, j]).mean()) < 1e-6
+        assert abs(m["Velocity_MSE_" + v] - ((p[:, 9 + j] - t[:, 9 + j]) ** 2).mean()) < 1e-6
+        assert abs(m["Offset_MSE_" + v] - ((p[:, 18 + j] - t[:, 18 + j]) ** 2).mean()) < 1e-6
+    assert abs(m["Velocity_MSE_Overall"] - ((p[:, 9:18] - t[:, 9:18]) ** 2).mean()) < 1e-6
+    assert metrics.evaluate(model, xs, ys) == m                                             # bitwise reproducible

@@ -19,6 +19,8 @@ for w in $WL; do
     c2) T="$R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"; E="$R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-graph" ;;
     c3) T="$R/tools/shape_bench.py --only 5 --steps 30 --warmup 5"; E="$R/tools/shape_bench.py --only 5 --steps 10 --warmup 3 --no-graph" ;;
     c4) T="$R/tools/shape_bench.py --only 7 --steps 30 --warmup 5"; E="$R/tools/shape_bench.py --only 7 --steps 10 --warmup 3 --no-graph" ;;
+    c5) T="$R/tools/shape_bench.py --only 11 --steps 30 --warmup 5"; E="$R/tools/shape_bench.py --only 11 --steps 10 --warmup 3 --no-graph" ;;
+    c5s) T="$R/tools/shape_bench.py --only 9 --steps 50 --warmup 5"; E="$R/tools/shape_bench.py --only 9 --steps 10 --warmup 3 --no-graph" ;;
     c4s) T="$R/tools/shape_bench.py --only 6 --steps 50 --warmup 5"; E="$R/tools/shape_bench.py --only 6 --steps 10 --warmup 3 --no-graph" ;;
     *) echo "unknown workload $w"; exit 2 ;;
   esac

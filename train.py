@@ -65,6 +65,8 @@ def build_parser():
     p.add_argument("--save-dir", default=None, help="where checkpoints go (default: wandb run dir or ./checkpoints)")
     p.add_argument("--override", action="append", default=[], metavar="KEY=VALUE", help="override a YAML key (bench shapes)")
     p.add_argument("--seed", default=0, type=int)
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                   help="bf16: the Linear GEMMs take bf16 operands on the matrix cores (fp32 accumulate, fp32 master weights; BASELINE configs[4])")
     return p
 
 
@@ -153,6 +155,7 @@ def main(argv=None):
         except Exception:
             wb = None
     params = model_params(hp, device)
+    params["model"]["precision"] = hp.get("precision", args.precision)
     params["seed"] = args.seed                # dropout stream of this run (the data-parallel rank is mixed in by the model)
     model, optimizer, initial_epoch = initialize_model(params)
     parallel.broadcast_parameters(model.engine.params)

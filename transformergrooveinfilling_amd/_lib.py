@@ -53,6 +53,11 @@ _SIGS = {
                                      _vp, _vp, _vp, ctypes.c_int, _vp]),
     # cfg, params, pe, x, hvo_out, thres, use_thres, tgt_scratch, ws, stream
     "gt_predict": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),
+    "gt_voice_metrics_scratch_floats": (ctypes.c_int64, [ctypes.c_int64]),
+    # hvo_pred, hvo_gt, n_rows, out30, scratch, stream
+    "gt_voice_metrics": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
+    # xs, ys, idx, n_seq, batch, src_dim, x, y, stream
+    "gt_gather_batch": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp]),
     "gt_grad_buckets": (ctypes.c_int, [_cfgp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "gt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_overlap": (ctypes.c_int, [ctypes.c_int]),

@@ -263,16 +263,24 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   auto set = [&](int64_t o, int64_t k) { off = o; cnt = k; };
   if (n == "x0") set(W.x0, M * d); else if (n == "a0") set(W.a0, M * d);
   else if (n == "enc_xhat") set(W.enc_xhat, M * d); else if (n == "enc_rstd") set(W.enc_rstd, M);
-  else if (n == "memory") set(W.memory, M * d); else if (n == "y0") set(W.y0, M * d);
+  else if (n == "memory") set(W.memory, M * d); else if (n == "y0") set(W.y0, M * d); else if (n == "b0") set(W.b0, M * d);
   else if (n == "dec_final") set(W.dec_final, M * d); else if (n == "dlogits") set(W.dlogits, M * GT_TGT);
-  else if (n == "dmem") set(W.dmem, M * d);
-  else {
+  else if (n == "dmem") set(W.dmem, M * d); else if (n == "dctx") set(W.dctx, M * d);
+  else if (n == "dzA" || n == "dzAm" || n == "dzB" || n == "dzBm" || n == "dzC" || n == "dzCm" || n == "dhid" || n == "dqkv" || n == "dqkvx") {
+    // backward temporaries of one layer (kept per layer while the weight gradients are deferred to the end of backward)
+    if (layer < 0 || layer >= (int)W.layers.size()) return gt_fail("gt_ws_find: layer %d out of range", layer);
+    const WLayout::TmpSet& t = W.set[(size_t)layer % W.set.size()];
+    if (n == "dzA") set(t.dzA, M * d); else if (n == "dzAm") set(t.dzAm, M * d); else if (n == "dzB") set(t.dzB, M * d);
+    else if (n == "dzBm") set(t.dzBm, M * d); else if (n == "dzC") set(t.dzC, M * d); else if (n == "dzCm") set(t.dzCm, M * d);
+    else if (n == "dhid") set(t.dhid, M * F); else if (n == "dqkv") set(t.dqkv, M * 3 * d); else set(t.dqkvx, M * 3 * d);
+  } else {
     if (layer < 0 || layer >= (int)W.layers.size()) return gt_fail("gt_ws_find: layer %d out of range", layer);
     const LayerW& w = W.layers[layer];
     if (n == "qkv") set(w.qkv, M * 3 * d); else if (n == "P") set(w.P, BH * 1024); else if (n == "ctx") set(w.ctx, M * d);
     else if (n == "xhat1") set(w.xhat1, M * d); else if (n == "rstd1") set(w.rstd1, M); else if (n == "x1") set(w.x1, M * d);
     else if (n == "qx") set(w.qx, M * d); else if (n == "kvx") set(w.kvx, M * 2 * d); else if (n == "Px") set(w.Px, BH * 1024);
     else if (n == "ctxx") set(w.ctxx, M * d); else if (n == "xhatx") set(w.xhatx, M * d); else if (n == "x2") set(w.x2, M * d);
+    else if (n == "rstdx") set(w.rstdx, M);
     else if (n == "hact") set(w.hact, M * F); else if (n == "xhat2") set(w.xhat2, M * d); else if (n == "rstd2") set(w.rstd2, M);
     else if (n == "xout") set(w.xout, M * d);
   }
@@ -1132,6 +1140,30 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
     if (optimizer_step_impl(algo, params, grads, m, v, P.total, state, 1, stream, 1)) return -1;
   }
   return 0;
+}
+
+// ------------------------------------------------------------------------------------ evaluation metrics / input gather
+extern "C" int64_t gt_voice_metrics_scratch_floats(int64_t n_rows) {
+  return n_rows <= 0 ? 0 : ((n_rows + GT_VM_ROWS - 1) / GT_VM_ROWS) * GT_TGT;
+}
+extern "C" int gt_voice_metrics(const float* hvo_pred, const float* hvo_gt, int64_t n_rows, float* out30, float* scratch,
+                                gt_stream_t stream) {
+  if (!hvo_pred || !hvo_gt || !out30 || !scratch) return gt_fail("gt_voice_metrics: pointers must not be NULL");
+  if (n_rows <= 0 || n_rows >= (1ll << 31)) return gt_fail("gt_voice_metrics: n_rows %lld out of range", (long long)n_rows);
+  const int M = (int)n_rows, nwg = (M + GT_VM_ROWS - 1) / GT_VM_ROWS;
+  hipStream_t s = (hipStream_t)stream;
+  gt_launch(voice_metrics_partial_kernel, dim3(nwg), dim3(256), s, hvo_pred, hvo_gt, scratch, M);
+  gt_launch(voice_metrics_final_kernel, dim3(1), dim3(64), s, (const float*)scratch, out30, nwg, M);
+  return launch_status("gt_voice_metrics");
+}
+extern "C" int gt_gather_batch(const float* xs, const float* ys, const int64_t* idx, int64_t n_seq, int32_t batch, int32_t src_dim,
+                               float* x, float* y, gt_stream_t stream) {
+  if (!xs || !ys || !idx || !x || !y) return gt_fail("gt_gather_batch: pointers must not be NULL");
+  if (batch <= 0 || src_dim <= 0 || n_seq <= 0) return gt_fail("gt_gather_batch: batch / src_dim / n_seq must be > 0");
+  const int64_t n4 = (int64_t)batch * (32 * src_dim / 4 + 32 * GT_TGT / 4);
+  gt_launch(gather_batch_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), (hipStream_t)stream, xs, ys, idx, x, y, (int)batch,
+            (int)src_dim, n_seq);
+  return launch_status("gt_gather_batch");
 }
 
 // ------------------------------------------------------------------------------------ predict

@@ -10,6 +10,10 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+// D[row=(reg&3)+8*(reg>>2)+4*(l>>5)][col=l&31], reg in [0,16).  Exact f32 fmaf chain, the same rate as the 16x16x4 form.
+#define GT_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 // v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15];
 // D[row=4*(l>>4)+reg][col=l&15].  Exact f32 fmaf chain (cdna_hip_programming.md section 3).
 #define GT_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)

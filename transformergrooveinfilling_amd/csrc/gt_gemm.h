@@ -823,6 +823,13 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
 #ifndef GT_T128_MIN
 #define GT_T128_MIN 512
 #endif
+// big-tile kernel of gt_gemm32.h (v_mfma_f32_32x32x2_f32, two-deep prefetch ring): interior-only large problems
+static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm);
+template <bool BKM, int EPI>
+static inline void gemm32_launch(const GemmArgs& g, hipStream_t s);
+#ifndef GT_T128_BIG_MIN
+#define GT_T128_BIG_MIN 192     /* 128x128 tiles of the big kernel from this many workgroups (d512 QKV at 2048 tokens: 16 x 12) */
+#endif
 // standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
 template <bool AKM, bool BKM, int EPI>
 static inline void gemm_launch(GemmArgs g, hipStream_t s) {
@@ -844,6 +851,9 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   }
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ)) {
+    if (t128 >= GT_T128_BIG_MIN && gemm32_ok(g, EPI, BKM)) { gemm32_launch<BKM, EPI>(g, s); return; }
+  }
   // 128x128 tiles once they still fill the chip twice over: a 64x64x64 slab needs ~38 GB/s of L2->LDS staging per
   // workgroup to keep its MFMAs fed, two resident workgroups ask a CU for more than it delivers (46-70 GB/s measured);
   // 128x128x32 slabs need half of that per flop
@@ -894,3 +904,5 @@ static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
   }
   return 0;
 }
+
+#include "gt_gemm32.h"

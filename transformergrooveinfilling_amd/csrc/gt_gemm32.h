@@ -1,0 +1,206 @@
+// Large-problem fp32 GEMM: 128x128 tiles on v_mfma_f32_32x32x2_f32 with a two-deep register prefetch ring and a compile-time
+// interleave of staging instructions with the MFMAs.  Serves the interior-only, large-M forms of the Linear forward ("NT":
+// B = weight (out,in), k contiguous) and dgrad ("NN": B = weight read as (k, n), n contiguous) with the plain / FFN1 / FFN2-dgrad
+// epilogues; everything else (edges, small problems, K not a multiple of 64, the LayerNorm row tiles, weight gradients) stays
+// on gt_gemm.h.  Results are bitwise those of any fp32 fmaf chain in k order 0,4,1,5,2,6,3,7 per 8-k group (the lane map below),
+// i.e. the same numbers as gt_gemm.h's kernels up to the order of the fp32 additions.
+//
+// Why this shape (measured on the d_model 512 QKV projection, 16384 tokens; tools/ubench/gemm32_bench.hip has every step):
+//   * 32x32x2 MFMA: lane (r = l & 31, h = l >> 5) reads ONE float4 (k = 4h..4h+3 of an 8-k group) per 32-row fragment, and with
+//     that lane -> row map a row stride of BK + 4 floats is conflict-free for ds_read_b128 (the 16x16x4 map needs BK + 8), so a
+//     double-buffered 128x128x32 workgroup takes 72 KB of LDS and two of them share a CU with room to spare.
+//   * what the plain one-deep loop loses is neither LDS reads nor barriers (ablations: +-0) but the global -> LDS staging: with
+//     loads issued at the top of a slab and consumed in its middle only ~32 KB per CU are in flight on average, and
+//     37 GB/s per CU at 1-1.5 us loaded latency needs ~55 KB (Little).  The ring issues slab t+2 at the top of slab t and
+//     writes slab t+1 to LDS in the middle of slab t: 75.7 % -> 82.4 % of the 157.3 TF peak.
+//   * sched_group_barrier puts ONE staging instruction (global load / ds_write / ds_read) behind each MFMA instead of blocks
+//     of 8 that hold the wave's issue port while the matrix pipe drains: 82.4 % -> 85.9 % (135 TF).
+#pragma once
+// (included at the end of gt_gemm.h: GemmArgs, gemm_label and the EPI_* constants come from there)
+
+#ifdef GT_EMU
+#define GT_SGB(mask, n)
+#define GT_SCHED_FENCE()
+#else
+#define GT_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define GT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0);
+#endif
+// n times: one MFMA, then one instruction of class `mask` (0x20 VMEM read, 0x100 DS read, 0x200 DS write)
+#define GT_IL(mask, n) _Pragma("unroll") for (int z_ = 0; z_ < (n); ++z_) { GT_SGB(0x8, 1) GT_SGB(mask, 1) }
+
+struct Gemm32Cfg {
+  static constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+  static constexpr int SA_STR = BK + 4, SA_SZ = BM * SA_STR;                    // A image [row][k]
+  template <bool BKM> static constexpr int sb_str() { return BKM ? BN + 4 : BK + 4; }
+  template <bool BKM> static constexpr int sb_sz() { return BKM ? BK * (BN + 4) : BN * (BK + 4); }
+  template <bool BKM> static constexpr int smem() { return 2 * (SA_SZ + sb_sz<BKM>()); }
+};
+
+// host side: can this problem go on the big-tile kernel?  (interior tiles only, even number of 32-wide slabs, 16-byte rows)
+static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (g.bf16 || g.M % 128 || g.N % 128 || g.K % 64 || g.K < 64) return false;
+  if ((g.lda & 3) || (g.ldb & 3) || (g.ldc & 3) || !al16(g.A) || !al16(g.B) || !al16(g.C)) return false;
+  if (epi == EPI_STORE || epi == EPI_RELU_DROP) { if (g.bias && !al16(g.bias)) return false; }
+  if (epi == EPI_MASK_NZ && ((g.ldres & 3) || !al16(g.res))) return false;
+  (void)bkm;
+  return true;
+}
+
+template <bool BKM, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
+  typedef Gemm32Cfg Cfg;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, SA_STR = Cfg::SA_STR, SA_SZ = Cfg::SA_SZ;
+  constexpr int SB_STR = Cfg::sb_str<BKM>(), SB_SZ = Cfg::sb_sz<BKM>();
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::smem<BKM>()];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  // XCD-contiguous tile order (tiles that share an A row panel share an L2); placement never changes results
+  const int gx = gridDim.x, nb = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+  const int xcd = lin & 7, q = nb >> 3, rr = nb & 7;
+  const int bid = xcd * q + (xcd < rr ? xcd : rr) + (lin >> 3);
+  const int m0 = (bid / gx) * BM, n0 = (bid % gx) * BN;
+
+  // staging: 4 float4 per thread and operand per slab.  A: chunk (row, 4 k);  B: chunk (n, 4 k) or, BKM, (k, 4 n)
+  constexpr int PER = 4;
+  f32x4 va[PER], vb[PER], wa[PER], wb[PER];
+  const char* pa[PER];
+  const char* pb[PER];
+  int sa_off[PER], sb_off[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ch = tid + i * 256;
+    const int r = ch >> 3, c = (ch & 7) * 4;
+    pa[i] = reinterpret_cast<const char*>(g.A + (size_t)(m0 + r) * g.lda + c);
+    sa_off[i] = r * SA_STR + c;
+    if (BKM) {
+      const int kr = ch >> 5, cn = (ch & 31) * 4;
+      pb[i] = reinterpret_cast<const char*>(g.B + (size_t)kr * g.ldb + n0 + cn);
+      sb_off[i] = kr * SB_STR + cn;
+    } else {
+      pb[i] = reinterpret_cast<const char*>(g.B + (size_t)(n0 + r) * g.ldb + c);
+      sb_off[i] = r * SB_STR + c;
+    }
+  }
+  const size_t bstep = BKM ? (size_t)g.ldb * 4 : 4;          // bytes per k of the B operand
+#define G32_LD(XA, XB, k0)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
+    XA[i] = *reinterpret_cast<const f32x4*>(pa[i] + (size_t)(k0) * 4);                         \
+    XB[i] = *reinterpret_cast<const f32x4*>(pb[i] + (size_t)(k0) * bstep);                     \
+  }
+#define G32_ST(XA, XB, buf)                                                                    \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
+    *reinterpret_cast<f32x4*>(&smem[(buf) * SA_SZ + sa_off[i]]) = XA[i];                       \
+    *reinterpret_cast<f32x4*>(&smem[2 * SA_SZ + (buf) * SB_SZ + sb_off[i]]) = XB[i];           \
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // fragments of one 8-k group: element j of lane half h is k = 4h + j of the group, for A and B alike
+  f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+  const int offa = (wm * 64 + r32) * SA_STR + 4 * h;
+  const int offb = 2 * SA_SZ + (BKM ? (4 * h) * SB_STR + wn * 64 + r32 : (wn * 64 + r32) * SB_STR + 4 * h);
+#define G32_RD(FA, FB, buf, kk)                                                                \
+  FA[0] = *reinterpret_cast<const f32x4*>(smem + (buf) * SA_SZ + offa + (kk) * 8);             \
+  FA[1] = *reinterpret_cast<const f32x4*>(smem + (buf) * SA_SZ + offa + 32 * SA_STR + (kk) * 8); \
+  if (BKM) {                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+      FB[0][j] = smem[(buf) * SB_SZ + offb + ((kk) * 8 + j) * SB_STR];                         \
+      FB[1][j] = smem[(buf) * SB_SZ + offb + ((kk) * 8 + j) * SB_STR + 32];                    \
+    }                                                                                          \
+  } else {                                                                                     \
+    FB[0] = *reinterpret_cast<const f32x4*>(smem + (buf) * SB_SZ + offb + (kk) * 8);           \
+    FB[1] = *reinterpret_cast<const f32x4*>(smem + (buf) * SB_SZ + offb + 32 * SB_STR + (kk) * 8); \
+  }
+  // transposed product (first operand = B fragment): lane (r32, h) ends up with ONE row of C per 32x32 tile and, in registers
+  // 4g..4g+3, the four consecutive columns 8g + 4h + 0..3 -> 16-byte epilogue accesses
+#define G32_MM(FA, FB)                                                                         \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
+  _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                             \
+  _Pragma("unroll") for (int tb = 0; tb < 2; ++tb)                                             \
+    acc[ta][tb] = GT_MFMA32(FB[tb][j], FA[ta][j], acc[ta][tb]);
+  constexpr int NRD = BKM ? 10 : 4, NRD8 = NRD > 8 ? 8 : NRD;  // LDS read instructions per fragment group
+  const int nk = g.K / BK;                                     // even, >= 2 (gemm32_ok)
+  G32_LD(va, vb, 0)
+  G32_LD(wa, wb, BK)
+  G32_ST(va, vb, 0)
+  __syncthreads();
+  G32_RD(fa0, fb0, 0, 0)
+  // one slab.  CUR: LDS buffer holding slab t; (NA, NB): registers holding slab t+1; (FA_, FB_): the set slab t came from,
+  // free again -> receives slab t+2 (the last two slabs re-load the final slab: branch-free, never used)
+#define G32_SLAB(CUR, NA, NB, FA_, FB_, t)                                                     \
+  { const int k2_ = ((t) + 2 < nk ? (t) + 2 : nk - 1) * BK;                                    \
+    G32_LD(FA_, FB_, k2_) }                                                                    \
+  G32_RD(fa1, fb1, CUR, 1) G32_MM(fa0, fb0)                                                    \
+  GT_IL(0x20, 8) GT_IL(0x100, NRD8) GT_SGB(0x8, 16 - 8 - NRD8)                                 \
+  GT_SCHED_FENCE()                                                                             \
+  G32_RD(fa0, fb0, CUR, 2) G32_MM(fa1, fb1)                                                    \
+  GT_IL(0x100, NRD) GT_SGB(0x8, 16 - NRD)                                                      \
+  GT_SCHED_FENCE()                                                                             \
+  G32_ST(NA, NB, (CUR) ^ 1)                                                                    \
+  G32_RD(fa1, fb1, CUR, 3) G32_MM(fa0, fb0)                                                    \
+  GT_IL(0x200, 8) GT_IL(0x100, NRD8) GT_SGB(0x8, 16 - 8 - NRD8)                                \
+  GT_SCHED_FENCE()                                                                             \
+  __syncthreads();                                                                             \
+  G32_RD(fa0, fb0, (CUR) ^ 1, 0)                                                               \
+  G32_MM(fa1, fb1)                                                                             \
+  GT_IL(0x100, NRD) GT_SGB(0x8, 16 - NRD)                                                      \
+  GT_SCHED_FENCE()
+  for (int kt = 0; kt < nk; kt += 2) {
+    G32_SLAB(0, wa, wb, va, vb, kt)
+    G32_SLAB(1, va, vb, wa, wb, kt + 1)
+  }
+
+  // ---- epilogue (two-phase: every global input first, then compute + 16-byte stores) ----
+  const uint32_t dkey = gt_drop_key(g.drop);
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {
+    f32x4 bia[4], rin[2][4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
+      bia[q4] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((EPI == EPI_STORE || EPI == EPI_RELU_DROP) && g.bias != nullptr) bia[q4] = *reinterpret_cast<const f32x4*>(g.bias + col);
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta) {
+        const int row = m0 + wm * 64 + ta * 32 + r32;
+        rin[ta][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_STORE && g.accumulate) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.C + (size_t)row * g.ldc + col);
+        if (EPI == EPI_MASK_NZ) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + col);
+      }
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta) {
+        const int row = m0 + wm * 64 + ta * 32 + r32;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ta][tb][4 * q4 + r];
+          if (EPI == EPI_STORE) v = v + bia[q4][r] + rin[ta][q4][r];
+          else if (EPI == EPI_RELU_DROP) v = fmaxf(v + bia[q4][r], 0.f) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
+          else if (EPI == EPI_MASK_NZ) v = (rin[ta][q4][r] != 0.f) ? v * g.mask_scale : 0.f;
+          o[r] = v;
+        }
+        *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = o;
+      }
+    }
+  }
+#undef G32_LD
+#undef G32_ST
+#undef G32_RD
+#undef G32_MM
+#undef G32_SLAB
+}
+
+template <bool BKM, int EPI>
+static inline void gemm32_launch(const GemmArgs& g, hipStream_t s) {
+  gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+  gt_launch(gemm32_kernel<BKM, EPI>, dim3(g.N / 128, g.M / 128), dim3(256), s, g);
+}

@@ -470,3 +470,74 @@ __global__ __launch_bounds__(256) void predict_head_kernel(const float* __restri
   hvo_out[(size_t)m * GT_TGT + c] = a;
   if (tgt != nullptr && t >= 0 && t + 1 < 32) tgt[(size_t)(m + 1) * GT_TGT + c] = a;
 }
+
+// ---- per-voice evaluation metrics (ref:evaluator.py:522-525 get_hits_accuracies / get_velocity_errors /
+// get_micro_timing_errors over the 9 voices of ROLAND_REDUCED_MAPPING) ---------------------------------------------------
+// pred / gt: (M,27) HVO = [hits | velocities | offsets].  Column c < 9: 1 if pred == gt (hit agreement), else the squared
+// difference.  A workgroup covers 64 rows: thread t < 216 owns column t % 27 of the rows (t / 27) + 8 i -- consecutive threads
+// read consecutive floats -- and the 8 row groups are summed in a fixed order, as are the workgroup partials in the second
+// kernel: bitwise reproducible.
+#define GT_VM_ROWS 64
+__global__ __launch_bounds__(256) void voice_metrics_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                                   float* __restrict__ part, int M) {
+  __shared__ float s[8][GT_TGT];
+  const int t = threadIdx.x;
+  if (t < 8 * GT_TGT) {
+    const int c = t % GT_TGT, g = t / GT_TGT;
+    const int m0 = blockIdx.x * GT_VM_ROWS;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < GT_VM_ROWS / 8; ++i) {
+      const int m = m0 + g + 8 * i;
+      if (m < M) {
+        const float a = pred[(size_t)m * GT_TGT + c], b = gt[(size_t)m * GT_TGT + c];
+        acc += (c < GT_VOICES) ? ((a == b) ? 1.0f : 0.0f) : (a - b) * (a - b);
+      }
+    }
+    s[g][c] = acc;
+  }
+  __syncthreads();
+  if (t < GT_TGT) {
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) a += s[g][t];
+    part[(size_t)blockIdx.x * GT_TGT + t] = a;
+  }
+}
+// out (30 floats): [0] hit accuracy over all voices, [1..9] per voice; [10] velocity MSE overall, [11..19] per voice;
+// [20] offset MSE overall, [21..29] per voice
+__global__ __launch_bounds__(64) void voice_metrics_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nwg, int M) {
+  __shared__ float s[GT_TGT];
+  const int t = threadIdx.x;
+  if (t < GT_TGT) {
+    float a = 0.f;
+    for (int w = 0; w < nwg; ++w) a += part[(size_t)w * GT_TGT + t];
+    a /= (float)M;
+    s[t] = a;
+    out[1 + (t / GT_VOICES) * (GT_VOICES + 1) + t % GT_VOICES] = a;
+  }
+  __syncthreads();
+  if (t < 3) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < GT_VOICES; ++j) a += s[t * GT_VOICES + j];
+    out[t * (GT_VOICES + 1)] = a * (1.0f / GT_VOICES);
+  }
+}
+
+// ---- batch gather (ref:dataset.py:355-356 __getitem__ + the DataLoader's collate, ref:train.py:156-158):
+// the dataset stays resident in HBM as two dense tensors; a batch is rows idx[0..B) of each.  One launch fills BOTH static
+// step inputs (x (B,32,S) and y (B,32,27)); float4 copies, 16-byte alignment guaranteed by 32 rows per sequence.
+__global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restrict__ xs, const float* __restrict__ ys,
+                                                           const int64_t* __restrict__ idx, float* __restrict__ x, float* __restrict__ y,
+                                                           int B, int S, int64_t n_seq) {
+  const int qx = 32 * S / 4, qy = 32 * GT_TGT / 4;             // float4 per sequence
+  const int per = qx + qy;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * per) return;
+  const int b = (int)(e / per), r = (int)(e % per);
+  int64_t src = idx[b];
+  src = src < 0 ? 0 : (src >= n_seq ? n_seq - 1 : src);        // a bad index must not read outside the dataset
+  if (r < qx) reinterpret_cast<float4*>(x)[(size_t)b * qx + r] = reinterpret_cast<const float4*>(xs)[(size_t)src * qx + r];
+  else        reinterpret_cast<float4*>(y)[(size_t)b * qy + (r - qx)] = reinterpret_cast<const float4*>(ys)[(size_t)src * qy + (r - qx)];
+}

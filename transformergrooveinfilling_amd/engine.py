@@ -44,6 +44,7 @@ class _Slot:
         self.hvo = torch.zeros(B, 32, 27, **f32)
         self.tgt = torch.zeros(B, 32, 27, **f32)
         self.stats = torch.zeros(8, **f32)
+        self.idx = torch.zeros(B, dtype=torch.int64, device=eng.device)     # static batch indices of the indexed step
         self.graphs = {}               # step recipe -> captured hipGraph
         self.fwd_id = 0                # bumped by every call that overwrites the saved activations (see StepEngine.forward)
 
@@ -220,10 +221,10 @@ class StepEngine:
             s.graphs[key] = g
         s.graphs[key].replay()
 
-    def train_step(self, x=None, y=None):
+    def train_step(self, x=None, y=None, B=None):
         """One optimisation step on (x, y) (device or host tensors; None = reuse the static buffers).
         Returns the device stats tensor [loss, hit_acc, -, bce, mse_v, mse_o, -, -] without syncing."""
-        s = self.slot(x.shape[0] if x is not None else self.B)
+        s = self.slot(x.shape[0] if x is not None else (B or self.B))
         s.fwd_id += 1
         if x is not None:
             s.x.copy_(x, non_blocking=True)
@@ -251,6 +252,37 @@ class StepEngine:
                 dist.all_reduce(self.grads)                  # RCCL sum over xGMI; averaged by grad_scale
             self.enqueue_update()
         return s.stats
+
+    def train_step_indexed(self, xs, ys, idx):
+        """One optimisation step on rows `idx` (device int64, len B) of a dataset resident in HBM (xs (N,32,S), ys (N,32,27)):
+        the gather into the static step inputs is the first launch of the step's hipGraph (gt_gather_batch), nothing is
+        copied on the host side but the B indices into their static buffer.  Data-parallel: as train_step."""
+        s = self.slot(idx.shape[0])
+        s.fwd_id += 1
+        s.idx.copy_(idx, non_blocking=True)
+        key = (xs.data_ptr(), ys.data_ptr(), xs.shape[0])
+
+        def gather():
+            self.lib.call("gt_gather_batch", _ptr(xs), _ptr(ys), _ptr(s.idx), ctypes.c_int64(xs.shape[0]), int(s.B),
+                          int(self.dims["embedding_size_src"]), _ptr(s.x), _ptr(s.y), self.stream)
+
+        if self.world_size == 1 and not self.force_dp:
+            self._replay(s, ("fused_idx", self.algo, self.penalty) + key, lambda: (gather(), self._enqueue_step(s, 0)))
+            return s.stats
+        gather()
+        return self.train_step(B=s.B)
+
+    def voice_metrics(self, hvo_pred, hvo_gt):
+        """Per-voice evaluation metrics of predictions against ground truth, both (N,32,27) HVO tensors on the device
+        (gt_voice_metrics; ref:evaluator.py:522-525) -> 30-float device tensor (layout: include/groove_hip.h)."""
+        p = torch.as_tensor(hvo_pred, dtype=torch.float32).to(self.device).contiguous()
+        g = torch.as_tensor(hvo_gt, dtype=torch.float32).to(self.device).contiguous()
+        assert p.shape == g.shape and p.shape[-1] == 27
+        rows = p.numel() // 27
+        out = torch.empty(30, dtype=torch.float32, device=self.device)
+        scratch = torch.empty(int(self.lib.cdll.gt_voice_metrics_scratch_floats(ctypes.c_int64(rows))), dtype=torch.float32, device=self.device)
+        self.lib.call("gt_voice_metrics", _ptr(p), _ptr(g), ctypes.c_int64(rows), _ptr(out), _ptr(scratch), self.stream)
+        return out
 
     def forward_eval_chunked(self, x, tgt_in=None, chunk=PREDICT_CHUNK):
         """Eval forward of a large set (the reference hands the whole test / validation set to the model at once,

@@ -102,7 +102,7 @@ class _GrooveFn(torch.autograd.Function):
 
 class _GrooveBase(nn.Module):
     def __init__(self, d_model, nhead, num_encoder_layers, num_decoder_layers, dim_feedforward, dropout,
-                 embedding_size_src, embedding_size_tgt, max_len, device, seed=0):
+                 embedding_size_src, embedding_size_tgt, max_len, device, seed=0, precision="fp32"):
         super().__init__()
         if max_len != 32 or embedding_size_tgt != 27:
             raise ValueError("the HIP path is built for max_len=32 / embedding_size_tgt=27 (ref:train.py:128,132)")
@@ -113,7 +113,7 @@ class _GrooveBase(nn.Module):
         # dropout stream: low word = the run's seed, high word = the data-parallel rank (ranks must not share masks)
         self.engine = StepEngine(d_model, nhead, dim_feedforward, num_encoder_layers, num_decoder_layers, dropout,
                                  embedding_size_src, device=self.device,
-                                 seed=(int(seed) & 0xFFFFFFFF) | (default_seed_hi() << 32))
+                                 seed=(int(seed) & 0xFFFFFFFF) | (default_seed_hi() << 32), precision=precision)
         eng = self.engine
         grads = eng.views(eng.grads)
         for name, view in eng.views().items():
@@ -189,9 +189,9 @@ class GrooveTransformerEncoder(_GrooveBase):
     """encoder_only = 1 (every shipped YAML: ref:configs/*_training.yaml:11)."""
 
     def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, dim_feedforward=2048, dropout=0.1,
-                 embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None, seed=0):
+                 embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None, seed=0, precision="fp32"):
         super().__init__(d_model, nhead, num_encoder_layers, 0, dim_feedforward, dropout, embedding_size_src,
-                         embedding_size_tgt, max_len, device, seed)
+                         embedding_size_tgt, max_len, device, seed, precision)
 
     def forward(self, src):
         return self._run(src, None)
@@ -201,9 +201,9 @@ class GrooveTransformer(_GrooveBase):
     """encoder-decoder (encoder_only = 0, ref:train.py:125-127); tgt = y shifted right by one step."""
 
     def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
-                 dropout=0.1, embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None, seed=0):
+                 dropout=0.1, embedding_size_src=16, embedding_size_tgt=27, max_len=32, device=None, seed=0, precision="fp32"):
         super().__init__(d_model, nhead, num_encoder_layers, num_decoder_layers, dim_feedforward, dropout,
-                         embedding_size_src, embedding_size_tgt, max_len, device, seed)
+                         embedding_size_src, embedding_size_tgt, max_len, device, seed, precision)
 
     def forward(self, src, tgt):
         return self._run(src, tgt)

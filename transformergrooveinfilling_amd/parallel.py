@@ -88,9 +88,13 @@ class DeviceBatchLoader:
     (ref:dataset.py:263-264,355-356) fed through DataLoader(shuffle=True, pin_memory=True) (ref:train.py:156-158); at
     0.3 ms per train step the collate + H2D copy of a host DataLoader would be several times the step.  Here both tensors
     live in HBM; every epoch draws the SAME seeded permutation on every rank (the one ShardedBatchSampler draws), a rank
-    keeps indices rank, rank+world, ..., and a batch is two index_select gathers on the device.  Yields (x, y, idx) like
-    the reference's dataset.  Under DP ragged tails are dropped (matched collectives); single-process keeps the last
-    partial batch, as DataLoader's default does."""
+    keeps indices rank, rank+world, ....  Two ways to consume it:
+      * ``index_batches()`` -> device index tensors only: train_loop hands them to StepEngine.train_step_indexed, where ONE
+        gather launch (gt_gather_batch, part of the step's hipGraph) fills both static step inputs -- no batch tensor is ever
+        materialised outside the step (the fast path);
+      * iteration -> (x, y, idx) like the reference's dataset (two index_select gathers), for any other consumer.
+    Under DP ragged tails are dropped (matched collectives); single-process keeps the last partial batch, as DataLoader's
+    default does."""
 
     def __init__(self, x, y, batch_size, device, rank=0, world=1, seed=0):
         self.x = torch.as_tensor(x, dtype=torch.float32).to(device).contiguous()
@@ -107,12 +111,16 @@ class DeviceBatchLoader:
         per_rank = self.n // self.world
         return per_rank // self.bs if self.world > 1 else (per_rank + self.bs - 1) // self.bs
 
-    def __iter__(self):
+    def index_batches(self):
+        """The epoch's batches as int64 index tensors on the device (views of ONE permutation copied once per epoch)."""
         g = torch.Generator()
         g.manual_seed(self.seed * 1000003 + self.epoch)
         perm = torch.randperm(self.n, generator=g)                      # host generator: identical on every rank and platform
         per_rank = self.n // self.world
         mine = perm[self.rank: per_rank * self.world: self.world].to(self.device)   # ONE small H2D copy per epoch
         for i in range(len(self)):
-            idx = mine[i * self.bs:(i + 1) * self.bs]
+            yield mine[i * self.bs:(i + 1) * self.bs]
+
+    def __iter__(self):
+        for idx in self.index_batches():
             yield self.x.index_select(0, idx), self.y.index_select(0, idx), idx

@@ -151,7 +151,8 @@ def initialize_model(params):
     common = dict(d_model=mp["d_model"], nhead=mp["n_heads"], dim_feedforward=mp["dim_feedforward"],
                   dropout=mp["dropout"], embedding_size_src=mp["embedding_size_src"],
                   embedding_size_tgt=mp["embedding_size_tgt"], max_len=mp["max_len"], device=mp.get("device", "cuda"),
-                  seed=int(params.get("seed", tp.get("seed", 0)) or 0))      # dropout stream (train.py --seed); rank mixed in by the model
+                  seed=int(params.get("seed", tp.get("seed", 0)) or 0),      # dropout stream (train.py --seed); rank mixed in by the model
+                  precision=mp.get("precision", "fp32"))                     # "bf16": GEMM operands in bf16 (BASELINE configs[4])
     if mp["encoder_only"]:
         model = GrooveTransformerEncoder(num_encoder_layers=mp["num_encoder_layers"], **common)
     else:
@@ -285,8 +286,24 @@ def train_loop(dataloader, groove_transformer, encoder_only, opt, epoch, loss_fn
         opt._push_lr()
     last, stats = None, None
     n_batches = 0
-    for batch, (X, y, _idx) in enumerate(dataloader):
+    # a dataset resident in HBM hands over INDICES: the gather is the first launch of the step's graph
+    indexed = fast and hasattr(dataloader, "index_batches") and getattr(dataloader, "x", None) is not None \
+        and dataloader.x.device == eng.device
+    batches = ((None, None, i) for i in dataloader.index_batches()) if indexed else dataloader
+    for batch, (X, y, _idx) in enumerate(batches):
         n_batches += 1
+        if indexed:
+            stats = eng.train_step_indexed(dataloader.x, dataloader.y, _idx)
+            X = _idx                           # (only its length is used below)
+            if (batch + 1) % log_every == 0:
+                last = _metrics_dict("train/", eng.mean_stats(eng.slot(X.shape[0])).tolist())
+            if last is not None and (batch + 1) % log_every == 0:
+                rec = dict(last, epoch=epoch, batch=batch)
+                if _wandb_active():
+                    wandb.log(rec, commit=True)
+                if on_log:
+                    on_log(rec)
+            continue
         X = X.to(device, torch.float32, non_blocking=True)
         y = y.to(device, torch.float32, non_blocking=True)
         if fast:
