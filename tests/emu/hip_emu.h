@@ -78,6 +78,8 @@ namespace emu { f32x16 mfma32(float a, float b, f32x16 c); }
 struct bf16x8 { uint16_t v[8]; };
 namespace emu { f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c); }
 #define GT_MFMA16_BF16(a, b, c) emu::mfma16_bf16((a), (b), (c))
+namespace emu { f32x16 mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c); }
+#define GT_MFMA32_BF16(a, b, c) emu::mfma32_bf16((a), (b), (c))
 static inline uint16_t gt_f2bf(float f) {          // round to nearest even; NaN stays NaN (what v_cvt_pk_bf16_f32 does)
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -85,6 +87,7 @@ static inline uint16_t gt_f2bf(float f) {          // round to nearest even; NaN
   return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+#define GT_BF16X8_SET(vec, j, x) (vec).v[j] = gt_f2bf(x)
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
@@ -239,6 +242,28 @@ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     for (int kg = 0; kg < 4; ++kg)
       for (int j = 0; j < 8; ++j) {
         uint32_t ua = (uint32_t)scratchHA[w][row + 16 * kg][j] << 16, ub = (uint32_t)scratchHB[w][col + 16 * kg][j] << 16;
+        float fa, fb;
+        memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+        acc += (double)fa * (double)fb;
+      }
+    c[r] = (float)acc;
+  }
+  wave_sync();
+  return c;
+}
+
+// v_mfma_f32_32x32x16_bf16: A[row l&31][k = 8(l>>5) + j], B[k = 8(l>>5) + j][col l&31]; D as the f32 32x32 form
+f32x16 mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  int w = cur / 64, l = cur % 64;
+  for (int j = 0; j < 8; ++j) { scratchHA[w][l][j] = a.v[j]; scratchHB[w][l][j] = b.v[j]; }
+  wave_sync();
+  int col = l & 31, hh = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    double acc = c[r];
+    for (int kh = 0; kh < 2; ++kh)
+      for (int j = 0; j < 8; ++j) {
+        uint32_t ua = (uint32_t)scratchHA[w][row + 32 * kh][j] << 16, ub = (uint32_t)scratchHB[w][col + 32 * kh][j] << 16;
         float fa, fb;
         memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
         acc += (double)fa * (double)fb;

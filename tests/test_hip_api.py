@@ -209,8 +209,8 @@ def test_indexed_train_step_and_voice_metrics():
         idx = torch.randperm(200, generator=g)[:16].cuda()
         sa = a.train_step_indexed(xs, ys, idx).clone()
         sb = b.train_step(xs[idx], ys[idx]).clone()
-        assert torch.equal(sa, sb)
-    assert torch.equal(a.params, b.params)
+        assert torch.allclose(sa, sb, rtol=2e-5, atol=1e-6)        # (weight gradients are fp32 atomics: later steps differ in the last bits)
+    assert torch.allclose(a.params, b.params, rtol=1e-4, atol=2e-6)
     # DeviceBatchLoader in index mode through train_loop == the same loader iterated as (x, y, idx) tensors
     from BaseGrooveTransformers import calculate_loss, initialize_model, train_loop
     bce, mse = torch.nn.BCEWithLogitsLoss(reduction="none"), torch.nn.MSELoss(reduction="none")
@@ -223,7 +223,7 @@ def test_indexed_train_step_and_voice_metrics():
         train_loop(dataloader=src, groove_transformer=model, encoder_only=1, opt=opt, epoch=0, loss_fn=calculate_loss, bce_fn=bce,
                    mse_fn=mse, device="cuda", hit_loss_penalty=0.38)
         res.append(model.engine.params.clone())
-    assert torch.equal(res[0], res[1])
+    assert torch.allclose(res[0], res[1], rtol=1e-4, atol=2e-6)
     # per-voice metrics
     pred = model.predict_hvo(xs)
     m = metrics.voice_metrics(model, pred, ys)

@@ -21,6 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (cdna_hip_programming.md 3, "A/B operand lane maps, bf16"); C/D as the f32 form above.  fp32 accumulate.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define GT_MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_32x32x16_bf16: lane l (r = l&31, h = l>>5) supplies A[row r][k = 8h + j] and B[k = 8h + j][col r]; C/D as the f32 32x32 form
+#define GT_MFMA32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define GT_BF16X8_SET(vec, j, x) (vec)[j] = (__bf16)(x)
 // f32 -> bf16, round to nearest even, NaN stays NaN: the plain cast lowers to v_cvt_pk_bf16_f32 (MI355X_MICROARCH.md,
 // "Correctness boundaries")
 __device__ __forceinline__ uint16_t gt_f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }

@@ -768,18 +768,26 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
 #ifndef GT_WGRAD_T128_MIN
 #define GT_WGRAD_T128_MIN 32
 #endif
+#ifndef GT_WGRAD32_SPLIT
+#define GT_WGRAD32_SPLIT 1024   /* A/B on C4 bs512: 64 / 128 / 256 / 1024 -> 10.6 / 10.9 / 10.5 / 9.76 ms: many short chunks balance the grouped launch */
+#endif
 struct WgradBatch {
-  GemmGroup grp[3];            // [0]: 32x32-tile problems, [1]: 64x64, [2]: 128x128
-  double flops[3], bytes[3];
+  GemmGroup grp[4];            // [0]: 32x32-tile problems, [1]: 64x64, [2]: 128x128, [3]: 128x128 on the big-tile body (gt_gemm32.h)
+  double flops[4], bytes[4];
   int bf16;                    // every problem of a batch shares the step's precision
-  WgradBatch() : bf16(0) { for (int k = 0; k < 3; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
-  bool empty() const { return grp[0].n == 0 && grp[1].n == 0 && grp[2].n == 0; }
+  WgradBatch() : bf16(0) { for (int k = 0; k < 4; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
+  bool empty() const { return grp[0].n == 0 && grp[1].n == 0 && grp[2].n == 0 && grp[3].n == 0; }
 };
+static inline bool wgrad32_ok(const GemmArgs& g);
+template <int PREC> __global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp);
 static inline void wgrad_flush_one(WgradBatch& wb, int k, hipStream_t s) {
   GemmGroup& G = wb.grp[k];
   if (G.n == 0) return;
   gt_prof_tag("gemm_wgrad", wb.flops[k], wb.bytes[k]);
-  if (wb.bf16) {
+  if (k == 3) {
+    if (wb.bf16) gt_launch(wgrad32_group_kernel<1>, dim3(G.start[G.n]), dim3(256), s, G);
+    else         gt_launch(wgrad32_group_kernel<0>, dim3(G.start[G.n]), dim3(256), s, G);
+  } else if (wb.bf16) {
     if (k == 0)      gt_launch(wgrad_group_kernel<1, 1>, dim3(G.start[G.n]), dim3(256), s, G);
     else if (k == 1) gt_launch(wgrad_group_kernel<2, 1>, dim3(G.start[G.n]), dim3(256), s, G);
     else             gt_launch(wgrad_group_kernel<4, 1>, dim3(G.start[G.n]), dim3(256), s, G);
@@ -790,17 +798,20 @@ static inline void wgrad_flush_one(WgradBatch& wb, int k, hipStream_t s) {
   }
   G.n = 0; wb.flops[k] = wb.bytes[k] = 0;
 }
-static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) { for (int k = 0; k < 3; ++k) wgrad_flush_one(wb, k, s); }
+static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) { for (int k = 0; k < 4; ++k) wgrad_flush_one(wb, k, s); }
 static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   // tile size by how many workgroups the problem still yields: 128x128 over >= 512-token chunks, else 64x64 over >= 256-token
   // chunks, else 32x32 (C2 at bs 64: 16 64x64-tiles x 8 chunks -> stays 32x32)
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-  const int cls = (g.M >= 128 && g.N >= 128 && t128 * ((g.K + 511) / 512) >= GT_WGRAD_T128_MIN) ? 2
-                : (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= GT_WGRAD_T64_MIN) ? 1 : 0;
+  int cls = (g.M >= 128 && g.N >= 128 && t128 * ((g.K + 511) / 512) >= GT_WGRAD_T128_MIN) ? 2
+          : (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= GT_WGRAD_T64_MIN) ? 1 : 0;
   const int tile = 32 << cls;
+  if (cls == 2 && wgrad32_ok(g)) cls = 3;             // interior-only 128x128 problems: the prefetch-ring body
   wb.bf16 = g.bf16;
   if (wb.grp[cls].n == GT_GROUP_MAX) wgrad_flush_one(wb, cls, s);
-  const int splitk = wgrad_split(g, cls ? GT_WGRAD_SPLIT_BIG : GT_WGRAD_SPLIT_SMALL, tile);
+  // (big-tile body: fewer, longer token chunks -- every chunk ends in 64 KB of fp32 atomics per tile, and the chip adds
+  //  ~1.3 TB/s of atomic bytes at most; a grouped launch has 16 problems' worth of workgroups anyway)
+  const int splitk = wgrad_split(g, cls == 3 ? GT_WGRAD32_SPLIT : cls ? GT_WGRAD_SPLIT_BIG : GT_WGRAD_SPLIT_SMALL, tile);
   GemmGroup& G = wb.grp[cls];
   const int i = G.n++;
   G.p[i] = g;
@@ -839,6 +850,10 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
     if (g.bf16) gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI, 1>(g, splitk, s);
     else        gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, splitk, s);
     return;
+  }
+  if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ)) {
+    const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (g.bf16 && b128 >= GT_T128_BIG_MIN && gemm32_ok(g, EPI, BKM)) { gemm32_launch<BKM, EPI>(g, s); return; }
   }
   if (g.bf16) {
     // bf16 operands: the same three tile classes; slabs of 64 k (two MFMA k-steps per barrier) except on the 128x128 tile,

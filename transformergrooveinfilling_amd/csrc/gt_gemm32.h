@@ -30,16 +30,17 @@
 
 struct Gemm32Cfg {
   static constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
-  static constexpr int SA_STR = BK + 4, SA_SZ = BM * SA_STR;                    // A image [row][k]
-  template <bool BKM> static constexpr int sb_str() { return BKM ? BN + 4 : BK + 4; }
-  template <bool BKM> static constexpr int sb_sz() { return BKM ? BK * (BN + 4) : BN * (BK + 4); }
-  template <bool BKM> static constexpr int smem() { return 2 * (SA_SZ + sb_sz<BKM>()); }
+  // operand images keep the SOURCE orientation: k-contiguous source -> [row][BK + 4] (fragment = one ds_read_b128),
+  // row-contiguous source (KM) -> [k][128 + 4] (fragment = four ds_read_b32, conflict-free: 32 consecutive floats per half wave)
+  template <bool KM> static constexpr int str() { return KM ? 128 + 4 : BK + 4; }
+  template <bool KM> static constexpr int sz() { return KM ? BK * (128 + 4) : 128 * (BK + 4); }
+  template <bool AKM, bool BKM> static constexpr int smem() { return 2 * (sz<AKM>() + sz<BKM>()); }
 };
 
 // host side: can this problem go on the big-tile kernel?  (interior tiles only, even number of 32-wide slabs, 16-byte rows)
 static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (g.bf16 || g.M % 128 || g.N % 128 || g.K % 64 || g.K < 64) return false;
+  if (g.M % 128 || g.N % 128 || g.K % 64 || g.K < 64) return false;
   if ((g.lda & 3) || (g.ldb & 3) || (g.ldc & 3) || !al16(g.A) || !al16(g.B) || !al16(g.C)) return false;
   if (epi == EPI_STORE || epi == EPI_RELU_DROP) { if (g.bias && !al16(g.bias)) return false; }
   if (epi == EPI_MASK_NZ && ((g.ldres & 3) || !al16(g.res))) return false;
@@ -47,19 +48,20 @@ static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm) {
   return true;
 }
 
-template <bool BKM, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
+// One 128x128 output tile: rows m0.., columns n0.., contraction range [kbeg, kbeg + nk * 32) (nk even, >= 2).
+// AKM / BKM as in gt_gemm.h: operand stored with the contraction index as its ROW index (weight gradients: both; dgrad: B).
+// PREC = 1 (gt_config.precision = 1): the same staging, fp32 LDS images in source orientation; the operands are rounded to bf16
+// when a lane assembles its fragment (8 consecutive k per lane half, two ds_read_b128 or eight ds_read_b32) and go through
+// v_mfma_f32_32x32x16_bf16.  16x fewer matrix cycles: the loop is then bound by the global -> LDS staging alone, so it runs a
+// plain one-barrier-per-slab schedule on the same two-deep ring.
+template <bool AKM, bool BKM, int EPI, int PREC = 0>
+__device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, const int n0, const int kbeg, const int nk, const bool want_dbias,
+                                            float* smem) {
   typedef Gemm32Cfg Cfg;
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, SA_STR = Cfg::SA_STR, SA_SZ = Cfg::SA_SZ;
-  constexpr int SB_STR = Cfg::sb_str<BKM>(), SB_SZ = Cfg::sb_sz<BKM>();
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::smem<BKM>()];
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+  constexpr int SA_STR = Cfg::str<AKM>(), SA_SZ = Cfg::sz<AKM>(), SB_STR = Cfg::str<BKM>(), SB_SZ = Cfg::sz<BKM>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
-  // XCD-contiguous tile order (tiles that share an A row panel share an L2); placement never changes results
-  const int gx = gridDim.x, nb = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
-  const int xcd = lin & 7, q = nb >> 3, rr = nb & 7;
-  const int bid = xcd * q + (xcd < rr ? xcd : rr) + (lin >> 3);
-  const int m0 = (bid / gx) * BM, n0 = (bid % gx) * BN;
 
   // staging: 4 float4 per thread and operand per slab.  A: chunk (row, 4 k);  B: chunk (n, 4 k) or, BKM, (k, 4 n)
   constexpr int PER = 4;
@@ -70,22 +72,27 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int ch = tid + i * 256;
-    const int r = ch >> 3, c = (ch & 7) * 4;
-    pa[i] = reinterpret_cast<const char*>(g.A + (size_t)(m0 + r) * g.lda + c);
-    sa_off[i] = r * SA_STR + c;
+    const int r = ch >> 3, c = (ch & 7) * 4;                   // k-contiguous source: (row, 4 k)
+    const int kr = ch >> 5, cn = (ch & 31) * 4;                // row-contiguous source: (k, 4 rows)
+    if (AKM) {
+      pa[i] = reinterpret_cast<const char*>(g.A + (size_t)(kbeg + kr) * g.lda + m0 + cn);
+      sa_off[i] = kr * SA_STR + cn;
+    } else {
+      pa[i] = reinterpret_cast<const char*>(g.A + (size_t)(m0 + r) * g.lda + kbeg + c);
+      sa_off[i] = r * SA_STR + c;
+    }
     if (BKM) {
-      const int kr = ch >> 5, cn = (ch & 31) * 4;
-      pb[i] = reinterpret_cast<const char*>(g.B + (size_t)kr * g.ldb + n0 + cn);
+      pb[i] = reinterpret_cast<const char*>(g.B + (size_t)(kbeg + kr) * g.ldb + n0 + cn);
       sb_off[i] = kr * SB_STR + cn;
     } else {
-      pb[i] = reinterpret_cast<const char*>(g.B + (size_t)(n0 + r) * g.ldb + c);
+      pb[i] = reinterpret_cast<const char*>(g.B + (size_t)(n0 + r) * g.ldb + kbeg + c);
       sb_off[i] = r * SB_STR + c;
     }
   }
-  const size_t bstep = BKM ? (size_t)g.ldb * 4 : 4;          // bytes per k of the B operand
+  const size_t astep = AKM ? (size_t)g.lda * 4 : 4, bstep = BKM ? (size_t)g.ldb * 4 : 4;    // bytes per k
 #define G32_LD(XA, XB, k0)                                                                     \
   _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
-    XA[i] = *reinterpret_cast<const f32x4*>(pa[i] + (size_t)(k0) * 4);                         \
+    XA[i] = *reinterpret_cast<const f32x4*>(pa[i] + (size_t)(k0) * astep);                     \
     XB[i] = *reinterpret_cast<const f32x4*>(pb[i] + (size_t)(k0) * bstep);                     \
   }
 #define G32_ST(XA, XB, buf)                                                                    \
@@ -102,11 +109,18 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // fragments of one 8-k group: element j of lane half h is k = 4h + j of the group, for A and B alike
   f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
-  const int offa = (wm * 64 + r32) * SA_STR + 4 * h;
+  const int offa = AKM ? (4 * h) * SA_STR + wm * 64 + r32 : (wm * 64 + r32) * SA_STR + 4 * h;
   const int offb = 2 * SA_SZ + (BKM ? (4 * h) * SB_STR + wn * 64 + r32 : (wn * 64 + r32) * SB_STR + 4 * h);
 #define G32_RD(FA, FB, buf, kk)                                                                \
-  FA[0] = *reinterpret_cast<const f32x4*>(smem + (buf) * SA_SZ + offa + (kk) * 8);             \
-  FA[1] = *reinterpret_cast<const f32x4*>(smem + (buf) * SA_SZ + offa + 32 * SA_STR + (kk) * 8); \
+  if (AKM) {                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+      FA[0][j] = smem[(buf) * SA_SZ + offa + ((kk) * 8 + j) * SA_STR];                         \
+      FA[1][j] = smem[(buf) * SA_SZ + offa + ((kk) * 8 + j) * SA_STR + 32];                    \
+    }                                                                                          \
+  } else {                                                                                     \
+    FA[0] = *reinterpret_cast<const f32x4*>(smem + (buf) * SA_SZ + offa + (kk) * 8);           \
+    FA[1] = *reinterpret_cast<const f32x4*>(smem + (buf) * SA_SZ + offa + 32 * SA_STR + (kk) * 8); \
+  }                                                                                            \
   if (BKM) {                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
       FB[0][j] = smem[(buf) * SB_SZ + offb + ((kk) * 8 + j) * SB_STR];                         \
@@ -116,19 +130,61 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
     FB[0] = *reinterpret_cast<const f32x4*>(smem + (buf) * SB_SZ + offb + (kk) * 8);           \
     FB[1] = *reinterpret_cast<const f32x4*>(smem + (buf) * SB_SZ + offb + 32 * SB_STR + (kk) * 8); \
   }
-  // transposed product (first operand = B fragment): lane (r32, h) ends up with ONE row of C per 32x32 tile and, in registers
-  // 4g..4g+3, the four consecutive columns 8g + 4h + 0..3 -> 16-byte epilogue accesses
+  // Store epilogues take the transposed product (first operand = B fragment): lane (r32, h) ends up with ONE row of C per
+  // 32x32 tile and, in registers 4g..4g+3, the four consecutive columns 8g + 4h + 0..3 -> 16-byte accesses.  The atomic
+  // epilogue keeps the plain product: register e of a tile is row (e&3) + 8(e>>2) + 4h, column r32 -- one atomic instruction
+  // covers two 128-byte row segments, the full-rate shape (MI355X_MICROARCH.md, "Global float atomics").
 #define G32_MM(FA, FB)                                                                         \
   _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
   _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                             \
   _Pragma("unroll") for (int tb = 0; tb < 2; ++tb)                                             \
-    acc[ta][tb] = GT_MFMA32(FB[tb][j], FA[ta][j], acc[ta][tb]);
-  constexpr int NRD = BKM ? 10 : 4, NRD8 = NRD > 8 ? 8 : NRD;  // LDS read instructions per fragment group
-  const int nk = g.K / BK;                                     // even, >= 2 (gemm32_ok)
+    acc[ta][tb] = (EPI != EPI_ATOMIC) ? GT_MFMA32(FB[tb][j], FA[ta][j], acc[ta][tb]) : GT_MFMA32(FA[ta][j], FB[tb][j], acc[ta][tb]);
+  constexpr int NRD = (AKM ? 8 : 2) + (BKM ? 8 : 2), NRD8 = NRD > 8 ? 8 : NRD, NRDF = NRD > 16 ? 16 : NRD;  // LDS reads per fragment group
+  float bsum = 0.f;                                            // EPI_ATOMIC: bias-gradient partial (column sum of the A slabs)
   G32_LD(va, vb, 0)
   G32_LD(wa, wb, BK)
   G32_ST(va, vb, 0)
   __syncthreads();
+  if constexpr (PREC == 1) {
+    // fragment of k-step s_ (16 k) of a 32-row tile: element j of lane half h is k = 16 s_ + 8 h + j
+    auto frag = [&](const int base, const int str, const bool km, const int tile, const int s_) -> bf16x8 {
+      bf16x8 r;
+      if (km) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) GT_BF16X8_SET(r, j, smem[base + (16 * s_ + 8 * h + j) * str + tile * 32 + r32]);
+      } else {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + base + (tile * 32 + r32) * str + 16 * s_ + 8 * h);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + base + (tile * 32 + r32) * str + 16 * s_ + 8 * h + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { GT_BF16X8_SET(r, j, lo[j]); GT_BF16X8_SET(r, 4 + j, hi[j]); }
+      }
+      return r;
+    };
+    const int abase = AKM ? wm * 64 : (wm * 64) * SA_STR, bbase = 2 * SA_SZ + (BKM ? wn * 64 : (wn * 64) * SB_STR);
+#define G32_SLAB16(CUR, NA, NB, FA_, FB_, t)                                                   \
+    { const int k2_ = ((t) + 2 < nk ? (t) + 2 : nk - 1) * BK;                                  \
+      G32_LD(FA_, FB_, k2_) }                                                                  \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                         \
+      bf16x8 a16[2], b16[2];                                                                   \
+      _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) {                                       \
+        a16[ti] = frag((CUR) * SA_SZ + abase, SA_STR, AKM, ti, s_);                            \
+        b16[ti] = frag((CUR) * SB_SZ + bbase, SB_STR, BKM, ti, s_);                            \
+      }                                                                                        \
+      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                         \
+      _Pragma("unroll") for (int tb = 0; tb < 2; ++tb)                                         \
+        acc[ta][tb] = (EPI != EPI_ATOMIC) ? GT_MFMA32_BF16(b16[tb], a16[ta], acc[ta][tb]) : GT_MFMA32_BF16(a16[ta], b16[tb], acc[ta][tb]); \
+    }                                                                                          \
+    if (EPI == EPI_ATOMIC && AKM && want_dbias && tid < BM) {  /* column sums of the bf16-rounded dY slab */ \
+      _Pragma("unroll 8") for (int kk_ = 0; kk_ < BK; ++kk_) bsum += gt_bf2f(gt_f2bf(smem[(CUR) * SA_SZ + kk_ * SA_STR + tid])); \
+    }                                                                                          \
+    G32_ST(NA, NB, (CUR) ^ 1)                                                                  \
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      G32_SLAB16(0, wa, wb, va, vb, kt)
+      G32_SLAB16(1, va, vb, wa, wb, kt + 1)
+    }
+#undef G32_SLAB16
+  } else {
   G32_RD(fa0, fb0, 0, 0)
   // one slab.  CUR: LDS buffer holding slab t; (NA, NB): registers holding slab t+1; (FA_, FB_): the set slab t came from,
   // free again -> receives slab t+2 (the last two slabs re-load the final slab: branch-free, never used)
@@ -139,22 +195,40 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
   GT_IL(0x20, 8) GT_IL(0x100, NRD8) GT_SGB(0x8, 16 - 8 - NRD8)                                 \
   GT_SCHED_FENCE()                                                                             \
   G32_RD(fa0, fb0, CUR, 2) G32_MM(fa1, fb1)                                                    \
-  GT_IL(0x100, NRD) GT_SGB(0x8, 16 - NRD)                                                      \
+  GT_IL(0x100, NRDF) GT_SGB(0x8, 16 - NRDF)                                                    \
   GT_SCHED_FENCE()                                                                             \
   G32_ST(NA, NB, (CUR) ^ 1)                                                                    \
   G32_RD(fa1, fb1, CUR, 3) G32_MM(fa0, fb0)                                                    \
   GT_IL(0x200, 8) GT_IL(0x100, NRD8) GT_SGB(0x8, 16 - 8 - NRD8)                                \
   GT_SCHED_FENCE()                                                                             \
+  /* bias gradient: every read of buffer CUR must precede this slab's barrier (the next slab overwrites it after it) */ \
+  if (EPI == EPI_ATOMIC && AKM && want_dbias && tid < BM) {                                    \
+    _Pragma("unroll 8") for (int kk_ = 0; kk_ < BK; ++kk_) bsum += smem[(CUR) * SA_SZ + kk_ * SA_STR + tid]; \
+  }                                                                                            \
   __syncthreads();                                                                             \
   G32_RD(fa0, fb0, (CUR) ^ 1, 0)                                                               \
   G32_MM(fa1, fb1)                                                                             \
-  GT_IL(0x100, NRD) GT_SGB(0x8, 16 - NRD)                                                      \
+  GT_IL(0x100, NRDF) GT_SGB(0x8, 16 - NRDF)                                                    \
   GT_SCHED_FENCE()
   for (int kt = 0; kt < nk; kt += 2) {
     G32_SLAB(0, wa, wb, va, vb, kt)
     G32_SLAB(1, va, vb, wa, wb, kt + 1)
   }
+  }   // PREC
 
+  if (EPI == EPI_ATOMIC) {
+    if (AKM && want_dbias && tid < BM) atomicAdd(&g.dbias[m0 + tid], bsum);
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 64 + ta * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, col = n0 + wn * 64 + tb * 32 + r32;
+          atomicAdd(&g.C[(size_t)row * g.ldc + col], acc[ta][tb][e]);
+        }
+    return;
+  }
   // ---- epilogue (two-phase: every global input first, then compute + 16-byte stores) ----
   const uint32_t dkey = gt_drop_key(g.drop);
 #pragma unroll
@@ -199,8 +273,42 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
 #undef G32_SLAB
 }
 
+template <bool BKM, int EPI, int PREC = 0>
+__global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[Gemm32Cfg::smem<false, BKM>()];
+  // XCD-contiguous tile order (tiles that share an A row panel share an L2); placement never changes results
+  const int gx = gridDim.x, nb = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+  const int xcd = lin & 7, q = nb >> 3, rr = nb & 7;
+  const int bid = xcd * q + (xcd < rr ? xcd : rr) + (lin >> 3);
+  gemm32_body<false, BKM, EPI, PREC>(g, (bid / gx) * 128, (bid % gx) * 128, 0, g.K / 32, false, smem);
+}
+
 template <bool BKM, int EPI>
 static inline void gemm32_launch(const GemmArgs& g, hipStream_t s) {
   gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
-  gt_launch(gemm32_kernel<BKM, EPI>, dim3(g.N / 128, g.M / 128), dim3(256), s, g);
+  if (g.bf16) gt_launch(gemm32_kernel<BKM, EPI, 1>, dim3(g.N / 128, g.M / 128), dim3(256), s, g);
+  else        gt_launch(gemm32_kernel<BKM, EPI, 0>, dim3(g.N / 128, g.M / 128), dim3(256), s, g);
+}
+
+// Weight gradients ("TN": dW (out x in) += dY^T X over a token chunk, fp32 atomics; bias gradient = column sums of the dY slabs
+// by the tiles of the first column): the grouped dispatch of gt_gemm.h on the big-tile body.  A problem qualifies when its
+// out / in sizes are multiples of 128 and its token count of 64 (wgrad32_ok); k_chunk is a multiple of 64.
+static inline bool wgrad32_ok(const GemmArgs& g) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return g.M % 128 == 0 && g.N % 128 == 0 && g.K % 64 == 0 && g.K >= 64 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 &&
+         al16(g.A) && al16(g.B);
+}
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp) {
+  __shared__ __attribute__((aligned(16))) float smem[Gemm32Cfg::smem<true, true>()];
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+  const int b = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+  int i = 0;
+  while (i + 1 < grp.n && b >= grp.start[i + 1]) ++i;
+  const GemmArgs& g = grp.p[i];
+  const int local = b - grp.start[i];
+  const int bx = local % grp.gx[i], t = local / grp.gx[i], by = t % grp.gy[i], bz = t / grp.gy[i];
+  const int kbeg = bz * g.k_chunk;
+  const int kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
+  gemm32_body<true, true, EPI_ATOMIC, PREC>(g, by * 128, bx * 128, kbeg, (kend - kbeg) / 32, g.dbias != nullptr && bx == 0, smem);
 }
