@@ -31,6 +31,7 @@ struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 struct uint2 { uint32_t x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 typedef float f32x4 __attribute__((vector_size(16)));
 typedef int hipStream_t_dummy;
 typedef void* hipStream_t;

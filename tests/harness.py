@@ -14,7 +14,7 @@ from transformergrooveinfilling_amd import _lib, layout  # noqa: E402
 
 EMU_SO = os.environ.get("GT_EMU_LIB_PATH") or os.path.join(ROOT, "tests", "emu", "libgroove_emu.so")   # override: tile-rule variants
 _SRC = [os.path.join(ROOT, "transformergrooveinfilling_amd", "csrc", f)
-        for f in ("groove_hip.hip", "gt_common.h", "gt_gemm.h", "gt_gemm32.h", "gt_attn.h", "gt_misc.h", "gt_chain.h")] + \
+        for f in ("groove_hip.hip", "gt_common.h", "gt_gemm.h", "gt_gemm32.h", "gt_seq.h", "gt_attn.h", "gt_misc.h", "gt_chain.h")] + \
        [os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "include", "groove_hip.h")]
 
 
@@ -58,10 +58,11 @@ def cfg_dict(d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_
 class Runner:
     """One model instance behind the C ABI.  backend = 'emu' | 'hip'."""
 
-    def __init__(self, cfg, B, backend="emu", rng=(1234, 99, 0), lr=0.094, chain=False):
+    def __init__(self, cfg, B, backend="emu", rng=(1234, 99, 0), lr=0.094, chain=False, seq=True):
         self.cfgd, self.B, self.backend = cfg, B, backend
         self.lib = emu_lib() if backend == "emu" else _lib.get_lib()
         self.lib.cdll.gt_set_chain(int(chain))          # process-global switch: fused row-chain kernels on / off
+        self.lib.cdll.gt_set_seq(int(seq and not chain))  # process-global switch: sequence-resident kernels (default where supported)
         self.Buf = NpBuf if backend == "emu" else CudaBuf
         self.c = _lib.make_config(B, cfg["embedding_size_src"], cfg["d_model"], cfg["n_heads"], cfg["dim_feedforward"],
                                   cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0), cfg.get("dropout", 0.0),

@@ -49,7 +49,7 @@ def adopt_device_kinks(r, C, cfg):
     return adopted
 
 
-def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chain=False):
+def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chain=False, seq=True):
     """forward + loss + backward (+ saved activations) against the fp64 numpy oracle."""
     cfg = dict(cfg, dropout=p)
     P = ng.init_params(cfg, seed=seed, perturb=0.05)
@@ -57,7 +57,7 @@ def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chai
     Ld = cfg.get("num_decoder_layers", 0)
     tgt = shift_right(y) if Ld else None
     rng = (1234, 99, 7)
-    r = Runner(cfg, B, backend, rng=rng, chain=chain)
+    r = Runner(cfg, B, backend, rng=rng, chain=chain, seq=seq)
     r.set_params(P)
     hvo = r.forward(x, tgt, train=p > 0)
     (h, v, o), C = ng.forward(P, cfg, x, tgt=tgt, rng=rng if p > 0 else None, dtype=np.float64)
@@ -366,14 +366,14 @@ def check_optimizers(backend, cfg, B):
             assert np.abs(got[k] - cur[k]).max() < 2e-6, (t, k)
 
 
-def check_train_step(backend, cfg, B, p, algo=0, chain=False):
+def check_train_step(backend, cfg, B, p, algo=0, chain=False, seq=True):
     """gt_train_step == forward+loss+backward+update with the oracle's masks; second step uses step+1."""
     cfg = dict(cfg, dropout=p)
     P = ng.init_params(cfg, seed=9, perturb=0.05)
     x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=4)
     Ld = cfg.get("num_decoder_layers", 0)
     tgt = shift_right(y) if Ld else None
-    r = Runner(cfg, B, backend, rng=(77, 5, 0), lr=0.05, chain=chain)
+    r = Runner(cfg, B, backend, rng=(77, 5, 0), lr=0.05, chain=chain, seq=seq)
     r.set_params(P)
     cur = {k: v.astype(np.float64) for k, v in P.items()}
     for step in range(2):
@@ -471,17 +471,17 @@ def golden_files():
     return sorted(glob.glob(os.path.join(GOLD, "g2_*.npz")))
 
 
-def check_bucketed_backward(backend, cfg, B, p, n_buckets, exact):
+def check_bucketed_backward(backend, cfg, B, p, n_buckets, exact, seq=True):
     """gt_train_step(skip_update=2) must leave bucket 0 of gt_grad_buckets FINAL (that is what the data-parallel path
     all-reduces while skip_update=3 runs), and 2 followed by 3 must equal the one-call backward (skip_update=1)."""
     cfg = dict(cfg, dropout=p)
     P = ng.init_params(cfg, seed=11, perturb=0.05)
     x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=12)
-    whole = Runner(cfg, B, backend, rng=(5, 6, 0))
+    whole = Runner(cfg, B, backend, rng=(5, 6, 0), seq=seq)
     whole.set_params(P)
     whole.train_step(x, y, 0.47, skip_update=1)
     gw = whole.grads.numpy().copy()
-    r = Runner(cfg, B, backend, rng=(5, 6, 0))
+    r = Runner(cfg, B, backend, rng=(5, 6, 0), seq=seq)
     r.set_params(P)
     buckets = r.lib.grad_buckets(r.c)
     assert len(buckets) == n_buckets

@@ -34,7 +34,7 @@ def _worker(rank, world, port, out):
     B = 4
     P = ng.init_params(cfg, seed=5 + rank, perturb=0.05)                   # deliberately different per rank ...
     x, y = ng.synthetic_batch(B, 16, seed=9)
-    run = Runner(cfg, B // world, "emu", lr=0.05)
+    run = Runner(cfg, B // world, "emu", lr=0.05, seq=False)       # two gradient buckets: the one-kernel-per-op path
     run.set_params(P)
     flat = torch.from_numpy(run.params.numpy())                            # shares memory with the runner's buffer
     parallel.broadcast_parameters(flat, src=0)                             # ... then made identical
@@ -68,7 +68,7 @@ def test_dp2_matches_single_process(tmp_path):
     cfg = cfg_dict(32, 4, 16, 2)
     P = ng.init_params(cfg, seed=5, perturb=0.05)
     x, y = ng.synthetic_batch(4, 16, seed=9)
-    single = Runner(cfg, 4, "emu", lr=0.05)
+    single = Runner(cfg, 4, "emu", lr=0.05, seq=False)
     single.set_params(P)
     single.train_step(x, y, 0.47, algo=0)
     ref = single.unflatten(single.params.numpy())

@@ -62,7 +62,7 @@ def test_demo_checkpoint():
 @pytest.mark.parametrize("cfg,B,p,nb", [(ENC, 2, 0.25, 2), (cfg_dict(32, 4, 16, 3), 2, 0.0, 2), (ENCDEC, 2, 0.2, 2), (cfg_dict(32, 2, 16, 1, 1), 1, 0.0, 2),
                                         (cfg_dict(32, 4, 16, 1), 2, 0.1, 1)])
 def test_bucketed_backward(cfg, B, p, nb):
-    parity.check_bucketed_backward("emu", cfg, B, p, nb, exact=True)
+    parity.check_bucketed_backward("emu", cfg, B, p, nb, exact=True, seq=False)      # (two buckets: the one-kernel-per-op path)
 
 
 # ---- bf16 operand path (gt_config.precision = 1) ---------------------------------------------------------------------------
@@ -77,7 +77,7 @@ def test_train_step_bf16_operands():
 
 
 def test_bucketed_backward_bf16_operands():
-    parity.check_bucketed_backward("emu", dict(ENC, precision=1), 2, 0.25, 2, exact=True)
+    parity.check_bucketed_backward("emu", dict(ENC, precision=1), 2, 0.25, 2, exact=True)      # (bf16: never the sequence-resident path)
 
 
 def test_predict_bf16_operands():
@@ -131,3 +131,32 @@ def test_gather_and_voice_metrics_kernels():
         cols = slice(9 * g, 9 * g + 9)
         per = (pred[:, cols] == gt[:, cols]).mean(0) if g == 0 else ((pred[:, cols] - gt[:, cols]) ** 2).mean(0)
         assert np.abs(out[base + 1:base + 10] - per).max() < 1e-6 and abs(out[base] - per.mean()) < 1e-6
+
+
+# ---- sequence-resident kernels (gt_seq.h): one workgroup per sequence runs the whole forward / backward.  They are the default
+# for the small encoder-only models they support, so the tests above already go through them where they apply; here the shapes
+# that exercise every branch (head_dim < 16 / 16 / 32 / 64, odd head count, F up to 512, S = 27, d_model 16 / 32 / 48 / 64),
+# and the same small models on the one-kernel-per-op path (gt_set_seq(0)) ------------------------------------------------------
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(32, 4, 16, 3), 2, 0.18),                        # testing YAML shape (3 of its 6 layers)
+                                     (cfg_dict(32, 16, 512, 1), 1, 0.24),                      # ClosedHH YAML: head_dim 2, F 512
+                                     (cfg_dict(64, 4, 64, 2), 1, 0.1),                         # head_dim 16
+                                     (cfg_dict(64, 2, 32, 1, embedding_size_src=27), 2, 0.0),  # head_dim 32, symbolic input
+                                     (cfg_dict(64, 1, 16, 1), 1, 0.2),                         # head_dim 64, one head (idle wave pair)
+                                     (cfg_dict(48, 3, 48, 2), 2, 0.15),                        # odd head count, d_model 48
+                                     (cfg_dict(16, 2, 16, 1, embedding_size_src=5), 1, 0.0)])
+def test_sequence_resident_kernels(cfg, B, p):
+    parity.check_step("emu", cfg, B, p)
+
+
+def test_sequence_resident_train_step_and_predict():
+    parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.2)
+    parity.check_bucketed_backward("emu", cfg_dict(32, 4, 16, 2), 2, 0.25, 1, exact=True)      # one bucket: the backward is one launch
+    parity.check_predict("emu", cfg_dict(32, 4, 16, 2), 2, True)
+
+
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 3, 0.25), (SYM, 1, 0.0), (cfg_dict(64, 4, 64, 1), 1, 0.1)])
+def test_small_models_on_the_one_kernel_per_op_path(cfg, B, p):
+    parity.check_step("emu", cfg, B, p, seq=False)
+    if cfg is ENC:
+        parity.check_train_step("emu", cfg, 2, 0.2, seq=False)
+        parity.check_bucketed_backward("emu", cfg, 2, 0.25, 2, exact=True, seq=False)

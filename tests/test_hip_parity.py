@@ -47,10 +47,12 @@ def test_step_parity_large_batches(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 
 
-@pytest.mark.parametrize("cfg,B,p,nb", [(C2, 64, 0.24, 2), (C3, 4, 0.3, 2), (C1, 32, 0.18, 2), (cfg_dict(128, 4, 512, 1), 8, 0.1, 1)])
-def test_bucketed_backward(cfg, B, p, nb):
-    """data-parallel overlap: the first half of a bucketed backward leaves bucket 0 final, both halves equal the whole"""
-    parity.check_bucketed_backward("hip", cfg, B, p, nb, exact=False)
+@pytest.mark.parametrize("cfg,B,p,nb,seq", [(C2, 64, 0.24, 2, True), (C3, 4, 0.3, 2, True), (C1, 32, 0.18, 2, False), (C1, 32, 0.18, 1, True),
+                                            (cfg_dict(128, 4, 512, 1), 8, 0.1, 1, True)])
+def test_bucketed_backward(cfg, B, p, nb, seq):
+    """data-parallel overlap: the first half of a bucketed backward leaves bucket 0 final, both halves equal the whole
+    (sequence-resident path: the backward is one launch, hence one bucket)"""
+    parity.check_bucketed_backward("hip", cfg, B, p, nb, exact=False, seq=seq)
 
 
 def test_train_step_row_chain_kernels():
@@ -170,6 +172,25 @@ def test_bucketed_backward_bf16_operands():
 def test_predict_bf16_operands():
     parity.check_predict("hip", dict(C2, precision=1), 16, True, out_tol=1e-2, margin_tol=5e-3)
     parity.check_predict("hip", dict(ENCDEC, precision=1), 4, True, out_tol=1e-2, margin_tol=5e-3)
+
+
+# ---- sequence-resident kernels (gt_seq.h): the default for small encoder-only models, so ENC / C1 / YAML_HH / SYM above already run
+# on them; here the remaining branches at real batch sizes, and the same models on the one-kernel-per-op path ------------------
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(64, 4, 64, 2), 16, 0.1), (cfg_dict(64, 2, 32, 2, embedding_size_src=27), 8, 0.2),
+                                     (cfg_dict(64, 1, 16, 1), 4, 0.2), (cfg_dict(48, 3, 48, 2), 5, 0.15), (cfg_dict(32, 16, 512, 6), 16, 0.24),
+                                     (cfg_dict(16, 2, 16, 1, embedding_size_src=5), 3, 0.0), (cfg_dict(32, 4, 16, 6), 64, 0.18)])
+def test_sequence_resident_kernels(cfg, B, p):
+    parity.check_step("hip", cfg, B, p)
+
+
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 5, 0.25), (C1, 32, 0.18), (YAML_HH, 16, 0.24), (SYM, 3, 0.1)])
+def test_small_models_on_the_one_kernel_per_op_path(cfg, B, p):
+    parity.check_step("hip", cfg, B, p, seq=False)
+
+
+def test_sequence_resident_train_step():
+    parity.check_train_step("hip", C1, 32, 0.18)
+    parity.check_train_step("hip", ENC, 4, 0.2, seq=False)
 
 
 def test_errors_are_reported():

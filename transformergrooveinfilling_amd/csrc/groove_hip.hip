@@ -20,6 +20,7 @@
 #include "gt_common.h"
 #include "gt_gemm.h"
 #include "gt_misc.h"
+#include "gt_seq.h"
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -184,7 +185,7 @@ struct LayerW {
 struct WLayout {
   int64_t x0, a0, enc_xhat, enc_rstd, memory, y0, b0, dec_xhat, dec_rstd, dec_final;
   std::vector<LayerW> layers;                        // encoder layers then decoder layers
-  int64_t hvo_tmp, dlogits, loss_part, dctx, dmem, da0_dec, ln_part, ln_part_stride, total;
+  int64_t hvo_tmp, dlogits, loss_part, dctx, dmem, da0_dec, ln_part, ln_part_stride, total, stamps = 0;
   struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; };
   std::vector<TmpSet> set;                           // 2 alternating sets, or one per layer (wgrad_deferred)
 };
@@ -246,6 +247,9 @@ static WLayout ws_layout(const gt_config& c) {
     if (c.n_dec_layers > 0) { t.dzC = add(M * d); t.dzCm = add(M * d); t.dqkvx = add(M * 3 * d); }
     else { t.dzC = t.dzCm = t.dqkvx = -1; }
   }
+#ifdef GT_SEQ_STAMPS
+  W.stamps = add(2048);
+#endif
   W.total = cur;
   return W;
 }
@@ -266,6 +270,9 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   else if (n == "memory") set(W.memory, M * d); else if (n == "y0") set(W.y0, M * d); else if (n == "b0") set(W.b0, M * d);
   else if (n == "dec_final") set(W.dec_final, M * d); else if (n == "dlogits") set(W.dlogits, M * GT_TGT);
   else if (n == "dmem") set(W.dmem, M * d); else if (n == "dctx") set(W.dctx, M * d);
+#ifdef GT_SEQ_STAMPS
+  else if (n == "stamps") set(W.stamps, 2048);
+#endif
   else if (n == "dzA" || n == "dzAm" || n == "dzB" || n == "dzBm" || n == "dzC" || n == "dzCm" || n == "dhid" || n == "dqkv" || n == "dqkvx") {
     // backward temporaries of one layer (kept per layer while the weight gradients are deferred to the end of backward)
     if (layer < 0 || layer >= (int)W.layers.size()) return gt_fail("gt_ws_find: layer %d out of range", layer);
@@ -625,9 +632,10 @@ static int self_attn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const f
                        lsite(gl, GT_SITE_DROP1));
 }
 
-static bool use_chain(const Ctx& x) { return x.c.n_dec_layers == 0 && chain_supported(x.d, x.F) && chain_enabled(x.d, x.F); }
+static bool use_seq(const gt_config& c);
+static bool use_chain(const Ctx& x) { return !use_seq(x.c) && x.c.n_dec_layers == 0 && chain_supported(x.d, x.F) && chain_enabled(x.d, x.F); }
 static bool chain_path_for(const gt_config& c) {
-  return c.precision == 0 && c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff) && chain_enabled(c.d_model, c.dim_ff);
+  return !use_seq(c) && c.precision == 0 && c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff) && chain_enabled(c.d_model, c.dim_ff);
 }
 
 template <typename Args>
@@ -669,6 +677,61 @@ static int encoder_fwd_chain(const Ctx& x, const float* pe, const float* src) {
     const double fl = 2.0 * x.M * ((double)d * d + 2.0 * d * x.F + (l == L - 1 ? 0.0 : 3.0 * d * d));
     gt_prof_tag("chain_fwd", fl, 4.0 * x.M * (6.0 * d + x.F));
     chain_launch(chain_fwd_kernel<64>, chain_fwd_kernel<128>, chain_fwd_kernel<256>, x, a);
+  }
+  return 0;
+}
+
+// ---- sequence-resident kernels (gt_seq.h): one workgroup per sequence walks the whole encoder -------------------------------
+// Default for the small encoder-only models they support; GT_SEQ=0 / gt_set_seq(0) switches them off.
+static int g_seq = -1;
+extern "C" int gt_set_seq(int on) { g_seq = on != 0; return 0; }
+static bool seq_supported(const gt_config& c) {
+  const int hd = c.d_model / c.n_heads;
+  return c.n_dec_layers == 0 && c.precision == 0 && c.d_model % 16 == 0 && c.d_model <= 64 && c.dim_ff % 16 == 0 &&
+         c.dim_ff <= GT_SEQ_FMAX && c.src_dim <= 32 && (hd < 16 || hd == 16 || hd == 32 || hd == 64);
+}
+static bool use_seq(const gt_config& c) {
+  if (g_seq < 0) { const char* e = getenv("GT_SEQ"); g_seq = (e && e[0] == '0') ? 0 : 1; }
+  return g_seq && seq_supported(c) && !(g_chain == 1);       // an explicit gt_set_chain(1) / GT_CHAIN=1 keeps the row-chain kernels
+}
+static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hvo) {
+  SeqArgs a;
+  memset(&a, 0, sizeof(a));
+  a.prm = x.prm; a.ws = x.ws; a.pe = pe; a.xin = src; a.hvo = hvo;
+  a.B = x.c.batch; a.S = x.c.src_dim; a.d = x.d; a.F = x.F; a.H = x.H; a.L = x.c.n_enc_layers; a.hd = x.hd;
+  a.st = x.drop ? x.st : nullptr; a.thr = x.drop ? (uint32_t)(x.c.dropout * 16777216.0f) : 0u;
+  a.dscale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
+  const LayerP& p = x.P.enc[0];
+  a.p0 = SeqLayerP{p.sa.in_w, p.sa.in_b, p.sa.out_w, p.sa.out_b, p.w1, p.b1, p.w2, p.b2, p.n1w, p.n1b, p.n2w, p.n2b};
+  a.pstride = x.c.n_enc_layers > 1 ? x.P.enc[1].sa.in_w - p.sa.in_w : 0;
+  const LayerW& w = x.W.layers[0];
+  a.w0 = SeqLayerW{w.qkv, w.P, w.ctx, w.xhat1, w.rstd1, w.x1, w.hact, w.xhat2, w.rstd2, w.xout};
+  a.wstride = x.c.n_enc_layers > 1 ? x.W.layers[1].qkv - w.qkv : 0;
+  const WLayout::TmpSet& t = x.W.set[0];
+  a.t0 = SeqTmp{t.dzA, t.dzAm, t.dzB, t.dzBm, t.dhid, t.dqkv};
+  a.tstride = x.W.set.size() > 1 ? x.W.set[1].dzA - t.dzA : 0;
+  a.in_w = x.P.in_w; a.in_b = x.P.in_b; a.encn_w = x.P.encn_w; a.encn_b = x.P.encn_b; a.out_w = x.P.out_w; a.out_b = x.P.out_b;
+  a.x0 = x.W.x0; a.a0 = x.W.a0; a.memory = x.W.memory; a.enc_xhat = x.W.enc_xhat; a.enc_rstd = x.W.enc_rstd;
+  a.dlogits = x.W.dlogits; a.da0 = x.W.dctx; a.ln_part = x.W.ln_part; a.ln_part_stride = x.W.ln_part_stride;
+  a.stamps = x.W.stamps;
+  return a;
+}
+// the whole forward (input layer ... output heads) of every sequence: ONE launch
+static int seq_forward(const Ctx& x, const float* pe, const float* src, float* hvo_out) {
+  const SeqArgs a = mk_seq(x, pe, src, hvo_out);
+  const double fl = 2.0 * x.M * ((double)x.c.src_dim * x.d + x.c.n_enc_layers * (4.0 * x.d * x.d + 64.0 * x.d + 2.0 * x.d * x.F) + 27.0 * x.d);
+  gt_prof_tag("seq_fwd", fl, 4.0 * x.M * (x.c.src_dim + x.c.n_enc_layers * (9.0 * x.d + x.F) + 27.0));
+  const dim3 grid(x.c.batch), block(GT_SEQ_NT);
+  const int hc = x.hd < 16 ? 0 : x.hd;             // head-dim class (one instantiation each: the attention bodies' registers differ 4x)
+  if (x.d <= 32) {
+    if (hc == 0) gt_launch(seq_fwd_kernel<32, 0>, grid, block, x.s, a);
+    else if (hc == 16) gt_launch(seq_fwd_kernel<32, 16>, grid, block, x.s, a);
+    else gt_launch(seq_fwd_kernel<32, 32>, grid, block, x.s, a);
+  } else {
+    if (hc == 0) gt_launch(seq_fwd_kernel<64, 0>, grid, block, x.s, a);
+    else if (hc == 16) gt_launch(seq_fwd_kernel<64, 16>, grid, block, x.s, a);
+    else if (hc == 32) gt_launch(seq_fwd_kernel<64, 32>, grid, block, x.s, a);
+    else gt_launch(seq_fwd_kernel<64, 64>, grid, block, x.s, a);
   }
   return 0;
 }
@@ -781,6 +844,10 @@ extern "C" int gt_forward(const gt_config* cfg, const float* params, const float
   if (make_ctx(x, cfg, params, nullptr, ws, state, train, stream)) return -1;
   if (!pe || !xin || !hvo_out) return gt_fail("gt_forward: pe / x / hvo_out must not be NULL");
   if (cfg->n_dec_layers > 0 && !tgt_in) return gt_fail("gt_forward: encoder-decoder model needs tgt_in");
+  if (use_seq(*cfg)) {
+    seq_forward(x, pe, xin, hvo_out);
+    return launch_status("gt_forward");
+  }
   if (encoder_fwd(x, pe, xin)) return -1;
   if (cfg->n_dec_layers > 0 && decoder_fwd(x, pe, tgt_in)) return -1;
   output_layer_fwd(x, hvo_out);
@@ -847,7 +914,7 @@ static GradSplit grad_split(const gt_config& c, const PLayout& P) {
   int64_t cut = 0;
   if (c.n_dec_layers > 0) { cut = P.din_w; g.split_layer = c.n_enc_layers; }
   else if (c.n_enc_layers >= 2) { g.split_layer = c.n_enc_layers / 2; cut = P.enc[g.split_layer].sa.in_w; }
-  if (cut > 0 && !chain_path_for(c)) {
+  if (cut > 0 && !chain_path_for(c) && !use_seq(c)) {
     g.nb = 2; g.off[0] = cut; g.cnt[0] = P.total - cut; g.off[1] = 0; g.cnt[1] = cut;
   }
   return g;
@@ -903,6 +970,49 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     return launch_status("gt_backward");
   };
 
+  if (use_seq(*cfg)) {
+    // ---- sequence-resident path (gt_seq.h): the whole backward chain of every sequence in ONE launch; the weight gradients
+    // (contractions over all sequences) and the LayerNorm parameter gradients leave as the grouped dispatch / the reduce
+    x.side = nullptr;
+    if (d_hvo != nullptr) {
+      gt_prof_tag("heads_bwd", 0, 12.0 * M * GT_TGT);
+      gt_launch(heads_bwd_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, d_hvo, hvo, ws + W.dlogits, M * GT_TGT);
+    }
+    // LayerNorm jobs in the order the kernel fills their partial blocks (one [2][d] row per sequence)
+    bool ok = ln_job(x, P.encn_w, cfg->batch) != nullptr;
+    for (int j = L - 1; j >= 0; --j) ok = ok && ln_job(x, P.enc[j].n2w, cfg->batch) && ln_job(x, P.enc[j].n1w, cfg->batch);
+    if (!ok) return gt_fail("too many LayerNorm instances for the partials table");
+    {
+      const SeqArgs a = mk_seq(x, nullptr, xin, nullptr);
+      const double fl = 4.0 * M * ((double)cfg->src_dim * d * 0 + L * (4.0 * d * d + 64.0 * d + 2.0 * d * x.F) + 27.0 * d);
+      gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
+      const dim3 grid(cfg->batch), block(GT_SEQ_NT);
+      const int hc = x.hd < 16 ? 0 : x.hd;
+      if (d <= 32) {
+        if (hc == 0) gt_launch(seq_bwd_kernel<32, 0>, grid, block, x.s, a);
+        else if (hc == 16) gt_launch(seq_bwd_kernel<32, 16>, grid, block, x.s, a);
+        else gt_launch(seq_bwd_kernel<32, 32>, grid, block, x.s, a);
+      } else {
+        if (hc == 0) gt_launch(seq_bwd_kernel<64, 0>, grid, block, x.s, a);
+        else if (hc == 16) gt_launch(seq_bwd_kernel<64, 16>, grid, block, x.s, a);
+        else if (hc == 32) gt_launch(seq_bwd_kernel<64, 32>, grid, block, x.s, a);
+        else gt_launch(seq_bwd_kernel<64, 64>, grid, block, x.s, a);
+      }
+    }
+    wgrad(x, ws + W.dlogits, GT_TGT, ws + W.memory, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
+    for (int j = L - 1; j >= 0; --j) {
+      const LayerP& p = P.enc[j];
+      const LayerW& w = W.layers[j];
+      const Tmp t = tmp_set(x, j);
+      const float* lin = (j == 0) ? ws + W.x0 : ws + W.layers[j - 1].xout;
+      wgrad(x, t.dzAm, d, ws + w.hact, x.F, grads + p.w2, grads + p.b2, d, x.F);
+      wgrad(x, t.dhid, x.F, ws + w.x1, d, grads + p.w1, grads + p.b1, x.F, d);
+      wgrad(x, t.dzBm, d, ws + w.ctx, d, grads + p.sa.out_w, grads + p.sa.out_b, d, d);
+      wgrad(x, t.dqkv, 3 * d, lin, d, grads + p.sa.in_w, grads + p.sa.in_b, 3 * d, d);
+    }
+    wgrad(x, ws + W.dctx, d, xin, cfg->src_dim, grads + P.in_w, grads + P.in_b, d, cfg->src_dim);
+    return finish();
+  }
   if (use_chain(x)) {
     // ---- row-chain path: per layer ONE chain launch + ONE attention-backward launch; every weight gradient of the
     // step is deferred to grouped dispatches at the end (their inputs are kept per layer in the workspace).

@@ -200,13 +200,15 @@ __device__ __forceinline__ float attn_ld1(const float* p, int col, int hd, const
   if (!PAD) return *p;
   return *(col < hd ? p : zp);
 }
+// (body: one (sequence, head) pair `bh`, query tile `ti` (0 / 1) per wave -- the stand-alone kernel runs it with 2 waves per
+//  workgroup, the sequence-resident kernels of gt_seq.h with wave pairs of a 4-wave workgroup)
 template <int HD, bool PAD>
-__global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const int bh, const int ti, const int lane) {
   constexpr int NQ = HD / 16;
   const int hdr = PAD ? a.hd : HD;               // real head_dim (PAD: < 16, operands zero-padded to 16 columns)
   const float* const zp = gt_zero_ptr();
-  const int lane = threadIdx.x & 63, ti = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int b = bh / a.H, h = bh % a.H;
   const int i = 16 * ti + l16;                                   // this lane's query row
   const float* qrow = a.q + (size_t)(b * 32 + i) * a.ldq + h * hdr + 4 * g;
   const float* krow = a.k + (size_t)(b * 32 + l16) * a.ldk + h * hdr + 4 * g;      // key tile 0; tile 1 = + 16 rows
@@ -283,23 +285,28 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
     for (int r = 0; r < 4; ++r) { if (!PAD || 16 * ct + l16 < hdr) orow[(size_t)r * a.ldc + 16 * ct] = o[ct][r]; }
 }
 
+template <int HD, bool PAD>
+__global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
+  attn_fwd_mfma_body<HD, PAD>(a, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63);
+}
+
 // Backward.  Each wave plays two roles, because dq contracts over keys and dk / dv contract over queries:
 //   role 1 (query tile w, S^T layout as above): dPd^T = V dO^T, dS in registers -> dq rows of tile w;  row sums
 //           rd[i] = sum_j dP P go through 32 floats of LDS so that role 2 can read the other wave's rows;
 //   role 2 (key tile w, S layout: lane holds X[i = 16 ti + 4g + r][j = l16]): dPd = dO V^T, P reloaded in this layout,
 //           (P*mask) and dS are then the A operands (A[m = j][k = i]) of  dv = (P*mask)^T dO  and  dk = dS^T q.
+// (two bodies with a workgroup barrier between them -- srd, 32 floats of LDS per (sequence, head), carries the row sums)
 template <int HD, bool PAD>
-__global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const int bh, const int w, const int lane, float* srd,
+                                                    f32x4 (&dq_out)[HD / 16]) {
   constexpr int NQ = HD / 16;
   const int hdr = PAD ? a.hd : HD;
   const float* const zp = gt_zero_ptr();
-  __shared__ float srd[32];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int b = bh / a.H, h = bh % a.H;
   const uint32_t dkey = gt_drop_key(a.drop);
   const size_t row0 = (size_t)b * 32;
   const int hc = h * hdr;
-  f32x4 dq_out[NQ];
 
   // ---------------------------------------------------------------- role 1: query tile w
   {
@@ -362,8 +369,18 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct) dq_out[ct] = o[ct];
   }
-  __syncthreads();
-
+}
+template <int HD, bool PAD>
+__device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const int bh, const int w, const int lane, const float* srd,
+                                                    const f32x4 (&dq_out)[HD / 16]) {
+  constexpr int NQ = HD / 16;
+  const int hdr = PAD ? a.hd : HD;
+  const float* const zp = gt_zero_ptr();
+  const int l16 = lane & 15, g = lane >> 4;
+  const int b = bh / a.H, h = bh % a.H;
+  const uint32_t dkey = gt_drop_key(a.drop);
+  const size_t row0 = (size_t)b * 32;
+  const int hc = h * hdr;
   // ---------------------------------------------------------------- role 2: key tile w
   {
     const int j = 16 * w + l16;
@@ -433,6 +450,15 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
         dkrow[(size_t)r * a.lddk + 16 * ct] = ok[ct][r];
       }
   }
+}
+template <int HD, bool PAD>
+__global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
+  __shared__ float srd[32];
+  f32x4 dq_out[HD / 16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  attn_bwd_mfma_role1<HD, PAD>(a, blockIdx.x, w, lane, srd, dq_out);
+  __syncthreads();
+  attn_bwd_mfma_role2<HD, PAD>(a, blockIdx.x, w, lane, srd, dq_out);
 }
 
 
