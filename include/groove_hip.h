@@ -180,10 +180,11 @@ int gt_set_overlap(int on);
  * automatically only where they win -- d_model <= 64 and dim_feedforward <= 64.  on = 1 forces them wherever supported,
  * on = 0 switches them off (env GT_CHAIN=1 / GT_CHAIN=0 do the same).  Results are the same on both paths. */
 int gt_set_chain(int on);
-/* Sequence-resident kernels (csrc/gt_seq.h): for encoder-only fp32 models with d_model <= 64 (% 16), dim_feedforward <= 512
+/* Sequence-resident kernels (csrc/gt_seq.h): for encoder-only fp32 models with d_model <= 128 (% 16), dim_feedforward <= 512
  * (% 16), src_dim <= 32 and head_dim 16 / 32 / 64 or below 16, ONE workgroup per sequence runs the whole forward (and one the
- * whole backward) in a single launch.  Default on where supported (env GT_SEQ=0 or on = 0 switches them off; gt_set_chain(1)
- * takes precedence).  Same results as the other paths to fp32 rounding. */
+ * whole backward) in a single launch; a train step is 7-8 launches.  Default (neither this call nor env GT_SEQ): used where they
+ * win -- d_model <= 64 always, d_model <= 128 from batch 64 up.  on = 1 forces them wherever supported, on = 0 switches them off
+ * (env GT_SEQ=1 / GT_SEQ=0 do the same; gt_set_chain(1) takes precedence).  Same results as the other paths to fp32 rounding. */
 int gt_set_seq(int on);
 int gt_profile_report(char* buf, size_t buf_len, int max_rows);
 

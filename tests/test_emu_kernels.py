@@ -135,7 +135,7 @@ def test_gather_and_voice_metrics_kernels():
 
 # ---- sequence-resident kernels (gt_seq.h): one workgroup per sequence runs the whole forward / backward.  They are the default
 # for the small encoder-only models they support, so the tests above already go through them where they apply; here the shapes
-# that exercise every branch (head_dim < 16 / 16 / 32 / 64, odd head count, F up to 512, S = 27, d_model 16 / 32 / 48 / 64),
+# that exercise every branch (head_dim < 16 / 16 / 32 / 64, odd head count, F up to 512, S = 27, d_model 16 ... 128),
 # and the same small models on the one-kernel-per-op path (gt_set_seq(0)) ------------------------------------------------------
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(32, 4, 16, 3), 2, 0.18),                        # testing YAML shape (3 of its 6 layers)
                                      (cfg_dict(32, 16, 512, 1), 1, 0.24),                      # ClosedHH YAML: head_dim 2, F 512
@@ -143,7 +143,11 @@ def test_gather_and_voice_metrics_kernels():
                                      (cfg_dict(64, 2, 32, 1, embedding_size_src=27), 2, 0.0),  # head_dim 32, symbolic input
                                      (cfg_dict(64, 1, 16, 1), 1, 0.2),                         # head_dim 64, one head (idle wave pair)
                                      (cfg_dict(48, 3, 48, 2), 2, 0.15),                        # odd head count, d_model 48
-                                     (cfg_dict(16, 2, 16, 1, embedding_size_src=5), 1, 0.0)])
+                                     (cfg_dict(16, 2, 16, 1, embedding_size_src=5), 1, 0.0),
+                                     (cfg_dict(128, 4, 512, 2), 1, 0.24),                      # the headline shape (2 of its 3 layers)
+                                     (cfg_dict(128, 16, 48, 1), 1, 0.1),                       # d_model class 128, head_dim 8
+                                     (cfg_dict(96, 6, 80, 1, embedding_size_src=27), 1, 0.1),  # d_model 96: five idle column tiles
+                                     (cfg_dict(128, 2, 32, 1), 1, 0.0)])                       # head_dim 64
 def test_sequence_resident_kernels(cfg, B, p):
     parity.check_step("emu", cfg, B, p)
 

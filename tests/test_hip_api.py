@@ -164,8 +164,8 @@ def test_engine_bucketed_data_parallel_sequence_matches_fused_step():
     import socket
     import torch.distributed as dist
     from transformergrooveinfilling_amd.engine import StepEngine
-    # (d_model 128: one kernel per op -- the sequence-resident kernels of smaller models run the backward as ONE launch, one bucket)
-    dims = dict(d_model=128, n_heads=4, dim_feedforward=128, num_encoder_layers=3, num_decoder_layers=0, dropout=0.2, embedding_size_src=16)
+    # (d_model 256: one kernel per op -- the sequence-resident kernels of smaller models run the backward as ONE launch, one bucket)
+    dims = dict(d_model=256, n_heads=4, dim_feedforward=128, num_encoder_layers=3, num_decoder_layers=0, dropout=0.2, embedding_size_src=16)
     x, y = ng.synthetic_batch(8, 16, seed=4)
     outs = []
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()

@@ -47,7 +47,7 @@ def test_step_parity_large_batches(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 
 
-@pytest.mark.parametrize("cfg,B,p,nb,seq", [(C2, 64, 0.24, 2, True), (C3, 4, 0.3, 2, True), (C1, 32, 0.18, 2, False), (C1, 32, 0.18, 1, True),
+@pytest.mark.parametrize("cfg,B,p,nb,seq", [(C2, 64, 0.24, 2, False), (C2, 64, 0.24, 1, True), (C3, 4, 0.3, 2, True), (C1, 32, 0.18, 2, False), (C1, 32, 0.18, 1, True),
                                             (cfg_dict(128, 4, 512, 1), 8, 0.1, 1, True)])
 def test_bucketed_backward(cfg, B, p, nb, seq):
     """data-parallel overlap: the first half of a bucketed backward leaves bucket 0 final, both halves equal the whole
@@ -178,12 +178,14 @@ def test_predict_bf16_operands():
 # on them; here the remaining branches at real batch sizes, and the same models on the one-kernel-per-op path ------------------
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(64, 4, 64, 2), 16, 0.1), (cfg_dict(64, 2, 32, 2, embedding_size_src=27), 8, 0.2),
                                      (cfg_dict(64, 1, 16, 1), 4, 0.2), (cfg_dict(48, 3, 48, 2), 5, 0.15), (cfg_dict(32, 16, 512, 6), 16, 0.24),
-                                     (cfg_dict(16, 2, 16, 1, embedding_size_src=5), 3, 0.0), (cfg_dict(32, 4, 16, 6), 64, 0.18)])
+                                     (cfg_dict(16, 2, 16, 1, embedding_size_src=5), 3, 0.0), (cfg_dict(32, 4, 16, 6), 64, 0.18),
+                                     (cfg_dict(128, 4, 512, 3), 64, 0.24), (cfg_dict(128, 16, 48, 2), 7, 0.1),
+                                     (cfg_dict(96, 6, 80, 2, embedding_size_src=27), 9, 0.1), (cfg_dict(128, 2, 32, 1), 3, 0.0)])
 def test_sequence_resident_kernels(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 
 
-@pytest.mark.parametrize("cfg,B,p", [(ENC, 5, 0.25), (C1, 32, 0.18), (YAML_HH, 16, 0.24), (SYM, 3, 0.1)])
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 5, 0.25), (C1, 32, 0.18), (YAML_HH, 16, 0.24), (SYM, 3, 0.1), (C2, 64, 0.24)])
 def test_small_models_on_the_one_kernel_per_op_path(cfg, B, p):
     parity.check_step("hip", cfg, B, p, seq=False)
 

@@ -38,7 +38,7 @@ def run(n, seed, backend="hip", verbose=True):
             parity.check_step(backend, cfg, B, p, seed=k)
             parity.check_predict(backend, cfg, min(B, 4), True)
             # the sequence-resident kernels (csrc/gt_seq.h) run the whole backward in one launch: a single gradient bucket
-            seq = Ld == 0 and d % 16 == 0 and d <= 64 and F % 16 == 0 and F <= 512 and S <= 32 and (hd < 16 or hd in (16, 32, 64))
+            seq = Ld == 0 and d % 16 == 0 and d <= 128 and F % 16 == 0 and F <= 512 and S <= 32 and (hd < 16 or hd in (16, 32, 64))
             parity.check_bucketed_backward(backend, cfg, min(B, 8), p, 2 if (Ld or L >= 2) and not seq else 1, exact=False)
             if verbose:
                 print("ok   %-40s %.1fs" % (tag, time.time() - t0), flush=True)

@@ -44,3 +44,8 @@ for k in range(L):
     prev = st[b + 6]
     print("  layer %d: " % (L - 1 - k) + "  ".join("%s %d" % (n, c) for n, c in zip(bl, d)) + "   = %d" % sum(d))
 print("  input-layer epilogue %d" % (st[102 + 10 * L] - prev))
+
+sub = st[200:216]
+if sub[0]:
+    print(" forward layer 1 in-proj, wave 0: issue first B loads %d; then per tile [wait + MFMAs, epilogue, gap]:" % (sub[1] - sub[0]),
+          " ".join("[%d %d %d]" % (sub[3 + 3 * i] - sub[2 + 3 * i], sub[4 + 3 * i] - sub[3 + 3 * i], (sub[5 + 3 * i] - sub[4 + 3 * i]) if i < 2 else 0) for i in range(3)))

@@ -35,11 +35,14 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="index of the single shape to run")
     ap.add_argument("--no-graph", action="store_true", help="eager launches (for rocprofv3 --pmc passes)")
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=0, help="override the batch size of the selected shape")
     args = ap.parse_args()
     for i, (name, dims, B) in enumerate(SHAPES):
         if args.only >= 0 and i != args.only:
             continue
         dims = dict(dict(embedding_size_src=16), **dims)
+        if args.batch:
+            B, name = args.batch, "%s [batch %d]" % (name, args.batch)
         eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=1, use_graph=not args.no_graph, **dims)
         eng.load_named(layout.init_params(dims, seed=0))
         x, y = layout.synthetic_batch(B, dims["embedding_size_src"], seed=2)

@@ -186,6 +186,7 @@ struct WLayout {
   int64_t x0, a0, enc_xhat, enc_rstd, memory, y0, b0, dec_xhat, dec_rstd, dec_final;
   std::vector<LayerW> layers;                        // encoder layers then decoder layers
   int64_t hvo_tmp, dlogits, loss_part, dctx, dmem, da0_dec, ln_part, ln_part_stride, total, stamps = 0;
+  int64_t pack_f = -1, pack_b = -1, pack_stride = 0;   // fragment-ordered weight copies of the sequence-resident kernels (gt_seq.h)
   struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; };
   std::vector<TmpSet> set;                           // 2 alternating sets, or one per layer (wgrad_deferred)
 };
@@ -197,6 +198,7 @@ struct WLayout {
 #define GT_WGRAD_DEFER_MAX_M (1ll << 40)
 #endif
 static bool wgrad_deferred(const gt_config& c) { return (int64_t)c.batch * 32 <= GT_WGRAD_DEFER_MAX_M; }
+static bool seq_supported(const gt_config& c);
 static WLayout ws_layout(const gt_config& c) {
   WLayout W;
   int64_t cur = 0;
@@ -246,6 +248,10 @@ static WLayout ws_layout(const gt_config& c) {
     t.dhid = add(M * F); t.dqkv = add(M * 3 * d);
     if (c.n_dec_layers > 0) { t.dzC = add(M * d); t.dzCm = add(M * d); t.dqkvx = add(M * 3 * d); }
     else { t.dzC = t.dzCm = t.dqkvx = -1; }
+  }
+  if (seq_supported(c)) {
+    W.pack_stride = (int64_t)4 * d * d + (int64_t)2 * d * F;
+    W.pack_f = add(W.pack_stride * c.n_enc_layers); W.pack_b = add(W.pack_stride * c.n_enc_layers);
   }
 #ifdef GT_SEQ_STAMPS
   W.stamps = add(2048);
@@ -682,18 +688,33 @@ static int encoder_fwd_chain(const Ctx& x, const float* pe, const float* src) {
 }
 
 // ---- sequence-resident kernels (gt_seq.h): one workgroup per sequence walks the whole encoder -------------------------------
-// Default for the small encoder-only models they support; GT_SEQ=0 / gt_set_seq(0) switches them off.
+// g_seq: 0 = off (GT_SEQ=0 / gt_set_seq(0)), 1 = every supported shape (GT_SEQ=1 / gt_set_seq(1): tests), 2 = by measurement (default):
+// always at d_model <= 64 (C1 1.9x, ClosedHH YAML 1.15x over one kernel per op); at d_model <= 128 a sequence's matmuls are bound
+// by the fp32 MFMA rate of the ONE CU its workgroup runs on, so from 64 sequences per GPU up (bs 64: tie, 96: 1.18x, 192: 1.53x).
 static int g_seq = -1;
 extern "C" int gt_set_seq(int on) { g_seq = on != 0; return 0; }
 static bool seq_supported(const gt_config& c) {
   const int hd = c.d_model / c.n_heads;
-  return c.n_dec_layers == 0 && c.precision == 0 && c.d_model % 16 == 0 && c.d_model <= 64 && c.dim_ff % 16 == 0 &&
+  return c.n_dec_layers == 0 && c.precision == 0 && c.d_model % 16 == 0 && c.d_model <= 128 && c.dim_ff % 16 == 0 &&
          c.dim_ff <= GT_SEQ_FMAX && c.src_dim <= 32 && (hd < 16 || hd == 16 || hd == 32 || hd == 64);
 }
 static bool use_seq(const gt_config& c) {
-  if (g_seq < 0) { const char* e = getenv("GT_SEQ"); g_seq = (e && e[0] == '0') ? 0 : 1; }
+  if (g_seq < 0) { const char* e = getenv("GT_SEQ"); g_seq = !e ? 2 : e[0] == '0' ? 0 : 1; }
+  if (g_seq == 2 && c.d_model > 64 && c.batch < 64) return false;
   return g_seq && seq_supported(c) && !(g_chain == 1);       // an explicit gt_set_chain(1) / GT_CHAIN=1 keeps the row-chain kernels
 }
+// kernel<DP, HDC, EXACT>: d_model class 32 / 64 / 128, head-dim class 0 (< 16) / 16 / 32 / 64, d_model == DP
+#define GT_SEQ_LAUNCH_HD(K, DP, EX, hc, grid, block, s, a)                       \
+  if ((hc) == 0) gt_launch(K<DP, 0, EX>, grid, block, s, a);                      \
+  else if ((hc) == 16) gt_launch(K<DP, 16, EX>, grid, block, s, a);               \
+  else if ((hc) == 32 || (DP) == 32) gt_launch(K<DP, 32, EX>, grid, block, s, a); \
+  else gt_launch(K<(DP) == 32 ? 64 : DP, 64, EX>, grid, block, s, a);
+#define GT_SEQ_LAUNCH_DP(K, DP, dm, hc, grid, block, s, a)                                                  \
+  { if ((dm) == (DP)) { GT_SEQ_LAUNCH_HD(K, DP, true, hc, grid, block, s, a) } else { GT_SEQ_LAUNCH_HD(K, DP, false, hc, grid, block, s, a) } }
+#define GT_SEQ_DISPATCH(K, dm, hc, grid, block, s, a)                         \
+  if ((dm) <= 32) GT_SEQ_LAUNCH_DP(K, 32, dm, hc, grid, block, s, a)           \
+  else if ((dm) <= 64) GT_SEQ_LAUNCH_DP(K, 64, dm, hc, grid, block, s, a)      \
+  else GT_SEQ_LAUNCH_DP(K, 128, dm, hc, grid, block, s, a)
 static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hvo) {
   SeqArgs a;
   memset(&a, 0, sizeof(a));
@@ -714,25 +735,22 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.x0 = x.W.x0; a.a0 = x.W.a0; a.memory = x.W.memory; a.enc_xhat = x.W.enc_xhat; a.enc_rstd = x.W.enc_rstd;
   a.dlogits = x.W.dlogits; a.da0 = x.W.dctx; a.ln_part = x.W.ln_part; a.ln_part_stride = x.W.ln_part_stride;
   a.stamps = x.W.stamps;
+  a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
   return a;
 }
 // the whole forward (input layer ... output heads) of every sequence: ONE launch
 static int seq_forward(const Ctx& x, const float* pe, const float* src, float* hvo_out) {
   const SeqArgs a = mk_seq(x, pe, src, hvo_out);
   const double fl = 2.0 * x.M * ((double)x.c.src_dim * x.d + x.c.n_enc_layers * (4.0 * x.d * x.d + 64.0 * x.d + 2.0 * x.d * x.F) + 27.0 * x.d);
+  {   // fragment-ordered copies of this step's weights, for the forward and the backward kernel
+    const int64_t frags = 2 * (int64_t)x.c.n_enc_layers * x.W.pack_stride / 256;
+    gt_prof_tag("seq_pack", 0.0, 12.0 * x.c.n_enc_layers * x.W.pack_stride);
+    gt_launch(seq_pack_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), x.s, a);
+  }
   gt_prof_tag("seq_fwd", fl, 4.0 * x.M * (x.c.src_dim + x.c.n_enc_layers * (9.0 * x.d + x.F) + 27.0));
   const dim3 grid(x.c.batch), block(GT_SEQ_NT);
   const int hc = x.hd < 16 ? 0 : x.hd;             // head-dim class (one instantiation each: the attention bodies' registers differ 4x)
-  if (x.d <= 32) {
-    if (hc == 0) gt_launch(seq_fwd_kernel<32, 0>, grid, block, x.s, a);
-    else if (hc == 16) gt_launch(seq_fwd_kernel<32, 16>, grid, block, x.s, a);
-    else gt_launch(seq_fwd_kernel<32, 32>, grid, block, x.s, a);
-  } else {
-    if (hc == 0) gt_launch(seq_fwd_kernel<64, 0>, grid, block, x.s, a);
-    else if (hc == 16) gt_launch(seq_fwd_kernel<64, 16>, grid, block, x.s, a);
-    else if (hc == 32) gt_launch(seq_fwd_kernel<64, 32>, grid, block, x.s, a);
-    else gt_launch(seq_fwd_kernel<64, 64>, grid, block, x.s, a);
-  }
+  GT_SEQ_DISPATCH(seq_fwd_kernel, x.d, hc, grid, block, x.s, a)
   return 0;
 }
 
@@ -988,16 +1006,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
       gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
       const dim3 grid(cfg->batch), block(GT_SEQ_NT);
       const int hc = x.hd < 16 ? 0 : x.hd;
-      if (d <= 32) {
-        if (hc == 0) gt_launch(seq_bwd_kernel<32, 0>, grid, block, x.s, a);
-        else if (hc == 16) gt_launch(seq_bwd_kernel<32, 16>, grid, block, x.s, a);
-        else gt_launch(seq_bwd_kernel<32, 32>, grid, block, x.s, a);
-      } else {
-        if (hc == 0) gt_launch(seq_bwd_kernel<64, 0>, grid, block, x.s, a);
-        else if (hc == 16) gt_launch(seq_bwd_kernel<64, 16>, grid, block, x.s, a);
-        else if (hc == 32) gt_launch(seq_bwd_kernel<64, 32>, grid, block, x.s, a);
-        else gt_launch(seq_bwd_kernel<64, 64>, grid, block, x.s, a);
-      }
+      GT_SEQ_DISPATCH(seq_bwd_kernel, d, hc, grid, block, x.s, a)
     }
     wgrad(x, ws + W.dlogits, GT_TGT, ws + W.memory, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
     for (int j = L - 1; j >= 0; --j) {

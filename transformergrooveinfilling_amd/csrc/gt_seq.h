@@ -9,7 +9,11 @@
 //
 //   activations of the sequence   LDS: x, x1, ctx tiles [32][DP + 8], the qkv tile, the FFN tile [32][F + 8] (A operands, k contiguous)
 //   weights                       read once per workgroup, straight from L2 into MFMA B fragments (no LDS staging: every wave
-//                                 owns its output columns, so no weight element is needed twice)
+//                                 owns its output columns, so no weight element is needed twice) -- from FRAGMENT-ORDERED copies
+//                                 that seq_pack_kernel writes in front of the forward: a wave's 16-byte-per-lane load is then
+//                                 1 KB contiguous.  Loaded from the row-major matrix the same fragment is 16 rows x 64 bytes,
+//                                 and one CU pulls only 15.7 B/clk that way against 57.8 B/clk for full lines
+//                                 (tools/ubench/frag_load_bench.hip) -- at d_model 128 that, not the MFMA, set the stage time.
 //   saved for backward / tests    written to the same workspace buffers the one-kernel-per-op path uses (gt_ws_find names)
 //   attention                     transposed-score MFMA bodies (the scheme of gt_attn.h) on LDS operands, four heads at a time
 //
@@ -20,7 +24,11 @@
 // 16-byte LDS / global accesses, wave-uniform branches instead of per-lane zero-page selects, every elementwise pass spread
 // over all 512 threads (16 lanes per token row), row reductions by DPP (no LDS round trip), the dropout state fetched once.
 //
-// Supported: encoder-only, fp32 operands, d_model % 16 == 0 and <= 64, dim_feedforward % 16 == 0 and <= 512, src_dim <= 32,
+// Three instantiations by d_model class DP = 32 / 64 / 128 (d_model % 16 == 0, <= DP).  At DP 128 (the headline workload:
+// d_model 128, dim_feedforward 512) a sequence's layer is ~13 MFLOP: the matmul stages are bound by the fp32 MFMA rate of the
+// ONE CU the workgroup runs on (256 FLOP/clk), the whole step is 7 launches instead of 49.
+//
+// Supported: encoder-only, fp32 operands, d_model % 16 == 0 and <= 128, dim_feedforward % 16 == 0 and <= 512, src_dim <= 32,
 // head_dim 16 / 32 / 64 or < 16 (seq_supported in groove_hip.hip).
 #pragma once
 #include "gt_attn.h"
@@ -41,13 +49,21 @@ struct SeqArgs {
   int64_t x0, a0, memory, enc_xhat, enc_rstd, dlogits, da0;  // workspace offsets
   int64_t ln_part, ln_part_stride;                           // LayerNorm dgamma/dbeta partials: job j at ln_part + j * stride, [B][2][d]
   int64_t stamps;                                            // diagnostic builds (-DGT_SEQ_STAMPS) only: workspace offset of the stamp buffer
+  int64_t pack_f, pack_b, kstride;                           // fragment-ordered weight copies (seq_pack_kernel): workspace offsets, floats per layer
 };
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md 7): workgroup 0, thread 0 records the shader clock at stage
 // boundaries into a buffer nothing else reads.  tools/seq_stamps.py prints the per-stage cycle counts.
 #ifdef GT_SEQ_STAMPS
 #define GT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<long long*>(a.ws + a.stamps)[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+__shared__ long long* gt_sub_ptr;      // sub-stage stamps of ONE matmul stage (set around it by the stamped workgroup's thread 0)
+#define GT_SUBSTAMP(i) do { if (threadIdx.x == 0 && gt_sub_ptr) gt_sub_ptr[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define GT_SUBWAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define GT_SUBSET(on) do { if (threadIdx.x == 0) gt_sub_ptr = ((on) && blockIdx.x == 0) ? reinterpret_cast<long long*>(a.ws + a.stamps) + 200 : nullptr; } while (0)
 #else
 #define GT_STAMP(i) do { } while (0)
+#define GT_SUBSTAMP(i) do { } while (0)
+#define GT_SUBWAIT() do { } while (0)
+#define GT_SUBSET(on) do { } while (0)
 #endif
 
 // Stage hand-overs inside these kernels go through LDS only (the global stores are copies for LATER kernels: saved activations,
@@ -118,141 +134,188 @@ __device__ __forceinline__ void seq_mma(f32x4& acc0, f32x4& acc1, const float (&
   acc0 = GT_MFMA16(b[2], a0.z, acc0); acc1 = GT_MFMA16(b[2], a1.z, acc1);
   acc0 = GT_MFMA16(b[3], a0.w, acc0); acc1 = GT_MFMA16(b[3], a1.w, acc1);
 }
-// wave w owns tile w (N <= 128).  epi(n0, acc0, acc1, bias4): bias4 = bias[n0 + 4 lg + 0..3] (zeros without a bias).
-template <bool BKM, bool VEC, typename Epi>
+// wave w owns tile w (N <= 128), K <= 16 NK.  epi(n0, acc0, acc1, bias4): bias4 = bias[n0 + 4 lg + 0..3] (zeros without a bias).
+template <bool BKM, bool VEC, int NK, typename Epi>
 __device__ __forceinline__ void seq_mm_edge(const float* sA, const int lda, const int K, const float* __restrict__ W, const int ldw, const int N,
                                             const float* __restrict__ bias, const int wave, const int lane, const float* zp, Epi epi) {
   const int l16 = lane & 15, lg = lane >> 4;
   const int n0 = wave * 16;
   if (n0 >= N) return;                                   // wave-uniform
-  float b[4][4], bi[4];
+  float b[NK][4], bi[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) seq_ldb<BKM, VEC>(b[u], W, ldw, n0 + l16, N, 16 * u + 4 * lg, K, zp);
+  for (int u = 0; u < NK; ++u) { if (16 * u < K) seq_ldb<BKM, VEC>(b[u], W, ldw, n0 + l16, N, 16 * u + 4 * lg, K, zp); }
 #pragma unroll
   for (int r = 0; r < 4; ++r) bi[r] = *((bias != nullptr && n0 + 4 * lg + r < N) ? bias + n0 + 4 * lg + r : zp);
   f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { if (16 * u < K) seq_mma(acc0, acc1, b[u], sA, lda, l16, 16 * u + 4 * lg); }
+  for (int u = 0; u < NK; ++u) { if (16 * u < K) seq_mma(acc0, acc1, b[u], sA, lda, l16, 16 * u + 4 * lg); }
   epi(n0, acc0, acc1, bi);
 }
 
-// ---- B fragment of one 16-column tile, K % 16 == 0 and <= 64, N % 16 == 0: 32-bit offsets from the wave-uniform W
-template <bool BKM>
-__device__ __forceinline__ void seq_ldb_tile(float4 (&b)[4], const float* __restrict__ W, const int ldw, const int n0, const int K, const int l16,
-                                             const int lg) {
-  if (!BKM) {
-    const float* wp = W + (unsigned)((n0 + l16) * ldw + 4 * lg);
+// ---- Fragment-ordered weights.  For a product C = A * B with B(k, n) taken from a weight matrix W (forward: B(k, n) = W[n][k];
+// dgrad: B(k, n) = W[k][n]) the pack holds, for column tile t and k-step u (16 k each; nkt k-steps in the whole contraction),
+// the 64 x 4 floats lane (l16, lg) feeds to four consecutive MFMAs:  pack[((t * nkt + u) * 64 + lane) * 4 + j] = B(16 u + 4 lg + j,
+// 16 t + l16).  Both packs of a layer use one layout: [in_w | out_w | w1 | w2] at offsets 0, 3 d^2, 4 d^2, 4 d^2 + d F.
+// FULL: nk == NK is known (d_model == DP, the common case): no per-k-step branches, so the compiler can count the outstanding loads
+// (a next-tile prefetch stays in flight under the MFMAs instead of being drained by a vmcnt(0)).
+template <int NK> struct SeqB { float4 v[NK]; };
+template <int NK, bool FULL = false>
+__device__ __forceinline__ void seq_b_load(SeqB<NK>& b, const float* __restrict__ Wp, const int nkt, const int t, const int u0, const int nk,
+                                           const int lane) {
+  const float* p = Wp + (unsigned)(((t * nkt + u0) * 64 + lane) * 4);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { if (16 * u < K) b[u] = *reinterpret_cast<const float4*>(wp + 16 * u); }
-  } else {
-    const float* wp = W + (unsigned)(4 * lg * ldw + n0 + l16);
+  for (int u = 0; u < NK; ++u) { if (FULL || u < nk) b.v[u] = *reinterpret_cast<const float4*>(p + 256 * u); }
+}
+// one wave per fragment: 4 fragments per 256-thread block, 2 packs x L layers x (3 d^2 + d^2 + 2 d F) / 256 fragments
+__global__ __launch_bounds__(256) void seq_pack_kernel(SeqArgs a) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, lg = lane >> 4;
+  const int d = a.d, F = a.F, d16 = d >> 4, f16 = F >> 4;
+  const int nf0 = 3 * d16 * d16, nf1 = d16 * d16, nf2 = f16 * d16, T = nf0 + nf1 + 2 * nf2;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= 2 * a.L * T) return;
+  const int pack = g / (a.L * T), r = g % (a.L * T), l = r / T;
+  int f = r % T, R, C;
+  int64_t src, moff;
+  if (f < nf0) { src = a.p0.in_w; R = 3 * d; C = d; moff = 0; }
+  else if (f < nf0 + nf1) { f -= nf0; src = a.p0.out_w; R = d; C = d; moff = (int64_t)3 * d * d; }
+  else if (f < nf0 + nf1 + nf2) { f -= nf0 + nf1; src = a.p0.w1; R = F; C = d; moff = (int64_t)4 * d * d; }
+  else { f -= nf0 + nf1 + nf2; src = a.p0.w2; R = d; C = F; moff = (int64_t)4 * d * d + (int64_t)d * F; }
+  const float* W = a.prm + src + (int64_t)l * a.pstride;
+  float4 v;
+  if (pack == 0) {                                           // forward: B(k, n) = W[n][k], tiles over the rows of W
+    const int nkt = C >> 4, t = f / nkt, u = f % nkt;
+    v = *reinterpret_cast<const float4*>(W + (size_t)(16 * t + l16) * C + 16 * u + 4 * lg);
+  } else {                                                   // dgrad: B(k, n) = W[k][n], tiles over the columns of W
+    const int nkt = R >> 4, t = f / nkt, u = f % nkt;
+    const float* p = W + (size_t)(16 * u + 4 * lg) * C + 16 * t + l16;
+    v = make_float4(p[0], p[C], p[2 * (size_t)C], p[3 * (size_t)C]);
+  }
+  *reinterpret_cast<float4*>(a.ws + (pack ? a.pack_b : a.pack_f) + (int64_t)l * a.kstride + moff + (int64_t)f * 256 + lane * 4) = v;
+}
+// acc0 / acc1 (rows l16 / 16 + l16) += A[:, k0 .. k0 + 16 nk) * B; ap = sA + l16 * lda + k0 + 4 lg (the A fragments are re-read from
+// LDS per tile: two 16-byte reads per 8 MFMAs)
+template <int NK, bool FULL = false>
+__device__ __forceinline__ void seq_b_mma(f32x4& acc0, f32x4& acc1, const SeqB<NK>& b, const float* ap, const int lda, const int nk) {
+  if (FULL) {               // A fragments one k-step ahead of the MFMAs that use them; the fence keeps the compiler from hoisting all of them
+    float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 16 * lda);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (16 * u < K) {
-        b[u].x = wp[(unsigned)((16 * u + 0) * ldw)]; b[u].y = wp[(unsigned)((16 * u + 1) * ldw)];
-        b[u].z = wp[(unsigned)((16 * u + 2) * ldw)]; b[u].w = wp[(unsigned)((16 * u + 3) * ldw)];
-      }
+    for (int u = 0; u < NK; ++u) {
+      float4 n0 = a0, n1 = a1;
+      if (u + 1 < NK) { n0 = *reinterpret_cast<const float4*>(ap + 16 * (u + 1)); n1 = *reinterpret_cast<const float4*>(ap + 16 * lda + 16 * (u + 1)); }
+      acc0 = GT_MFMA16(b.v[u].x, a0.x, acc0); acc1 = GT_MFMA16(b.v[u].x, a1.x, acc1);
+      acc0 = GT_MFMA16(b.v[u].y, a0.y, acc0); acc1 = GT_MFMA16(b.v[u].y, a1.y, acc1);
+      acc0 = GT_MFMA16(b.v[u].z, a0.z, acc0); acc1 = GT_MFMA16(b.v[u].z, a1.z, acc1);
+      acc0 = GT_MFMA16(b.v[u].w, a0.w, acc0); acc1 = GT_MFMA16(b.v[u].w, a1.w, acc1);
+      GT_SCHED_FENCE()
+      a0 = n0; a1 = n1;
+    }
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < NK; ++u) {
+    if (FULL || u < nk) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * u), a1 = *reinterpret_cast<const float4*>(ap + 16 * lda + 16 * u);
+      acc0 = GT_MFMA16(b.v[u].x, a0.x, acc0); acc1 = GT_MFMA16(b.v[u].x, a1.x, acc1);
+      acc0 = GT_MFMA16(b.v[u].y, a0.y, acc0); acc1 = GT_MFMA16(b.v[u].y, a1.y, acc1);
+      acc0 = GT_MFMA16(b.v[u].z, a0.z, acc0); acc1 = GT_MFMA16(b.v[u].z, a1.z, acc1);
+      acc0 = GT_MFMA16(b.v[u].w, a0.w, acc0); acc1 = GT_MFMA16(b.v[u].w, a1.w, acc1);
     }
   }
+}
+// Short contraction (K % 16 == 0, <= 16 NK), N % 16 == 0: wave w owns tiles w, w + 8, ... (at most MAXT of them); the B fragment
+// of the wave's next tile is requested before the MFMAs of the current one.  epi(n0, acc0, acc1, bias float4).
+template <int NK, int MAXT, bool FULL, typename Epi>
+__device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
+                                                  const float* __restrict__ bias, const int wave, const int lane, Epi& epi) {
+  const int l16 = lane & 15, lg = lane >> 4, ntile = N >> 4, nk = K >> 4;
+  if (wave >= ntile) return;                             // wave-uniform
+  const float* ap = sA + l16 * lda + 4 * lg;
+  SeqB<NK> b[2];
+  float4 bi[2];
+  GT_SUBSTAMP(0);
+  seq_b_load<NK, FULL>(b[0], Wp, nk, wave, 0, nk, lane);
+  bi[0] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * wave + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+  GT_SUBSTAMP(1);
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t = wave + i * GT_SEQ_WAVES;
+    if (t < ntile) {
+      if (i + 1 < MAXT && t + GT_SEQ_WAVES < ntile) {
+        seq_b_load<NK, FULL>(b[(i + 1) & 1], Wp, nk, t + GT_SEQ_WAVES, 0, nk, lane);
+        bi[(i + 1) & 1] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * (t + GT_SEQ_WAVES) + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      GT_SUBSTAMP(2 + 3 * i);
+      seq_b_mma<NK, FULL>(acc0, acc1, b[i & 1], ap, lda, nk);
+#ifdef GT_SEQ_STAMPS
+      asm volatile("" : "+v"(acc0), "+v"(acc1));
+#endif
+      GT_SUBSTAMP(3 + 3 * i);
+      epi(16 * t, acc0, acc1, bi[i & 1]);
+      GT_SUBSTAMP(4 + 3 * i);
+    }
+  }
+}
+// FULL (K == 16 NK) is a property of the kernel instantiation (EXACT: d_model == DP): a run-time dispatch between the two bodies gets
+// merged back into the branchy one by the compiler.
+template <int NK, int MAXT, bool FULL, typename Epi>
+__device__ __forceinline__ void seq_mm_tiles(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
+                                             const float* __restrict__ bias, const int wave, const int lane, Epi epi) {
+  seq_mm_tiles_impl<NK, MAXT, FULL>(sA, lda, K, Wp, N, bias, wave, lane, epi);
 }
 __device__ __forceinline__ void seq_mma4(f32x4& acc, const float4& b, const float4& a) {
   acc = GT_MFMA16(b.x, a.x, acc); acc = GT_MFMA16(b.y, a.y, acc); acc = GT_MFMA16(b.z, a.z, acc); acc = GT_MFMA16(b.w, a.w, acc);
 }
-// Short contraction (K % 16 == 0, <= 64), N % 16 == 0: wave w owns tiles w, w + 8, ... (at most MAXT of them).  The A fragments
-// (both 16-row halves) are read from LDS once and reused by all tiles of the wave.  epi(n0, acc0, acc1, bias float4).
-template <bool BKM, int MAXT, typename Epi>
-__device__ __forceinline__ void seq_mm_tiles(const float* sA, const int lda, const int K, const float* __restrict__ W, const int ldw, const int N,
-                                             const float* __restrict__ bias, const int wave, const int lane, Epi epi) {
-  const int l16 = lane & 15, lg = lane >> 4, ntile = N >> 4;
-  if (wave >= ntile) return;                             // wave-uniform
-  float4 b[MAXT][4], bi[MAXT];
-#pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    const int t = wave + i * GT_SEQ_WAVES;
-    if (t < ntile) {
-      seq_ldb_tile<BKM>(b[i], W, ldw, 16 * t, K, l16, lg);
-      bi[i] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * t + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  float4 a0[4], a1[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (16 * u < K) {
-      a0[u] = *reinterpret_cast<const float4*>(sA + l16 * lda + 16 * u + 4 * lg);
-      a1[u] = *reinterpret_cast<const float4*>(sA + (16 + l16) * lda + 16 * u + 4 * lg);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    const int t = wave + i * GT_SEQ_WAVES;
-    if (t < ntile) {
-      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (16 * u < K) {
-          acc0 = GT_MFMA16(b[i][u].x, a0[u].x, acc0); acc1 = GT_MFMA16(b[i][u].x, a1[u].x, acc1);
-          acc0 = GT_MFMA16(b[i][u].y, a0[u].y, acc0); acc1 = GT_MFMA16(b[i][u].y, a1[u].y, acc1);
-          acc0 = GT_MFMA16(b[i][u].z, a0[u].z, acc0); acc1 = GT_MFMA16(b[i][u].z, a1[u].z, acc1);
-          acc0 = GT_MFMA16(b[i][u].w, a0[u].w, acc0); acc1 = GT_MFMA16(b[i][u].w, a1[u].w, acc1);
-        }
-      }
-      epi(16 * t, acc0, acc1, bi[i]);
-    }
-  }
-}
-// Square projection (N = K = d <= 64): 2 * (d / 16) <= 8 units of (column tile, 16-row half), one per wave -- the raw 16 x 16
+// Square projection at d <= 64 (N = K = d): 2 * (d / 16) <= 8 units of (column tile, 16-row half), one per wave -- the raw 16 x 16
 // results go to an LDS tile [32][srs]; bias / dropout / residual belong to the LayerNorm pass that reads it (all 512 threads).
-template <bool BKM>
-__device__ __forceinline__ void seq_mm_square(const float* sA, const int lda, const int d, const float* __restrict__ W, float* sOut, const int srs,
+__device__ __forceinline__ void seq_mm_square(const float* sA, const int lda, const int d, const float* __restrict__ Wp, float* sOut, const int srs,
                                               const int wave, const int lane) {
   const int l16 = lane & 15, lg = lane >> 4, t = wave >> 1, half = wave & 1;
   if (16 * t >= d) return;
-  float4 b[4], av[4];
-  seq_ldb_tile<BKM>(b, W, d, 16 * t, d, l16, lg);
+  SeqB<4> b;
+  float4 av[4];
+  seq_b_load<4>(b, Wp, d >> 4, t, 0, d >> 4, lane);
 #pragma unroll
   for (int u = 0; u < 4; ++u) { if (16 * u < d) av[u] = *reinterpret_cast<const float4*>(sA + (16 * half + l16) * lda + 16 * u + 4 * lg); }
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { if (16 * u < d) seq_mma4(acc, b[u], av[u]); }
+  for (int u = 0; u < 4; ++u) { if (16 * u < d) seq_mma4(acc, b.v[u], av[u]); }
   *reinterpret_cast<float4*>(sOut + (16 * half + l16) * srs + 16 * t + 4 * lg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
-// Long contraction (K % 16 == 0, up to 512) into few columns (N <= 64: NT = N / 16 <= 4 tiles): the 8 waves split K as well --
-// wave w takes tile w % NT and k-part w / NT of KS = 8 / NT parts -- and leave partial tiles in sR[part][32][srs]; the pass that
-// reads them (seq_parts_sum, inside the following LayerNorm pass) sums the parts in a fixed order, part 0 first.
-__device__ __forceinline__ int seq_splitk_parts(const int N) { return GT_SEQ_WAVES / ((N + 15) >> 4); }
-template <bool BKM>
-__device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, const int K, const float* __restrict__ W, const int ldw, const int N,
+// Long contraction (K % 16 == 0, up to 512) into N <= 128 columns (NT = N / 16 tiles): the 8 waves split K as well -- wave w takes
+// tile w % NT and k-part w / NT of KS = 8 / NT parts (NT 1, 2, 4, 8 -> KS 8, 4, 2, 1; other NT leave waves idle) -- and leave
+// partial tiles in sR[part][32][srs]; the pass that reads them (seq_parts_sum, inside the following LayerNorm pass) sums the
+// parts in a fixed order, part 0 first.  B moves in chunks of 8 k-steps, the next chunk requested before the current one's MFMAs.
+__device__ __forceinline__ int seq_splitk_parts(const int N) { return GT_SEQ_WAVES / (N >> 4); }
+__device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
                                               float* sR, const int srs, const int wave, const int lane) {
   const int l16 = lane & 15, lg = lane >> 4;
-  const int NT = N >> 4, KS = GT_SEQ_WAVES / NT;                  // NT in {1, 2, 4} -> KS in {8, 4, 2}; NT = 3 -> KS = 2 (two waves idle)
+  const int NT = N >> 4, KS = GT_SEQ_WAVES / NT;
   const int t = wave % NT, part = wave / NT;
   if (part >= KS) return;
   const int nks = K >> 4, per = (nks + KS - 1) / KS, ks0 = part * per, ks1 = (ks0 + per < nks) ? ks0 + per : nks;
   const int n0 = t * 16;
-  const float* wp = BKM ? W + (unsigned)(4 * lg * ldw + n0 + l16) : W + (unsigned)((n0 + l16) * ldw + 4 * lg);
   const float* ap = sA + l16 * lda + 4 * lg;
   f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int c0 = ks0; c0 < ks1; c0 += 8) {                          // at most 8 k-steps (128 k) per round trip; K 512 / KS 2 -> two
-    float4 b[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (c0 + u < ks1) {                                          // wave-uniform
-        const int k = 16 * (c0 + u);
-        if (!BKM) b[u] = *reinterpret_cast<const float4*>(wp + k);
-        else {
-          b[u].x = wp[(unsigned)((k + 0) * ldw)]; b[u].y = wp[(unsigned)((k + 1) * ldw)];
-          b[u].z = wp[(unsigned)((k + 2) * ldw)]; b[u].w = wp[(unsigned)((k + 3) * ldw)];
-        }
+  SeqB<8> b[2];
+  if (ks1 > ks0 && ((ks1 - ks0) & 7) == 0) {                       // whole chunks only (F and 3 d multiples of 128 per part): branch-free bodies
+    seq_b_load<8, true>(b[0], Wp, nks, t, ks0, 8, lane);
+    for (int c0 = ks0; c0 < ks1; c0 += 16) {                       // two chunks per trip: the buffer index stays compile-time
+      if (c0 + 8 < ks1) seq_b_load<8, true>(b[1], Wp, nks, t, c0 + 8, 8, lane);
+      seq_b_mma<8, true>(acc0, acc1, b[0], ap + 16 * c0, lda, 8);
+      if (c0 + 8 < ks1) {
+        if (c0 + 16 < ks1) seq_b_load<8, true>(b[0], Wp, nks, t, c0 + 16, 8, lane);
+        seq_b_mma<8, true>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, 8);
       }
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (c0 + u < ks1) {
-        const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * (c0 + u)), a1 = *reinterpret_cast<const float4*>(ap + 16 * lda + 16 * (c0 + u));
-        acc0 = GT_MFMA16(b[u].x, a0.x, acc0); acc1 = GT_MFMA16(b[u].x, a1.x, acc1);
-        acc0 = GT_MFMA16(b[u].y, a0.y, acc0); acc1 = GT_MFMA16(b[u].y, a1.y, acc1);
-        acc0 = GT_MFMA16(b[u].z, a0.z, acc0); acc1 = GT_MFMA16(b[u].z, a1.z, acc1);
-        acc0 = GT_MFMA16(b[u].w, a0.w, acc0); acc1 = GT_MFMA16(b[u].w, a1.w, acc1);
+  } else {
+    if (ks0 < ks1) seq_b_load<8>(b[0], Wp, nks, t, ks0, ks1 - ks0, lane);
+    for (int c0 = ks0; c0 < ks1; c0 += 16) {
+      if (c0 + 8 < ks1) seq_b_load<8>(b[1], Wp, nks, t, c0 + 8, ks1 - c0 - 8, lane);
+      seq_b_mma<8>(acc0, acc1, b[0], ap + 16 * c0, lda, ks1 - c0);
+      if (c0 + 8 < ks1) {
+        if (c0 + 16 < ks1) seq_b_load<8>(b[0], Wp, nks, t, c0 + 16, ks1 - c0 - 16, lane);
+        seq_b_mma<8>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, ks1 - c0 - 8);
       }
     }
   }
@@ -274,6 +337,15 @@ template <> struct SeqVec<4> {
   static __device__ __forceinline__ void ld(float (&v)[4], const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
   static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
+template <> struct SeqVec<8> {
+  static __device__ __forceinline__ void ld(float (&v)[8], const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p), u = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
 // sum of the split-K partial tiles of this thread's columns, part 0 first
 template <int CW>
 __device__ __forceinline__ void seq_parts_sum(float (&v)[CW], const float* sR, const int srs, const int parts, const int row, const int c0) {
@@ -283,6 +355,17 @@ __device__ __forceinline__ void seq_parts_sum(float (&v)[CW], const float* sR, c
     SeqVec<CW>::ld(u, sR + (p * 32 + row) * srs + c0);
 #pragma unroll
     for (int e = 0; e < CW; ++e) v[e] += u[e];
+  }
+}
+
+// a [32][ncol] LDS tile -> the sequence's rows in global memory, 16 bytes per thread and pass: every wave-instruction writes 1 KB of
+// consecutive addresses.  (The MFMA epilogues do NOT store their tiles to global themselves: a fragment-shaped store is 16 rows x
+// 64 bytes per instruction and moves ~15 B/clk per CU, like the fragment-shaped loads -- tools/ubench/frag_load_bench.hip.)
+__device__ __forceinline__ void seq_tile_out(float* __restrict__ dst, const float* sT, const int str, const int ncol, const int tid) {
+  const int q4 = ncol >> 2;
+  for (int e = tid; e < 32 * q4; e += GT_SEQ_NT) {
+    const int r = e / q4, c = (e - r * q4) * 4;
+    *reinterpret_cast<float4*>(dst + (unsigned)(r * ncol + c)) = *reinterpret_cast<const float4*>(sT + r * str + c);
   }
 }
 
@@ -491,7 +574,8 @@ __device__ __forceinline__ void seq_attn_fwd(const SeqAttn& a, float* ctx, const
 }
 
 // Backward, two roles per wave with a workgroup barrier between them (gt_attn.h): role 1 (query tile w) -> dq in registers and
-// the row sums rd -> srd (32 floats of LDS per head); role 2 (key tile w) -> dk, dv, and the dq / dk / dv stores into the dqkv tile.
+// the row sums rd -> srd (32 floats of LDS per head); role 2 (key tile w) -> dk, dv in registers; after another barrier
+// seq_attn_bwd_store writes dq / dk / dv over q / k / v of the head (the dqkv tile IS the qkv tile).
 template <int HD, bool PAD>
 __device__ __forceinline__ void seq_attn_bwd1(const SeqAttn& a, const float* dctx, const int lddc, const SeqDropK& dk, const uint32_t key,
                                               const int w, const int lane, float* srd, f32x4 (&dq_out)[HD / 16]) {
@@ -556,8 +640,7 @@ __device__ __forceinline__ void seq_attn_bwd1(const SeqAttn& a, const float* dct
 }
 template <int HD, bool PAD>
 __device__ __forceinline__ void seq_attn_bwd2(const SeqAttn& a, const float* dctx, const int lddc, const SeqDropK& dk, const uint32_t key,
-                                              const int w, const int lane, const float* srd, const f32x4 (&dq_out)[HD / 16], float* dq,
-                                              const int lddq, const int dstep) {
+                                              const int w, const int lane, const float* srd, f32x4 (&dk_out)[HD / 16], f32x4 (&dv_out)[HD / 16]) {
   constexpr int NQ = HD / 16;
   const int hdr = PAD ? a.hd : HD;
   const int l16 = lane & 15, g = lane >> 4;
@@ -610,39 +693,56 @@ __device__ __forceinline__ void seq_attn_bwd2(const SeqAttn& a, const float* dct
       pdm[ti][r] = pvv[ti][r] * mk;
       ds[ti][r] = pvv[ti][r] * (dd[ti][r] * mk - rdv[ti][r]) * a.scale;
     }
-  f32x4 ov[NQ], ok[NQ];
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct) {
-    ov[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dv_out[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dk_out[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        ov[ct] = GT_MFMA16(pdm[ti][c], db[ct][ti][c], ov[ct]);
-        ok[ct] = GT_MFMA16(ds[ti][c], qb[ct][ti][c], ok[ct]);
+        dv_out[ct] = GT_MFMA16(pdm[ti][c], db[ct][ti][c], dv_out[ct]);
+        dk_out[ct] = GT_MFMA16(ds[ti][c], qb[ct][ti][c], dk_out[ct]);
       }
   }
-  float* dqrow = dq + (16 * w + 4 * g) * lddq + l16;              // dq; dk = + dstep columns, dv = + 2 dstep
+}
+// rows 16 w + 4 g + r, columns 16 ct + l16 of the head: dq over q, dk over k (+ d columns), dv over v (+ 2 d)
+template <int HD, bool PAD>
+__device__ __forceinline__ void seq_attn_bwd_store(float* dq, const int ldq, const int d, const int hd, const int w, const int lane,
+                                                   const f32x4 (&dq_out)[HD / 16], const f32x4 (&dk_out)[HD / 16], const f32x4 (&dv_out)[HD / 16]) {
+  constexpr int NQ = HD / 16;
+  const int hdr = PAD ? hd : HD;
+  const int l16 = lane & 15, g = lane >> 4;
+  float* dqrow = dq + (16 * w + 4 * g) * ldq + l16;
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (PAD && 16 * ct + l16 >= hdr) continue;
-      dqrow[r * lddq + 16 * ct] = dq_out[ct][r];
-      dqrow[r * lddq + 16 * ct + dstep] = ok[ct][r];
-      dqrow[r * lddq + 16 * ct + 2 * dstep] = ov[ct][r];
+      dqrow[r * ldq + 16 * ct] = dq_out[ct][r];
+      dqrow[r * ldq + 16 * ct + d] = dk_out[ct][r];
+      dqrow[r * ldq + 16 * ct + 2 * d] = dv_out[ct][r];
     }
 }
 
 // ================================================================================================================ forward
-template <int DP, int HDC>
+// LDS geometry of a d_model class.  RP: most split-K parts a [32][d] result can come in (d = 16 -> 8 parts ... d > 64 -> 1).
+template <int DP> struct SeqGeo {
+  static constexpr int SX = DP + 8, SH = GT_SEQ_FMAX + 8, SQ = 3 * DP + 8, SRS = DP + 8, RP = DP == 32 ? 8 : DP == 64 ? 2 : 1, CW = DP / 16;
+  static constexpr int TILE = 32 * SX, QKV = 32 * SQ, FFN = 32 * SH, RES = RP * 32 * SRS, NK = DP / 16;
+  static constexpr int UNI = QKV > FFN ? QKV : FFN;          // the qkv tile and the FFN tile are never live together in the forward
+};
+// EXACT: d_model == DP (every shipped configuration): d is a compile-time constant, the matmul bodies are branch-free.
+template <int DP, int HDC, bool EXACT>
 __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
-  constexpr int SX = DP + 8, SH = GT_SEQ_FMAX + 8, SQ = 3 * DP + 8, SRS = DP + 8, RP = (DP == 32) ? 8 : 2, CW = DP / 16;
+  using G = SeqGeo<DP>;
+  constexpr int SX = G::SX, SH = G::SH, SQ = G::SQ, SRS = G::SRS, CW = G::CW, NK = G::NK;
   constexpr int HD = SeqHd<HDC>::HD;
   constexpr bool PAD = SeqHd<HDC>::PAD;
-  __shared__ __attribute__((aligned(16))) float sX[32 * SX], sX1[32 * SX], sC[32 * SX], sQ[32 * SQ], sH[32 * SH], sR[RP * 32 * SRS];
+  __shared__ __attribute__((aligned(16))) float sX[G::TILE], sX1[G::TILE], sC[G::TILE], sR[G::RES], sU[G::UNI];
+  float* const sQ = sU;                                      // qkv tile: in-proj -> attention
+  float* const sH = sU;                                      // FFN tile: FFN1 -> FFN2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x, d = a.d, F = a.F;
+  const int b = blockIdx.x, d = EXACT ? DP : a.d, F = a.F;
   const size_t r0 = (size_t)b * 32;                          // first token row of this sequence
   const float* const zp = gt_zero_ptr();
   const float* prm = a.prm;
@@ -650,6 +750,10 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   const SeqDropK dk = seq_dropk(a);
   const uint32_t idxd = (uint32_t)(r0 * d), idxf = (uint32_t)(r0 * F);   // dropout element index of this sequence's first row
 
+#ifdef GT_SEQ_STAMPS
+  GT_SUBSET(false);
+  GT_BARRIER();
+#endif
   GT_STAMP(0);
   // ---- input layer: a0 = x Win^T + b; x0 = drop(relu(a0) + pe)     (A tile: the 32 x S input rows, zero-padded to 32 columns)
   for (int e = tid; e < 32 * 32; e += GT_SEQ_NT) {
@@ -662,7 +766,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     const uint32_t key = seq_key(dk, GT_SITE_PE_ENC);
     float* ga0 = ws + a.a0 + r0 * d;
     float* gx0 = ws + a.x0 + r0 * d;
-    seq_mm_edge<false, false>(sC, SX, a.S, prm + a.in_w, a.S, d, prm + a.in_b, wave, lane, zp,
+    seq_mm_edge<false, false, 2>(sC, SX, a.S, prm + a.in_w, a.S, d, prm + a.in_b, wave, lane, zp,
                               [&](int n0, const f32x4& c0, const f32x4& c1, const float (&bi)[4]) {
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
@@ -687,28 +791,30 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   const float ascale = 1.0f / sqrtf((float)a.hd);
   for (int l = 0; l < a.L; ++l) {
     const float* pl = prm + (int64_t)l * a.pstride;          // this layer's parameters / saved activations (wave-uniform bases)
+    const float* kf = ws + a.pack_f + (int64_t)l * a.kstride;                    // its fragment-ordered weights: in_w, out_w, w1, w2
+    const float* kf_out = kf + 3 * d * d, *kf_w1 = kf + 4 * d * d, *kf_w2 = kf_w1 + d * F;
     float* wl = ws + (int64_t)l * a.wstride;
     const int site0 = GT_SITE_LAYER0 + 8 * l;
     const int sb = 2 + 10 * l;                               // stamp base of this layer
     GT_STAMP(sb);
-    // ---- in-proj: qkv = x Win^T + b -> LDS (the attention bodies read it there) and global (saved for backward)
+    GT_SUBSET(l == 1);
+    // ---- in-proj: qkv = x Win^T + b -> LDS (the attention bodies read it there; saved to global for the backward from there)
     {
-      float* gq = wl + a.w0.qkv + r0 * 3 * d;
-      seq_mm_tiles<false, (3 * DP / 16 + 7) / 8>(sX, SX, d, pl + a.p0.in_w, d, 3 * d, pl + a.p0.in_b, wave, lane,
-                                                 [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
+      seq_mm_tiles<NK, (3 * DP / 16 + 7) / 8, EXACT>(sX, SX, d, kf, 3 * d, pl + a.p0.in_b, wave, lane,
+                                                     [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
         const int col = n0 + 4 * lg;
         const float4 o0 = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
         const float4 o1 = make_float4(c1[0] + bi.x, c1[1] + bi.y, c1[2] + bi.z, c1[3] + bi.w);
         *reinterpret_cast<float4*>(&sQ[l16 * SQ + col]) = o0;
         *reinterpret_cast<float4*>(&sQ[(16 + l16) * SQ + col]) = o1;
-        *reinterpret_cast<float4*>(gq + (unsigned)(l16 * 3 * d + col)) = o0;
-        *reinterpret_cast<float4*>(gq + (unsigned)((16 + l16) * 3 * d + col)) = o1;
       });
     }
     GT_BARRIER();
     GT_STAMP(sb + 1);
+    GT_SUBSET(false);
     // ---- attention: four heads at a time (wave pair p = wave >> 1 takes head h4 + p); operands from the LDS qkv tile,
     // P to global, ctx to the LDS tile
+    seq_tile_out(wl + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid);
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
       for (int h4 = 0; h4 < a.H; h4 += GT_SEQ_WAVES / 2) {
@@ -725,10 +831,13 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     GT_STAMP(sb + 2);
     // ---- out-proj (raw product -> sR part 0); the ctx tile also goes to global here (operand of the out-proj weight gradient)
     {
-      float* gc = wl + a.w0.ctx + r0 * d;
-      const int row = tid >> 4, c0 = (tid & 15) * CW;
-      if (c0 < d) { float v[CW]; SeqVec<CW>::ld(v, &sC[row * SX + c0]); SeqVec<CW>::st(gc + (unsigned)(row * d + c0), v); }
-      seq_mm_square<false>(sC, SX, d, pl + a.p0.out_w, sR, SRS, wave, lane);
+      seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid);
+      if (DP <= 64) seq_mm_square(sC, SX, d, kf_out, sR, SRS, wave, lane);
+      else
+        seq_mm_tiles<NK, 1, EXACT>(sC, SX, d, kf_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
+          *reinterpret_cast<float4*>(&sR[l16 * SRS + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+          *reinterpret_cast<float4*>(&sR[(16 + l16) * SRS + n0 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+        });
     }
     GT_BARRIER();
     GT_STAMP(sb + 3);
@@ -748,9 +857,8 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     // ---- FFN1: hact = drop(relu(x1 W1^T + b1))
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_FFN);
-      float* gh = wl + a.w0.hact + r0 * F;
-      seq_mm_tiles<false, GT_SEQ_FMAX / 128>(sX1, SX, d, pl + a.p0.w1, d, F, pl + a.p0.b1, wave, lane,
-                                             [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
+      seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT>(sX1, SX, d, kf_w1, F, pl + a.p0.b1, wave, lane,
+                                                 [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
         const int col = n0 + 4 * lg;
         const unsigned o0 = (unsigned)(l16 * F + col), o1 = (unsigned)((16 + l16) * F + col);
         float4 v0, v1;
@@ -760,14 +868,13 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         v0.w = fmaxf(c0[3] + bi.w, 0.f) * seq_dmul(dk, key, idxf + o0 + 3); v1.w = fmaxf(c1[3] + bi.w, 0.f) * seq_dmul(dk, key, idxf + o1 + 3);
         *reinterpret_cast<float4*>(&sH[l16 * SH + col]) = v0;
         *reinterpret_cast<float4*>(&sH[(16 + l16) * SH + col]) = v1;
-        *reinterpret_cast<float4*>(gh + o0) = v0;
-        *reinterpret_cast<float4*>(gh + o1) = v1;
       });
     }
     GT_BARRIER();
     GT_STAMP(sb + 5);
-    // ---- FFN2 (K = F: split over the waves) -> partial tiles
-    seq_mm_splitk<false>(sH, SH, F, pl + a.p0.w2, F, d, sR, SRS, wave, lane);
+    // ---- FFN2 (K = F: split over the waves) -> partial tiles; the FFN tile goes to global (saved for the backward)
+    seq_tile_out(wl + a.w0.hact + r0 * F, sH, SH, F, tid);
+    seq_mm_splitk(sH, SH, F, kf_w2, d, sR, SRS, wave, lane);
     GT_BARRIER();
     GT_STAMP(sb + 6);
     // ---- z2 = drop(sum of the parts + b2) + x1;  norm2 -> the next layer's input
@@ -789,7 +896,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   seq_ln_fwd<DP>([&](int row, int c0, float (&z)[CW]) { SeqVec<CW>::ld(z, &sX[row * SX + c0]); }, sC, SX, d, prm + a.encn_w, prm + a.encn_b,
                  ws + a.memory + r0 * d, ws + a.enc_xhat + r0 * d, ws + a.enc_rstd + r0, tid);
   GT_BARRIER();
-  seq_mm_edge<false, true>(sC, SX, d, prm + a.out_w, d, GT_TGT, prm + a.out_b, wave, lane, zp,
+  seq_mm_edge<false, true, NK>(sC, SX, d, prm + a.out_w, d, GT_TGT, prm + a.out_b, wave, lane, zp,
                            [&](int n0, const f32x4& c0, const f32x4& c1, const float (&bi)[4]) {
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
@@ -812,18 +919,24 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
 // ================================================================================================================ backward
 // LayerNorm jobs (dgamma / dbeta partial blocks, [B][2][d] each) in the order the kernel fills them: 0 = final norm, then for
 // l = L-1 .. 0: 1 + 2 (L-1-l) = norm2 of layer l, 2 + 2 (L-1-l) = norm1 of layer l.  The host registers them in this order.
-template <int DP, int HDC>
+template <int DP, int HDC, bool EXACT>
 __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
-  constexpr int SX = DP + 8, SH = GT_SEQ_FMAX + 8, SQ = 3 * DP + 8, SRS = DP + 8, RP = (DP == 32) ? 8 : 2, CW = DP / 16;
+  using G = SeqGeo<DP>;
+  constexpr int SX = G::SX, SH = G::SH, SQ = G::SQ, SRS = G::SRS, CW = G::CW, NK = G::NK;
   constexpr int HD = SeqHd<HDC>::HD;
   constexpr bool PAD = SeqHd<HDC>::PAD;
-  // sG: gradient w.r.t. the current layer's output; sDZ: the LayerNorm backward's dz (residual gradient); sC: dz * dropout mask
-  // (A operand of the next dgrad); sZ: dctx; sQ: the dqkv tile; sH: the FFN tile -- and, between the FFN1 dgrad and the end of
-  // the attention backward, the saved qkv tile of this layer (sK = sH, [32][SQ])
-  __shared__ __attribute__((aligned(16))) float sG[32 * SX], sZ[32 * SX], sDZ[32 * SX], sC[32 * SX], sQ[32 * SQ], sH[32 * SH], sR[RP * 32 * SRS],
+  // sZ: gradient w.r.t. the last layer's output (first LayerNorm backward only), then dctx; sDZ: the LayerNorm backward's dz (residual
+  // gradient); sC: dz * dropout mask (A operand of the next dgrad); sQ: the saved qkv tile of the layer, overwritten IN PLACE by
+  // dq / dk / dv in the attention backward; sH: the FFN tile (hact, then dhid in place).  ALIAS (DP 128: 160 KB do not hold both):
+  // sQ and sH share storage -- the FFN tile is dead once the FFN1 dgrad has read it, the qkv tile is loaded after that, and the
+  // next layer's FFN tile is requested only after the in-proj dgrad has read dqkv.
+  constexpr bool ALIAS = DP > 64;
+  __shared__ __attribute__((aligned(16))) float sZ[G::TILE], sDZ[G::TILE], sC[G::TILE], sR[G::RES], sU[ALIAS ? G::UNI : G::QKV + G::FFN],
       sP[2 * GT_SEQ_WAVES * DP], srd[32 * GT_SEQ_WAVES / 2];
+  float* const sQ = sU;
+  float* const sH = ALIAS ? sU : sU + G::QKV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x, d = a.d, F = a.F;
+  const int b = blockIdx.x, d = EXACT ? DP : a.d, F = a.F;
   const size_t r0 = (size_t)b * 32;
   const float* const zp = gt_zero_ptr();
   const float* prm = a.prm;
@@ -832,7 +945,6 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   const uint32_t idxd = (uint32_t)(r0 * d);
   const float mscale = dk.thr ? dk.scale : 1.0f;
   const float ascale = 1.0f / sqrtf((float)a.hd);
-  float* const sK = sH;
   auto part_at = [&](int job) { return ws + a.ln_part + (int64_t)job * a.ln_part_stride + (size_t)b * 2 * d; };
   // a [32][ncol] tile of this sequence, global -> LDS, 16 bytes per thread and pass
   auto load_tile = [&](float* dst, const int str, const float* src, const int ncol) {
@@ -843,6 +955,10 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     }
   };
 
+#ifdef GT_SEQ_STAMPS
+  GT_SUBSET(false);
+  GT_BARRIER();
+#endif
   GT_STAMP(100);
   // ---- output layer dgrad: dmem = dlogits Wout   (A tile: 32 x 27 zero-padded to 32 columns)
   for (int e = tid; e < 32 * 32; e += GT_SEQ_NT) {
@@ -851,17 +967,17 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   }
   load_tile(sH, SH, ws + a.w0.hact + (int64_t)(a.L - 1) * a.wstride + r0 * F, F);
   GT_BARRIER();
-  seq_mm_edge<true, true>(sC, SX, GT_TGT, prm + a.out_w, d, d, nullptr, wave, lane, zp,
+  seq_mm_edge<true, true, 2>(sC, SX, GT_TGT, prm + a.out_w, d, d, nullptr, wave, lane, zp,
                           [&](int n0, const f32x4& c0, const f32x4& c1, const float (&)[4]) {
     const int col = n0 + 4 * lg;
     *reinterpret_cast<float4*>(&sZ[l16 * SX + col]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
     *reinterpret_cast<float4*>(&sZ[(16 + l16) * SX + col]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
   });
   GT_BARRIER();
-  // ---- final norm backward -> gradient w.r.t. the last layer's output (sG); its dz is not a weight-gradient operand
+  // ---- final norm backward -> gradient w.r.t. the last layer's output (sZ, in place); its dz is not a weight-gradient operand
   {
     SeqDropK nd = dk; nd.thr = 0u;
-    seq_ln_bwd<DP>([&](int row, int c0, float (&g)[CW]) { SeqVec<CW>::ld(g, &sZ[row * SX + c0]); }, sG, sC, SX, d, ws + a.enc_xhat + r0 * d,
+    seq_ln_bwd<DP>([&](int row, int c0, float (&g)[CW]) { SeqVec<CW>::ld(g, &sZ[row * SX + c0]); }, sZ, sC, SX, d, ws + a.enc_xhat + r0 * d,
                    ws + a.enc_rstd + r0, prm + a.encn_w, nd, 0u, 0u, nullptr, nullptr, sP, tid);
   }
   GT_BARRIER();
@@ -872,18 +988,21 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   bool first = true;                                            // the first norm2 backward reads g from sG; later ones add the parts
   for (int l = a.L - 1; l >= 0; --l) {
     const float* pl = prm + (int64_t)l * a.pstride;
+    const float* kb = ws + a.pack_b + (int64_t)l * a.kstride;                    // dgrad-ordered weights: in_w, out_w, w1, w2
+    const float* kb_out = kb + 3 * d * d, *kb_w1 = kb + 4 * d * d, *kb_w2 = kb_w1 + d * F;
     float* wl = ws + (int64_t)l * a.wstride;
     float* tl = ws + (int64_t)l * a.tstride;
     const int site0 = GT_SITE_LAYER0 + 8 * l, jb = 1 + 2 * (a.L - 1 - l);
     const int sb = 102 + 10 * (a.L - 1 - l);
-    // ---- norm2 backward: g = gradient w.r.t. this layer's output (l == L-1: sG; else the in-proj dgrad parts of layer l+1 + its
+    // ---- norm2 backward: g = gradient w.r.t. this layer's output (l == L-1: sZ; else the in-proj dgrad parts of layer l+1 + its
     // dz1) -> dz2 -> sDZ, dz2 * mask(dropout on the FFN output) -> sC; both to global for the weight gradients
+    if (ALIAS && !first) load_tile(sH, SH, wl + a.w0.hact + r0 * F, F);          // (the in-proj dgrad above has read dqkv out of this storage)
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_DROPF);
       const int parts = seq_splitk_parts(d);
       const bool fromg = first;
       seq_ln_bwd<DP>([&](int row, int c0, float (&g)[CW]) {
-        if (fromg) SeqVec<CW>::ld(g, &sG[row * SX + c0]);
+        if (fromg) SeqVec<CW>::ld(g, &sZ[row * SX + c0]);
         else {
           float r[CW];
           seq_parts_sum<CW>(g, sR, SRS, parts, row, c0); SeqVec<CW>::ld(r, &sDZ[row * SX + c0]);
@@ -899,9 +1018,8 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     // ---- FFN2 dgrad: dhid = (dz2m W2) * [hact != 0] * 1/(1-p), in place over the hact tile in sH
     seq_ln_part<DP>(sP, part_at(jb), d, tid);
     {
-      float* gd = tl + a.t0.dhid + r0 * F;
-      seq_mm_tiles<true, GT_SEQ_FMAX / 128>(sC, SX, d, pl + a.p0.w2, F, F, nullptr, wave, lane,
-                                            [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
+      seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT>(sC, SX, d, kb_w2, F, nullptr, wave, lane,
+                                                [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
         const int col = n0 + 4 * lg;
         const float4 ha = *reinterpret_cast<const float4*>(&sH[l16 * SH + col]), hb = *reinterpret_cast<const float4*>(&sH[(16 + l16) * SH + col]);
         const float4 o0 = make_float4(ha.x != 0.f ? c0[0] * mscale : 0.f, ha.y != 0.f ? c0[1] * mscale : 0.f, ha.z != 0.f ? c0[2] * mscale : 0.f,
@@ -910,19 +1028,18 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
                                       hb.w != 0.f ? c1[3] * mscale : 0.f);
         *reinterpret_cast<float4*>(&sH[l16 * SH + col]) = o0;
         *reinterpret_cast<float4*>(&sH[(16 + l16) * SH + col]) = o1;
-        *reinterpret_cast<float4*>(gd + (unsigned)(l16 * F + col)) = o0;
-        *reinterpret_cast<float4*>(gd + (unsigned)((16 + l16) * F + col)) = o1;
       });
     }
     GT_BARRIER();
     GT_STAMP(sb + 1);
-    // ---- FFN1 dgrad (K = F: split over the waves) -> partial tiles
-    seq_mm_splitk<true>(sH, SH, F, pl + a.p0.w1, d, d, sR, SRS, wave, lane);
+    // ---- FFN1 dgrad (K = F: split over the waves) -> partial tiles; dhid goes to global (operand of both FFN weight gradients)
+    seq_tile_out(tl + a.t0.dhid + r0 * F, sH, SH, F, tid);
+    seq_mm_splitk(sH, SH, F, kb_w1, d, sR, SRS, wave, lane);
     GT_BARRIER();
     GT_STAMP(sb + 2);
-    // ---- norm1 backward: g1 = parts + dz2 -> dz1 -> sDZ, dz1 * mask(dropout1) -> sC.  sH is free from here to the end of the
-    // attention backward: the saved qkv tile of this layer is requested into it now
-    load_tile(sK, SQ, wl + a.w0.qkv + r0 * 3 * d, 3 * d);
+    // ---- norm1 backward: g1 = parts + dz2 -> dz1 -> sDZ, dz1 * mask(dropout1) -> sC.  The saved qkv tile of this layer is
+    // requested now (ALIAS: over the FFN tile, which the FFN1 dgrad has finished reading)
+    load_tile(sQ, SQ, wl + a.w0.qkv + r0 * 3 * d, 3 * d);
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_DROP1);
       const int parts = seq_splitk_parts(d);
@@ -938,39 +1055,39 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     GT_STAMP(sb + 3);
     // ---- out-proj dgrad: dctx = dz1m Wo -> sZ (LDS: the attention backward reads it there)
     seq_ln_part<DP>(sP, part_at(jb + 1), d, tid);
-    seq_mm_square<true>(sC, SX, d, pl + a.p0.out_w, sZ, SX, wave, lane);
+    if (DP <= 64) seq_mm_square(sC, SX, d, kb_out, sZ, SX, wave, lane);
+    else
+      seq_mm_tiles<NK, 1, EXACT>(sC, SX, d, kb_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
+        *reinterpret_cast<float4*>(&sZ[l16 * SX + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+        *reinterpret_cast<float4*>(&sZ[(16 + l16) * SX + n0 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+      });
     GT_BARRIER();
     GT_STAMP(sb + 4);
-    // ---- attention backward, four heads at a time: q / k / v from the LDS copy, P from global (saved), dctx from LDS,
-    // dq / dk / dv -> the sQ tile
+    // ---- attention backward, four heads at a time: q / k / v from the LDS tile, P from global (saved), dctx from LDS; dq / dk / dv
+    // replace q / k / v of the head in place (every wave of the round has finished reading before anyone stores: third barrier)
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
       for (int h4 = 0; h4 < a.H; h4 += GT_SEQ_WAVES / 2) {
         const int h = h4 + (wave >> 1);
         const bool active = h < a.H;
         SeqAttn at;
-        at.q = sK + h * a.hd; at.k = at.q + d; at.v = at.q + 2 * d; at.ldq = SQ; at.hd = a.hd; at.scale = ascale;
+        at.q = sQ + h * a.hd; at.k = at.q + d; at.v = at.q + 2 * d; at.ldq = SQ; at.hd = a.hd; at.scale = ascale;
         at.pidx = (uint32_t)((b * a.H + h) * 1024); at.P = wl + a.w0.P + (size_t)(b * a.H + h) * 1024;
-        f32x4 dq_out[HD / 16];
+        f32x4 dq_out[HD / 16], dk_out[HD / 16], dv_out[HD / 16];
         if (active) seq_attn_bwd1<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dq_out);
         GT_BARRIER();
-        if (active) seq_attn_bwd2<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dq_out, sQ + h * a.hd, SQ, d);
+        if (active) seq_attn_bwd2<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dk_out, dv_out);
         GT_BARRIER();
+        if (active) seq_attn_bwd_store<HD, PAD>(sQ + h * a.hd, SQ, d, a.hd, wave & 1, lane, dq_out, dk_out, dv_out);
       }
     }
+    GT_BARRIER();
     GT_STAMP(sb + 5);
     // ---- dqkv tile -> global (operand of the in-proj weight gradient); in-proj dgrad (K = 3 d: split over the waves); the
-    // FFN tile of the next layer down is requested into sH (the qkv copy in it is dead now)
-    {
-      float* gq = tl + a.t0.dqkv + r0 * 3 * d;
-      const int q4 = (3 * d) >> 2;
-      for (int e = tid; e < 32 * q4; e += GT_SEQ_NT) {
-        const int r = e / q4, c = (e - r * q4) * 4;
-        *reinterpret_cast<float4*>(gq + (unsigned)(r * 3 * d + c)) = *reinterpret_cast<const float4*>(&sQ[r * SQ + c]);
-      }
-    }
-    if (l > 0) load_tile(sH, SH, ws + (int64_t)(l - 1) * a.wstride + a.w0.hact + r0 * F, F);
-    seq_mm_splitk<true>(sQ, SQ, 3 * d, pl + a.p0.in_w, d, d, sR, SRS, wave, lane);
+    // FFN tile of the next layer down is requested into sH (ALIAS: at the next layer's first stage instead)
+    seq_tile_out(tl + a.t0.dqkv + r0 * 3 * d, sQ, SQ, 3 * d, tid);
+    if (!ALIAS && l > 0) load_tile(sH, SH, ws + (int64_t)(l - 1) * a.wstride + a.w0.hact + r0 * F, F);
+    seq_mm_splitk(sQ, SQ, 3 * d, kb, d, sR, SRS, wave, lane);
     GT_BARRIER();
     GT_STAMP(sb + 6);
   }
