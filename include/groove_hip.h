@@ -186,6 +186,10 @@ int gt_set_chain(int on);
  * win -- d_model <= 64 always, d_model <= 128 from batch 64 up.  on = 1 forces them wherever supported, on = 0 switches them off
  * (env GT_SEQ=1 / GT_SEQ=0 do the same; gt_set_chain(1) takes precedence).  Same results as the other paths to fp32 rounding. */
 int gt_set_seq(int on);
+/* Two workgroups per sequence (16 token rows each) and one launch per layer and direction for the d_model-128 sequence-resident
+ * kernels: -1 = default (when 2 x batch workgroups fit the CUs once), 0 = off, 1 = on (env GT_SEQ_SPLIT=0/1 does the same).  Same
+ * results bit for bit: the split is over token rows. */
+int gt_set_seq_split(int on);
 int gt_profile_report(char* buf, size_t buf_len, int max_rows);
 
 #ifdef __cplusplus

@@ -152,6 +152,13 @@ def test_sequence_resident_kernels(cfg, B, p):
     parity.check_step("emu", cfg, B, p)
 
 
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(128, 4, 512, 2), 1, 0.24), (cfg_dict(128, 16, 48, 3), 2, 0.1), (cfg_dict(128, 2, 32, 1), 1, 0.0)])
+def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
+    """d_model 128, SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels"""
+    parity.check_step("emu", cfg, B, p, seq="split")
+    parity.check_step("emu", cfg, B, p, seq="whole")
+
+
 def test_sequence_resident_train_step_and_predict():
     parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.2)
     parity.check_bucketed_backward("emu", cfg_dict(32, 4, 16, 2), 2, 0.25, 1, exact=True)      # one bucket: the backward is one launch

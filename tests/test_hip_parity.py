@@ -190,6 +190,19 @@ def test_small_models_on_the_one_kernel_per_op_path(cfg, B, p):
     parity.check_step("hip", cfg, B, p, seq=False)
 
 
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(128, 4, 512, 3), 64, 0.24), (cfg_dict(128, 16, 48, 2), 7, 0.1), (cfg_dict(128, 2, 32, 1), 3, 0.0),
+                                     (cfg_dict(128, 8, 128, 4, embedding_size_src=27), 33, 0.2)])
+def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
+    parity.check_step("hip", cfg, B, p, seq="split")
+    parity.check_step("hip", cfg, B, p, seq="whole")
+
+
+def test_sequence_resident_split_train_step_and_buckets():
+    parity.check_train_step("hip", C2, 64, 0.24, seq="split")
+    parity.check_train_step("hip", C2, 64, 0.24, seq="whole")
+    parity.check_bucketed_backward("hip", C2, 64, 0.24, 1, exact=False, seq="split")
+
+
 def test_sequence_resident_train_step():
     parity.check_train_step("hip", C1, 32, 0.18)
     parity.check_train_step("hip", ENC, 4, 0.2, seq=False)

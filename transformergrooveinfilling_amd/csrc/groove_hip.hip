@@ -187,6 +187,7 @@ struct WLayout {
   std::vector<LayerW> layers;                        // encoder layers then decoder layers
   int64_t hvo_tmp, dlogits, loss_part, dctx, dmem, da0_dec, ln_part, ln_part_stride, total, stamps = 0;
   int64_t pack_f = -1, pack_b = -1, pack_stride = 0;   // fragment-ordered weight copies of the sequence-resident kernels (gt_seq.h)
+  int64_t seq_dctx = -1;                               // hand-over buffer of their two-workgroups-per-sequence (SPLIT) backward phases
   struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; };
   std::vector<TmpSet> set;                           // 2 alternating sets, or one per layer (wgrad_deferred)
 };
@@ -252,6 +253,7 @@ static WLayout ws_layout(const gt_config& c) {
   if (seq_supported(c)) {
     W.pack_stride = (int64_t)4 * d * d + (int64_t)2 * d * F;
     W.pack_f = add(W.pack_stride * c.n_enc_layers); W.pack_b = add(W.pack_stride * c.n_enc_layers);
+    if (d > 64) W.seq_dctx = add(2 * M * d);
   }
 #ifdef GT_SEQ_STAMPS
   W.stamps = add(2048);
@@ -693,6 +695,29 @@ static int encoder_fwd_chain(const Ctx& x, const float* pe, const float* src) {
 // by the fp32 MFMA rate of the ONE CU its workgroup runs on, so from 64 sequences per GPU up (bs 64: tie, 96: 1.18x, 192: 1.53x).
 static int g_seq = -1;
 extern "C" int gt_set_seq(int on) { g_seq = on != 0; return 0; }
+// SPLIT mode of the d_model-128 class: 2 x batch workgroups of 16 token rows, one launch per layer and direction (+1).  Default
+// (-1): when the pairs fit the chip once (2 x batch <= CUs) -- there a sequence per CU leaves most of the MFMA rate idle.
+static int g_seq_split = -1;
+extern "C" int gt_set_seq_split(int on) { g_seq_split = on < 0 ? -1 : on != 0; return 0; }
+static int seq_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+#ifdef GT_EMU
+    n = 256;
+#else
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+#endif
+  }
+  return n;
+}
+static bool seq_split(const gt_config& c) {
+  if (c.d_model != 128) return false;
+  if (g_seq_split < 0) { const char* e = getenv("GT_SEQ_SPLIT"); if (e) g_seq_split = e[0] != '0'; }
+  if (g_seq_split >= 0) return g_seq_split != 0;
+  return 2 * c.batch <= seq_cu_count();
+}
 static bool seq_supported(const gt_config& c) {
   const int hd = c.d_model / c.n_heads;
   return c.n_dec_layers == 0 && c.precision == 0 && c.d_model % 16 == 0 && c.d_model <= 128 && c.dim_ff % 16 == 0 &&
@@ -704,11 +729,17 @@ static bool use_seq(const gt_config& c) {
   return g_seq && seq_supported(c) && !(g_chain == 1);       // an explicit gt_set_chain(1) / GT_CHAIN=1 keeps the row-chain kernels
 }
 // kernel<DP, HDC, EXACT>: d_model class 32 / 64 / 128, head-dim class 0 (< 16) / 16 / 32 / 64, d_model == DP
-#define GT_SEQ_LAUNCH_HD(K, DP, EX, hc, grid, block, s, a)                       \
-  if ((hc) == 0) gt_launch(K<DP, 0, EX>, grid, block, s, a);                      \
-  else if ((hc) == 16) gt_launch(K<DP, 16, EX>, grid, block, s, a);               \
-  else if ((hc) == 32 || (DP) == 32) gt_launch(K<DP, 32, EX>, grid, block, s, a); \
-  else gt_launch(K<(DP) == 32 ? 64 : DP, 64, EX>, grid, block, s, a);
+#define GT_SEQ_LAUNCH_HD(K, DP, EX, hc, grid, block, s, a)                              \
+  if ((hc) == 0) gt_launch(K<DP, 0, EX, false>, grid, block, s, a);                      \
+  else if ((hc) == 16) gt_launch(K<DP, 16, EX, false>, grid, block, s, a);               \
+  else if ((hc) == 32 || (DP) == 32) gt_launch(K<DP, 32, EX, false>, grid, block, s, a); \
+  else gt_launch(K<(DP) == 32 ? 64 : DP, 64, EX, false>, grid, block, s, a);
+// the SPLIT kernels (two workgroups per sequence, one launch per phase): d_model 128 exactly
+#define GT_SEQ_LAUNCH_SPLIT(K, hc, grid, block, s, a)                    \
+  if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);        \
+  else if ((hc) == 16) gt_launch(K<128, 16, true, true>, grid, block, s, a); \
+  else if ((hc) == 32) gt_launch(K<128, 32, true, true>, grid, block, s, a); \
+  else gt_launch(K<128, 64, true, true>, grid, block, s, a);
 #define GT_SEQ_LAUNCH_DP(K, DP, dm, hc, grid, block, s, a)                                                  \
   { if ((dm) == (DP)) { GT_SEQ_LAUNCH_HD(K, DP, true, hc, grid, block, s, a) } else { GT_SEQ_LAUNCH_HD(K, DP, false, hc, grid, block, s, a) } }
 #define GT_SEQ_DISPATCH(K, dm, hc, grid, block, s, a)                         \
@@ -736,6 +767,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.dlogits = x.W.dlogits; a.da0 = x.W.dctx; a.ln_part = x.W.ln_part; a.ln_part_stride = x.W.ln_part_stride;
   a.stamps = x.W.stamps;
   a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
+  a.dctx = x.W.seq_dctx; a.phase = 0;
   return a;
 }
 // the whole forward (input layer ... output heads) of every sequence: ONE launch
@@ -748,8 +780,19 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
     gt_launch(seq_pack_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), x.s, a);
   }
   gt_prof_tag("seq_fwd", fl, 4.0 * x.M * (x.c.src_dim + x.c.n_enc_layers * (9.0 * x.d + x.F) + 27.0));
-  const dim3 grid(x.c.batch), block(GT_SEQ_NT);
+  const dim3 block(GT_SEQ_NT);
   const int hc = x.hd < 16 ? 0 : x.hd;             // head-dim class (one instantiation each: the attention bodies' registers differ 4x)
+  if (seq_split(x.c)) {
+    const dim3 grid(2 * x.c.batch);
+    for (int p = 0; p <= x.c.n_enc_layers; ++p) {
+      SeqArgs ap = a;
+      ap.phase = p;
+      if (p > 0) gt_prof_tag("seq_fwd", p == 1 ? fl : 0.0, 0.0);
+      GT_SEQ_LAUNCH_SPLIT(seq_fwd_kernel, hc, grid, block, x.s, ap)
+    }
+    return 0;
+  }
+  const dim3 grid(x.c.batch);
   GT_SEQ_DISPATCH(seq_fwd_kernel, x.d, hc, grid, block, x.s, a)
   return 0;
 }
@@ -997,16 +1040,29 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
       gt_launch(heads_bwd_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, d_hvo, hvo, ws + W.dlogits, M * GT_TGT);
     }
     // LayerNorm jobs in the order the kernel fills their partial blocks (one [2][d] row per sequence)
-    bool ok = ln_job(x, P.encn_w, cfg->batch) != nullptr;
-    for (int j = L - 1; j >= 0; --j) ok = ok && ln_job(x, P.enc[j].n2w, cfg->batch) && ln_job(x, P.enc[j].n1w, cfg->batch);
+    const bool split = seq_split(*cfg);
+    const int nwg = split ? 2 * cfg->batch : cfg->batch;       // partial rows per LayerNorm instance: one per workgroup
+    bool ok = ln_job(x, P.encn_w, nwg) != nullptr;
+    for (int j = L - 1; j >= 0; --j) ok = ok && ln_job(x, P.enc[j].n2w, nwg) && ln_job(x, P.enc[j].n1w, nwg);
     if (!ok) return gt_fail("too many LayerNorm instances for the partials table");
     {
       const SeqArgs a = mk_seq(x, nullptr, xin, nullptr);
       const double fl = 4.0 * M * ((double)cfg->src_dim * d * 0 + L * (4.0 * d * d + 64.0 * d + 2.0 * d * x.F) + 27.0 * d);
       gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
-      const dim3 grid(cfg->batch), block(GT_SEQ_NT);
+      const dim3 block(GT_SEQ_NT);
       const int hc = x.hd < 16 ? 0 : x.hd;
-      GT_SEQ_DISPATCH(seq_bwd_kernel, d, hc, grid, block, x.s, a)
+      if (split) {
+        const dim3 grid(2 * cfg->batch);
+        for (int p = 0; p <= L; ++p) {
+          SeqArgs ap = a;
+          ap.phase = p;
+          if (p > 0) gt_prof_tag("seq_bwd", 0.0, 0.0);
+          GT_SEQ_LAUNCH_SPLIT(seq_bwd_kernel, hc, grid, block, x.s, ap)
+        }
+      } else {
+        const dim3 grid(cfg->batch);
+        GT_SEQ_DISPATCH(seq_bwd_kernel, d, hc, grid, block, x.s, a)
+      }
     }
     wgrad(x, ws + W.dlogits, GT_TGT, ws + W.memory, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
     for (int j = L - 1; j >= 0; --j) {

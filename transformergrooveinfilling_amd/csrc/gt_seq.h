@@ -50,6 +50,10 @@ struct SeqArgs {
   int64_t ln_part, ln_part_stride;                           // LayerNorm dgamma/dbeta partials: job j at ln_part + j * stride, [B][2][d]
   int64_t stamps;                                            // diagnostic builds (-DGT_SEQ_STAMPS) only: workspace offset of the stamp buffer
   int64_t pack_f, pack_b, kstride;                           // fragment-ordered weight copies (seq_pack_kernel): workspace offsets, floats per layer
+  int64_t dctx;                                              // SPLIT kernels: two [M][d] hand-over buffers of the backward phases (phase p writes
+                                                             // buffer p & 1 and reads the other: a fast workgroup must not overwrite rows its
+                                                             // partner has yet to read)
+  int phase;                                                 // SPLIT kernels: which phase this launch runs
 };
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md 7): workgroup 0, thread 0 records the shader clock at stage
 // boundaries into a buffer nothing else reads.  tools/seq_stamps.py prints the per-stage cycle counts.
@@ -126,16 +130,18 @@ __device__ __forceinline__ void seq_ldb(float (&b)[4], const float* __restrict__
     for (int j = 0; j < 4; ++j) b[j] = *((n < N && k + j < K) ? W + (size_t)(k + j) * ldw + n : zp);
   }
 }
+// HALF (the SPLIT kernels: a workgroup owns 16 of the 32 token rows): sA points at the first own row, only acc0 is computed
+template <bool HALF>
 __device__ __forceinline__ void seq_mma(f32x4& acc0, f32x4& acc1, const float (&b)[4], const float* sA, const int lda, const int l16, const int k) {
   const float4 a0 = *reinterpret_cast<const float4*>(sA + l16 * lda + k);
-  const float4 a1 = *reinterpret_cast<const float4*>(sA + (16 + l16) * lda + k);
-  acc0 = GT_MFMA16(b[0], a0.x, acc0); acc1 = GT_MFMA16(b[0], a1.x, acc1);
-  acc0 = GT_MFMA16(b[1], a0.y, acc0); acc1 = GT_MFMA16(b[1], a1.y, acc1);
-  acc0 = GT_MFMA16(b[2], a0.z, acc0); acc1 = GT_MFMA16(b[2], a1.z, acc1);
-  acc0 = GT_MFMA16(b[3], a0.w, acc0); acc1 = GT_MFMA16(b[3], a1.w, acc1);
+  acc0 = GT_MFMA16(b[0], a0.x, acc0); acc0 = GT_MFMA16(b[1], a0.y, acc0); acc0 = GT_MFMA16(b[2], a0.z, acc0); acc0 = GT_MFMA16(b[3], a0.w, acc0);
+  if (!HALF) {
+    const float4 a1 = *reinterpret_cast<const float4*>(sA + (16 + l16) * lda + k);
+    acc1 = GT_MFMA16(b[0], a1.x, acc1); acc1 = GT_MFMA16(b[1], a1.y, acc1); acc1 = GT_MFMA16(b[2], a1.z, acc1); acc1 = GT_MFMA16(b[3], a1.w, acc1);
+  }
 }
 // wave w owns tile w (N <= 128), K <= 16 NK.  epi(n0, acc0, acc1, bias4): bias4 = bias[n0 + 4 lg + 0..3] (zeros without a bias).
-template <bool BKM, bool VEC, int NK, typename Epi>
+template <bool BKM, bool VEC, int NK, bool HALF, typename Epi>
 __device__ __forceinline__ void seq_mm_edge(const float* sA, const int lda, const int K, const float* __restrict__ W, const int ldw, const int N,
                                             const float* __restrict__ bias, const int wave, const int lane, const float* zp, Epi epi) {
   const int l16 = lane & 15, lg = lane >> 4;
@@ -148,7 +154,7 @@ __device__ __forceinline__ void seq_mm_edge(const float* sA, const int lda, cons
   for (int r = 0; r < 4; ++r) bi[r] = *((bias != nullptr && n0 + 4 * lg + r < N) ? bias + n0 + 4 * lg + r : zp);
   f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < NK; ++u) { if (16 * u < K) seq_mma(acc0, acc1, b[u], sA, lda, l16, 16 * u + 4 * lg); }
+  for (int u = 0; u < NK; ++u) { if (16 * u < K) seq_mma<HALF>(acc0, acc1, b[u], sA, lda, l16, 16 * u + 4 * lg); }
   epi(n0, acc0, acc1, bi);
 }
 
@@ -193,9 +199,34 @@ __global__ __launch_bounds__(256) void seq_pack_kernel(SeqArgs a) {
   *reinterpret_cast<float4*>(a.ws + (pack ? a.pack_b : a.pack_f) + (int64_t)l * a.kstride + moff + (int64_t)f * 256 + lane * 4) = v;
 }
 // acc0 / acc1 (rows l16 / 16 + l16) += A[:, k0 .. k0 + 16 nk) * B; ap = sA + l16 * lda + k0 + 4 lg (the A fragments are re-read from
-// LDS per tile: two 16-byte reads per 8 MFMAs)
-template <int NK, bool FULL = false>
+// acc0 / acc1 (rows l16 / 16 + l16 from ap's row) += A[:, k0 .. k0 + 16 nk) * B; the A fragments are re-read from LDS per tile
+// (two 16-byte reads per 8 MFMAs).  HALF: only acc0.
+template <int NK, bool FULL = false, bool HALF = false>
 __device__ __forceinline__ void seq_b_mma(f32x4& acc0, f32x4& acc1, const SeqB<NK>& b, const float* ap, const int lda, const int nk) {
+  if (FULL && HALF) {       // one accumulator: two interleaved partial sums would change the summation order, so one chain it is
+    float4 a0 = *reinterpret_cast<const float4*>(ap);
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      float4 n0 = a0;
+      if (u + 1 < NK) n0 = *reinterpret_cast<const float4*>(ap + 16 * (u + 1));
+      acc0 = GT_MFMA16(b.v[u].x, a0.x, acc0); acc0 = GT_MFMA16(b.v[u].y, a0.y, acc0);
+      acc0 = GT_MFMA16(b.v[u].z, a0.z, acc0); acc0 = GT_MFMA16(b.v[u].w, a0.w, acc0);
+      GT_SCHED_FENCE()
+      a0 = n0;
+    }
+    return;
+  }
+  if (HALF) {
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      if (u < nk) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * u);
+        acc0 = GT_MFMA16(b.v[u].x, a0.x, acc0); acc0 = GT_MFMA16(b.v[u].y, a0.y, acc0);
+        acc0 = GT_MFMA16(b.v[u].z, a0.z, acc0); acc0 = GT_MFMA16(b.v[u].w, a0.w, acc0);
+      }
+    }
+    return;
+  }
   if (FULL) {               // A fragments one k-step ahead of the MFMAs that use them; the fence keeps the compiler from hoisting all of them
     float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 16 * lda);
 #pragma unroll
@@ -224,7 +255,7 @@ __device__ __forceinline__ void seq_b_mma(f32x4& acc0, f32x4& acc1, const SeqB<N
 }
 // Short contraction (K % 16 == 0, <= 16 NK), N % 16 == 0: wave w owns tiles w, w + 8, ... (at most MAXT of them); the B fragment
 // of the wave's next tile is requested before the MFMAs of the current one.  epi(n0, acc0, acc1, bias float4).
-template <int NK, int MAXT, bool FULL, typename Epi>
+template <int NK, int MAXT, bool FULL, bool HALF, typename Epi>
 __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
                                                   const float* __restrict__ bias, const int wave, const int lane, Epi& epi) {
   const int l16 = lane & 15, lg = lane >> 4, ntile = N >> 4, nk = K >> 4;
@@ -246,7 +277,7 @@ __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda
       }
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
       GT_SUBSTAMP(2 + 3 * i);
-      seq_b_mma<NK, FULL>(acc0, acc1, b[i & 1], ap, lda, nk);
+      seq_b_mma<NK, FULL, HALF>(acc0, acc1, b[i & 1], ap, lda, nk);
 #ifdef GT_SEQ_STAMPS
       asm volatile("" : "+v"(acc0), "+v"(acc1));
 #endif
@@ -258,10 +289,10 @@ __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda
 }
 // FULL (K == 16 NK) is a property of the kernel instantiation (EXACT: d_model == DP): a run-time dispatch between the two bodies gets
 // merged back into the branchy one by the compiler.
-template <int NK, int MAXT, bool FULL, typename Epi>
+template <int NK, int MAXT, bool FULL, bool HALF, typename Epi>
 __device__ __forceinline__ void seq_mm_tiles(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
                                              const float* __restrict__ bias, const int wave, const int lane, Epi epi) {
-  seq_mm_tiles_impl<NK, MAXT, FULL>(sA, lda, K, Wp, N, bias, wave, lane, epi);
+  seq_mm_tiles_impl<NK, MAXT, FULL, HALF>(sA, lda, K, Wp, N, bias, wave, lane, epi);
 }
 __device__ __forceinline__ void seq_mma4(f32x4& acc, const float4& b, const float4& a) {
   acc = GT_MFMA16(b.x, a.x, acc); acc = GT_MFMA16(b.y, a.y, acc); acc = GT_MFMA16(b.z, a.z, acc); acc = GT_MFMA16(b.w, a.w, acc);
@@ -287,6 +318,7 @@ __device__ __forceinline__ void seq_mm_square(const float* sA, const int lda, co
 // partial tiles in sR[part][32][srs]; the pass that reads them (seq_parts_sum, inside the following LayerNorm pass) sums the
 // parts in a fixed order, part 0 first.  B moves in chunks of 8 k-steps, the next chunk requested before the current one's MFMAs.
 __device__ __forceinline__ int seq_splitk_parts(const int N) { return GT_SEQ_WAVES / (N >> 4); }
+template <bool HALF>
 __device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
                                               float* sR, const int srs, const int wave, const int lane) {
   const int l16 = lane & 15, lg = lane >> 4;
@@ -302,26 +334,26 @@ __device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, co
     seq_b_load<8, true>(b[0], Wp, nks, t, ks0, 8, lane);
     for (int c0 = ks0; c0 < ks1; c0 += 16) {                       // two chunks per trip: the buffer index stays compile-time
       if (c0 + 8 < ks1) seq_b_load<8, true>(b[1], Wp, nks, t, c0 + 8, 8, lane);
-      seq_b_mma<8, true>(acc0, acc1, b[0], ap + 16 * c0, lda, 8);
+      seq_b_mma<8, true, HALF>(acc0, acc1, b[0], ap + 16 * c0, lda, 8);
       if (c0 + 8 < ks1) {
         if (c0 + 16 < ks1) seq_b_load<8, true>(b[0], Wp, nks, t, c0 + 16, 8, lane);
-        seq_b_mma<8, true>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, 8);
+        seq_b_mma<8, true, HALF>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, 8);
       }
     }
   } else {
     if (ks0 < ks1) seq_b_load<8>(b[0], Wp, nks, t, ks0, ks1 - ks0, lane);
     for (int c0 = ks0; c0 < ks1; c0 += 16) {
       if (c0 + 8 < ks1) seq_b_load<8>(b[1], Wp, nks, t, c0 + 8, ks1 - c0 - 8, lane);
-      seq_b_mma<8>(acc0, acc1, b[0], ap + 16 * c0, lda, ks1 - c0);
+      seq_b_mma<8, false, HALF>(acc0, acc1, b[0], ap + 16 * c0, lda, ks1 - c0);
       if (c0 + 8 < ks1) {
         if (c0 + 16 < ks1) seq_b_load<8>(b[0], Wp, nks, t, c0 + 16, ks1 - c0 - 16, lane);
-        seq_b_mma<8>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, ks1 - c0 - 8);
+        seq_b_mma<8, false, HALF>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, ks1 - c0 - 8);
       }
     }
   }
   float* r = sR + part * 32 * srs + n0 + 4 * lg;
   *reinterpret_cast<float4*>(r + l16 * srs) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
-  *reinterpret_cast<float4*>(r + (16 + l16) * srs) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+  if (!HALF) *reinterpret_cast<float4*>(r + (16 + l16) * srs) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
 }
 
 // ================================================================================================================ row passes
@@ -361,21 +393,24 @@ __device__ __forceinline__ void seq_parts_sum(float (&v)[CW], const float* sR, c
 // a [32][ncol] LDS tile -> the sequence's rows in global memory, 16 bytes per thread and pass: every wave-instruction writes 1 KB of
 // consecutive addresses.  (The MFMA epilogues do NOT store their tiles to global themselves: a fragment-shaped store is 16 rows x
 // 64 bytes per instruction and moves ~15 B/clk per CU, like the fragment-shaped loads -- tools/ubench/frag_load_bench.hip.)
-__device__ __forceinline__ void seq_tile_out(float* __restrict__ dst, const float* sT, const int str, const int ncol, const int tid) {
+// rows rb .. rb + nrows - 1 of the tile (dst: the sequence's row 0)
+__device__ __forceinline__ void seq_tile_out(float* __restrict__ dst, const float* sT, const int str, const int ncol, const int tid, const int rb = 0,
+                                             const int nrows = 32) {
   const int q4 = ncol >> 2;
-  for (int e = tid; e < 32 * q4; e += GT_SEQ_NT) {
-    const int r = e / q4, c = (e - r * q4) * 4;
+  for (int e = tid; e < nrows * q4; e += GT_SEQ_NT) {
+    const int r = rb + e / q4, c = (e % q4) * 4;
     *reinterpret_cast<float4*>(dst + (unsigned)(r * ncol + c)) = *reinterpret_cast<const float4*>(sT + r * str + c);
   }
 }
 
 // LayerNorm forward: z (this thread's CW values, from zfun(row, c0, z)) -> y = LN(z) gamma + beta -> the LDS tile sY and the
 // global y / xhat / rstd rows of this sequence (gy, gxhat, grstd: wave-uniform bases of the sequence's first row)
-template <int DP, typename ZFun>
+template <int DP, bool HALF, typename ZFun>
 __device__ __forceinline__ void seq_ln_fwd(ZFun zfun, float* sY, const int str, const int d, const float* __restrict__ gamma,
-                                           const float* __restrict__ beta, float* gy, float* gxhat, float* grstd, const int tid) {
+                                           const float* __restrict__ beta, float* gy, float* gxhat, float* grstd, const int tid, const int rb) {
   constexpr int CW = DP / 16;
-  const int row = tid >> 4, seg = tid & 15, c0 = seg * CW;
+  if (HALF && tid >= 256) return;                            // 16 own rows: waves 0..3
+  const int row = rb + (tid >> 4), seg = tid & 15, c0 = seg * CW;
   const bool ok = c0 < d;
   float z[CW], ga[CW], be[CW];
 #pragma unroll
@@ -406,12 +441,13 @@ __device__ __forceinline__ void seq_ln_fwd(ZFun zfun, float* sY, const int str, 
 // LayerNorm backward: g (from gfun) -> dz = LNbwd(g) -> sDz (LDS, unmasked: the residual gradient), dz * dropout mask -> sDzm
 // (LDS: the next dgrad's A operand), both to global when gdz / gdzm are given (weight-gradient operands); the per-wave column
 // sums of g xhat / g (4 rows each) -> sP[wave][2][DP]; seq_ln_part sums them over the waves after the stage barrier.
-template <int DP, typename GFun>
+template <int DP, bool HALF, typename GFun>
 __device__ __forceinline__ void seq_ln_bwd(GFun gfun, float* sDz, float* sDzm, const int str, const int d, const float* __restrict__ gxhat,
                                            const float* __restrict__ grstd, const float* __restrict__ gamma, const SeqDropK& dk, const uint32_t key,
-                                           const uint32_t idx0, float* gdz, float* gdzm, float* sP, const int tid) {
+                                           const uint32_t idx0, float* gdz, float* gdzm, float* sP, const int tid, const int rb) {
   constexpr int CW = DP / 16;
-  const int row = tid >> 4, seg = tid & 15, c0 = seg * CW, lane = tid & 63, wave = tid >> 6;
+  if (HALF && tid >= 256) return;                            // 16 own rows: waves 0..3
+  const int row = rb + (tid >> 4), seg = tid & 15, c0 = seg * CW, lane = tid & 63, wave = tid >> 6;
   const bool ok = c0 < d;
   const unsigned o = (unsigned)(row * d + c0);
   float g[CW], xh[CW], ga[CW];
@@ -446,7 +482,7 @@ __device__ __forceinline__ void seq_ln_bwd(GFun gfun, float* sDz, float* sDzm, c
 }
 // ... after the barrier: dgamma / dbeta partials of this sequence -> part[2][d], waves summed in a fixed order.  Runs on the LAST
 // 2 * DP threads of the workgroup (the waves with the least matmul work in the stage that follows).
-template <int DP>
+template <int DP, bool HALF>
 __device__ __forceinline__ void seq_ln_part(const float* sP, float* part, const int d, const int tid) {
   const int t = tid - (GT_SEQ_NT - 2 * DP);
   if (t < 0) return;
@@ -454,7 +490,7 @@ __device__ __forceinline__ void seq_ln_part(const float* sP, float* part, const 
   if (c >= d) return;
   float s = sP[which * DP + c];
 #pragma unroll
-  for (int w = 1; w < GT_SEQ_WAVES; ++w) s += sP[(2 * w + which) * DP + c];
+  for (int w = 1; w < (HALF ? GT_SEQ_WAVES / 2 : GT_SEQ_WAVES); ++w) s += sP[(2 * w + which) * DP + c];
   part[which * d + c] = s;
 }
 
@@ -732,45 +768,57 @@ template <int DP> struct SeqGeo {
   static constexpr int UNI = QKV > FFN ? QKV : FFN;          // the qkv tile and the FFN tile are never live together in the forward
 };
 // EXACT: d_model == DP (every shipped configuration): d is a compile-time constant, the matmul bodies are branch-free.
-template <int DP, int HDC, bool EXACT>
+// SPLIT: TWO workgroups per sequence, 16 token rows each, and one launch per PHASE (a.phase):  every stage but attention is
+// row-local, and attention needs the other half's K / V rows -- so a phase ends where those are produced (the in-proj) and the next
+// launch picks its state up from the saved-activation buffers the backward needs anyway.  phase 0: input layer + in-proj(0);
+// phase l + 1: attention(l) .. norm2(l), then in-proj(l + 1) or the output layer.  2 x batch workgroups fill twice the CUs: the
+// path for small batches of the d_model-128 class, where a sequence's matmuls are bound by the MFMA rate of one CU.
+template <int DP, int HDC, bool EXACT, bool SPLIT>
 __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   using G = SeqGeo<DP>;
   constexpr int SX = G::SX, SH = G::SH, SQ = G::SQ, SRS = G::SRS, CW = G::CW, NK = G::NK;
   constexpr int HD = SeqHd<HDC>::HD;
   constexpr bool PAD = SeqHd<HDC>::PAD;
+  constexpr bool HALF = SPLIT;
+  constexpr int NH = HALF ? 1 : 2, NROW = HALF ? 16 : 32;    // 16-row halves a matmul epilogue sees / rows this workgroup owns
   __shared__ __attribute__((aligned(16))) float sX[G::TILE], sX1[G::TILE], sC[G::TILE], sR[G::RES], sU[G::UNI];
   float* const sQ = sU;                                      // qkv tile: in-proj -> attention
   float* const sH = sU;                                      // FFN tile: FFN1 -> FFN2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x, d = EXACT ? DP : a.d, F = a.F;
+  const int b = SPLIT ? blockIdx.x >> 1 : blockIdx.x, rb = SPLIT ? 16 * (blockIdx.x & 1) : 0;
+  const int d = EXACT ? DP : a.d, F = a.F;
   const size_t r0 = (size_t)b * 32;                          // first token row of this sequence
   const float* const zp = gt_zero_ptr();
   const float* prm = a.prm;
   float* ws = a.ws;
   const SeqDropK dk = seq_dropk(a);
   const uint32_t idxd = (uint32_t)(r0 * d), idxf = (uint32_t)(r0 * F);   // dropout element index of this sequence's first row
+  const float ascale = 1.0f / sqrtf((float)a.hd);
+  // rows rb .. rb + nrows - 1 of a [32][ncol] tile of this sequence, global -> LDS, 16 bytes per thread and pass
+  auto load_rows = [&](float* dst, const int str, const float* src, const int ncol, const int rb_, const int nrows) {
+    const int q4 = ncol >> 2;
+    for (int e = tid; e < nrows * q4; e += GT_SEQ_NT) {
+      const int r = rb_ + e / q4, c = (e % q4) * 4;
+      *reinterpret_cast<float4*>(dst + r * str + c) = *reinterpret_cast<const float4*>(src + (unsigned)(r * ncol + c));
+    }
+  };
 
-#ifdef GT_SEQ_STAMPS
-  GT_SUBSET(false);
-  GT_BARRIER();
-#endif
-  GT_STAMP(0);
-  // ---- input layer: a0 = x Win^T + b; x0 = drop(relu(a0) + pe)     (A tile: the 32 x S input rows, zero-padded to 32 columns)
-  for (int e = tid; e < 32 * 32; e += GT_SEQ_NT) {
-    const int r = e >> 5, c = e & 31;
-    sC[r * SX + c] = *(c < a.S ? a.xin + (r0 + r) * a.S + c : zp);
-  }
-  GT_BARRIER();
-  GT_STAMP(1);
-  {
+  // ---- input layer: a0 = x Win^T + b; x0 = drop(relu(a0) + pe)     (A tile: the own input rows, zero-padded to 32 columns)
+  auto input_layer = [&]() {
+    for (int e = tid; e < NROW * 32; e += GT_SEQ_NT) {
+      const int r = rb + (e >> 5), c = e & 31;
+      sC[r * SX + c] = *(c < a.S ? a.xin + (r0 + r) * a.S + c : zp);
+    }
+    GT_BARRIER();
+    GT_STAMP(1);
     const uint32_t key = seq_key(dk, GT_SITE_PE_ENC);
     float* ga0 = ws + a.a0 + r0 * d;
     float* gx0 = ws + a.x0 + r0 * d;
-    seq_mm_edge<false, false, 2>(sC, SX, a.S, prm + a.in_w, a.S, d, prm + a.in_b, wave, lane, zp,
-                              [&](int n0, const f32x4& c0, const f32x4& c1, const float (&bi)[4]) {
+    seq_mm_edge<false, false, 2, HALF>(sC + rb * SX, SX, a.S, prm + a.in_w, a.S, d, prm + a.in_b, wave, lane, zp,
+                                       [&](int n0, const f32x4& c0, const f32x4& c1, const float (&bi)[4]) {
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const int row = 16 * h2 + l16, col = n0 + 4 * lg;
+      for (int h2 = 0; h2 < NH; ++h2) {
+        const int row = rb + 16 * h2 + l16, col = n0 + 4 * lg;
         const f32x4& c = h2 ? c1 : c0;
         const float4 pe = *reinterpret_cast<const float4*>(a.pe + row * d + col);
         const unsigned o = (unsigned)(row * d + col);
@@ -785,45 +833,46 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         *reinterpret_cast<float4*>(&sX[row * SX + col]) = v;
       }
     });
-  }
-  GT_BARRIER();
-
-  const float ascale = 1.0f / sqrtf((float)a.hd);
-  for (int l = 0; l < a.L; ++l) {
+    GT_BARRIER();
+  };
+  // ---- in-proj of layer l: qkv = x Win^T + b -> the LDS qkv tile (own rows); ends with a barrier
+  auto in_proj = [&](const int l) {
+    const float* pl = prm + (int64_t)l * a.pstride;
+    const float* kf = ws + a.pack_f + (int64_t)l * a.kstride;
+    GT_STAMP(2 + 10 * l);
+    GT_SUBSET(l == 1);
+    seq_mm_tiles<NK, (3 * DP / 16 + 7) / 8, EXACT, HALF>(sX + rb * SX, SX, d, kf, 3 * d, pl + a.p0.in_b, wave, lane,
+                                                          [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
+      const int col = n0 + 4 * lg;
+      *reinterpret_cast<float4*>(&sQ[(rb + l16) * SQ + col]) = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
+      if (!HALF) *reinterpret_cast<float4*>(&sQ[(16 + l16) * SQ + col]) = make_float4(c1[0] + bi.x, c1[1] + bi.y, c1[2] + bi.z, c1[3] + bi.w);
+    });
+    GT_BARRIER();
+    GT_STAMP(2 + 10 * l + 1);
+    GT_SUBSET(false);
+  };
+  // ---- the rest of layer l: attention .. norm2 -> the next layer's input in sX (own rows); ends with a barrier
+  auto layer_rest = [&](const int l, const bool save_qkv) {
     const float* pl = prm + (int64_t)l * a.pstride;          // this layer's parameters / saved activations (wave-uniform bases)
     const float* kf = ws + a.pack_f + (int64_t)l * a.kstride;                    // its fragment-ordered weights: in_w, out_w, w1, w2
     const float* kf_out = kf + 3 * d * d, *kf_w1 = kf + 4 * d * d, *kf_w2 = kf_w1 + d * F;
     float* wl = ws + (int64_t)l * a.wstride;
     const int site0 = GT_SITE_LAYER0 + 8 * l;
     const int sb = 2 + 10 * l;                               // stamp base of this layer
-    GT_STAMP(sb);
-    GT_SUBSET(l == 1);
-    // ---- in-proj: qkv = x Win^T + b -> LDS (the attention bodies read it there; saved to global for the backward from there)
-    {
-      seq_mm_tiles<NK, (3 * DP / 16 + 7) / 8, EXACT>(sX, SX, d, kf, 3 * d, pl + a.p0.in_b, wave, lane,
-                                                     [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
-        const int col = n0 + 4 * lg;
-        const float4 o0 = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
-        const float4 o1 = make_float4(c1[0] + bi.x, c1[1] + bi.y, c1[2] + bi.z, c1[3] + bi.w);
-        *reinterpret_cast<float4*>(&sQ[l16 * SQ + col]) = o0;
-        *reinterpret_cast<float4*>(&sQ[(16 + l16) * SQ + col]) = o1;
-      });
-    }
-    GT_BARRIER();
-    GT_STAMP(sb + 1);
-    GT_SUBSET(false);
-    // ---- attention: four heads at a time (wave pair p = wave >> 1 takes head h4 + p); operands from the LDS qkv tile,
-    // P to global, ctx to the LDS tile
-    seq_tile_out(wl + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid);
+    // ---- attention: operands from the LDS qkv tile, P to global, ctx to the LDS tile.  Whole: wave pair p takes head h4 + p and the
+    // pair's two waves the two query tiles; SPLIT: wave w takes head h8 + w, query tile = the own half.  The qkv tile goes to global
+    // here (saved for the backward) -- line-shaped, see seq_tile_out.
+    if (save_qkv) seq_tile_out(wl + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
-      for (int h4 = 0; h4 < a.H; h4 += GT_SEQ_WAVES / 2) {
-        const int h = h4 + (wave >> 1);
+      constexpr int HPR = HALF ? GT_SEQ_WAVES : GT_SEQ_WAVES / 2;              // heads per round
+      for (int h4 = 0; h4 < a.H; h4 += HPR) {
+        const int h = h4 + (HALF ? wave : wave >> 1);
         if (h < a.H) {
           SeqAttn at;
           at.q = sQ + h * a.hd; at.k = at.q + d; at.v = at.q + 2 * d; at.ldq = SQ; at.hd = a.hd; at.scale = ascale;
           at.pidx = (uint32_t)((b * a.H + h) * 1024); at.P = wl + a.w0.P + (size_t)(b * a.H + h) * 1024;
-          seq_attn_fwd<HD, PAD>(at, sC + h * a.hd, SX, dk, key, wave & 1, lane);
+          seq_attn_fwd<HD, PAD>(at, sC + h * a.hd, SX, dk, key, HALF ? (rb >> 4) : (wave & 1), lane);
         }
       }
     }
@@ -831,12 +880,12 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     GT_STAMP(sb + 2);
     // ---- out-proj (raw product -> sR part 0); the ctx tile also goes to global here (operand of the out-proj weight gradient)
     {
-      seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid);
+      seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid, rb, NROW);
       if (DP <= 64) seq_mm_square(sC, SX, d, kf_out, sR, SRS, wave, lane);
       else
-        seq_mm_tiles<NK, 1, EXACT>(sC, SX, d, kf_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
-          *reinterpret_cast<float4*>(&sR[l16 * SRS + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
-          *reinterpret_cast<float4*>(&sR[(16 + l16) * SRS + n0 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+        seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kf_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
+          *reinterpret_cast<float4*>(&sR[(rb + l16) * SRS + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+          if (!HALF) *reinterpret_cast<float4*>(&sR[(16 + l16) * SRS + n0 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
         });
     }
     GT_BARRIER();
@@ -845,36 +894,40 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_DROP1);
       const float* bo = pl + a.p0.out_b;
-      seq_ln_fwd<DP>([&](int row, int c0, float (&z)[CW]) {
+      seq_ln_fwd<DP, HALF>([&](int row, int c0, float (&z)[CW]) {
         float bi[CW], xr[CW];
         SeqVec<CW>::ld(z, &sR[row * SRS + c0]); SeqVec<CW>::ld(bi, bo + c0); SeqVec<CW>::ld(xr, &sX[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, wl + a.w0.x1 + r0 * d, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid);
+      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, wl + a.w0.x1 + r0 * d, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 4);
     // ---- FFN1: hact = drop(relu(x1 W1^T + b1))
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_FFN);
-      seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT>(sX1, SX, d, kf_w1, F, pl + a.p0.b1, wave, lane,
-                                                 [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
+      seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT, HALF>(sX1 + rb * SX, SX, d, kf_w1, F, pl + a.p0.b1, wave, lane,
+                                                       [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
         const int col = n0 + 4 * lg;
-        const unsigned o0 = (unsigned)(l16 * F + col), o1 = (unsigned)((16 + l16) * F + col);
-        float4 v0, v1;
-        v0.x = fmaxf(c0[0] + bi.x, 0.f) * seq_dmul(dk, key, idxf + o0);     v1.x = fmaxf(c1[0] + bi.x, 0.f) * seq_dmul(dk, key, idxf + o1);
-        v0.y = fmaxf(c0[1] + bi.y, 0.f) * seq_dmul(dk, key, idxf + o0 + 1); v1.y = fmaxf(c1[1] + bi.y, 0.f) * seq_dmul(dk, key, idxf + o1 + 1);
-        v0.z = fmaxf(c0[2] + bi.z, 0.f) * seq_dmul(dk, key, idxf + o0 + 2); v1.z = fmaxf(c1[2] + bi.z, 0.f) * seq_dmul(dk, key, idxf + o1 + 2);
-        v0.w = fmaxf(c0[3] + bi.w, 0.f) * seq_dmul(dk, key, idxf + o0 + 3); v1.w = fmaxf(c1[3] + bi.w, 0.f) * seq_dmul(dk, key, idxf + o1 + 3);
-        *reinterpret_cast<float4*>(&sH[l16 * SH + col]) = v0;
-        *reinterpret_cast<float4*>(&sH[(16 + l16) * SH + col]) = v1;
+#pragma unroll
+        for (int h2 = 0; h2 < NH; ++h2) {
+          const int row = rb + 16 * h2 + l16;
+          const f32x4& c = h2 ? c1 : c0;
+          const unsigned o = (unsigned)(row * F + col);
+          float4 v;
+          v.x = fmaxf(c[0] + bi.x, 0.f) * seq_dmul(dk, key, idxf + o);
+          v.y = fmaxf(c[1] + bi.y, 0.f) * seq_dmul(dk, key, idxf + o + 1);
+          v.z = fmaxf(c[2] + bi.z, 0.f) * seq_dmul(dk, key, idxf + o + 2);
+          v.w = fmaxf(c[3] + bi.w, 0.f) * seq_dmul(dk, key, idxf + o + 3);
+          *reinterpret_cast<float4*>(&sH[row * SH + col]) = v;
+        }
       });
     }
     GT_BARRIER();
     GT_STAMP(sb + 5);
     // ---- FFN2 (K = F: split over the waves) -> partial tiles; the FFN tile goes to global (saved for the backward)
-    seq_tile_out(wl + a.w0.hact + r0 * F, sH, SH, F, tid);
-    seq_mm_splitk(sH, SH, F, kf_w2, d, sR, SRS, wave, lane);
+    seq_tile_out(wl + a.w0.hact + r0 * F, sH, SH, F, tid, rb, NROW);
+    seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kf_w2, d, sR + rb * SRS, SRS, wave, lane);
     GT_BARRIER();
     GT_STAMP(sb + 6);
     // ---- z2 = drop(sum of the parts + b2) + x1;  norm2 -> the next layer's input
@@ -882,49 +935,86 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_DROPF);
       const float* b2 = pl + a.p0.b2;
       const int parts = seq_splitk_parts(d);
-      seq_ln_fwd<DP>([&](int row, int c0, float (&z)[CW]) {
+      seq_ln_fwd<DP, HALF>([&](int row, int c0, float (&z)[CW]) {
         float bi[CW], xr[CW];
         seq_parts_sum<CW>(z, sR, SRS, parts, row, c0); SeqVec<CW>::ld(bi, b2 + c0); SeqVec<CW>::ld(xr, &sX1[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, wl + a.w0.xout + r0 * d, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid);
+      }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, wl + a.w0.xout + r0 * d, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 7);
-  }
+  };
   // ---- final encoder norm -> memory, then the output layer: [h logits | sigmoid v | 0.5 tanh o]
-  seq_ln_fwd<DP>([&](int row, int c0, float (&z)[CW]) { SeqVec<CW>::ld(z, &sX[row * SX + c0]); }, sC, SX, d, prm + a.encn_w, prm + a.encn_b,
-                 ws + a.memory + r0 * d, ws + a.enc_xhat + r0 * d, ws + a.enc_rstd + r0, tid);
-  GT_BARRIER();
-  seq_mm_edge<false, true, NK>(sC, SX, d, prm + a.out_w, d, GT_TGT, prm + a.out_b, wave, lane, zp,
-                           [&](int n0, const f32x4& c0, const f32x4& c1, const float (&bi)[4]) {
+  auto output_layer = [&]() {
+    seq_ln_fwd<DP, HALF>([&](int row, int c0, float (&z)[CW]) { SeqVec<CW>::ld(z, &sX[row * SX + c0]); }, sC, SX, d, prm + a.encn_w, prm + a.encn_b,
+                         ws + a.memory + r0 * d, ws + a.enc_xhat + r0 * d, ws + a.enc_rstd + r0, tid, rb);
+    GT_BARRIER();
+    seq_mm_edge<false, true, NK, HALF>(sC + rb * SX, SX, d, prm + a.out_w, d, GT_TGT, prm + a.out_b, wave, lane, zp,
+                                       [&](int n0, const f32x4& c0, const f32x4& c1, const float (&bi)[4]) {
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const f32x4& c = h2 ? c1 : c0;
+      for (int h2 = 0; h2 < NH; ++h2) {
+        const f32x4& c = h2 ? c1 : c0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = n0 + 4 * lg + r;
-        if (col < GT_TGT) {
-          float v = c[r] + bi[r];
-          if (col >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
-          else if (col >= GT_VOICES) v = gt_sigmoid(v);
-          a.hvo[(r0 + 16 * h2 + l16) * GT_TGT + col] = v;
+        for (int r = 0; r < 4; ++r) {
+          const int col = n0 + 4 * lg + r;
+          if (col < GT_TGT) {
+            float v = c[r] + bi[r];
+            if (col >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
+            else if (col >= GT_VOICES) v = gt_sigmoid(v);
+            a.hvo[(r0 + rb + 16 * h2 + l16) * GT_TGT + col] = v;
+          }
         }
       }
+    });
+  };
+
+#ifdef GT_SEQ_STAMPS
+  GT_SUBSET(false);
+  GT_BARRIER();
+#endif
+  if (!SPLIT) {
+    GT_STAMP(0);
+    input_layer();
+    for (int l = 0; l < a.L; ++l) { in_proj(l); layer_rest(l, true); }
+    output_layer();
+    GT_STAMP(2 + 10 * a.L);
+  } else if (a.phase == 0) {
+    input_layer();
+    in_proj(0);
+    seq_tile_out(ws + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
+  } else {
+    const int l = a.phase - 1;
+    load_rows(sX, SX, (l == 0 ? ws + a.x0 : ws + (int64_t)(l - 1) * a.wstride + a.w0.xout) + r0 * d, d, rb, NROW);   // own rows of the layer input
+    load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                          // q / k / v of the whole sequence
+    GT_BARRIER();
+    layer_rest(l, false);
+    if (l + 1 < a.L) {
+      in_proj(l + 1);
+      seq_tile_out(ws + (int64_t)(l + 1) * a.wstride + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
+    } else {
+      output_layer();
     }
-  });
-  GT_STAMP(2 + 10 * a.L);
+  }
 }
 
 // ================================================================================================================ backward
-// LayerNorm jobs (dgamma / dbeta partial blocks, [B][2][d] each) in the order the kernel fills them: 0 = final norm, then for
-// l = L-1 .. 0: 1 + 2 (L-1-l) = norm2 of layer l, 2 + 2 (L-1-l) = norm1 of layer l.  The host registers them in this order.
-template <int DP, int HDC, bool EXACT>
+// LayerNorm jobs (dgamma / dbeta partial blocks, one [2][d] row per workgroup) in the order the kernel fills them: 0 = final norm, then
+// for l = L-1 .. 0: 1 + 2 (L-1-l) = norm2 of layer l, 2 + 2 (L-1-l) = norm1 of layer l.  The host registers them in this order.
+// SPLIT (two workgroups per sequence, 16 rows each, one launch per phase): only the attention backward couples the rows (dk / dv
+// contract over all queries), so a phase ends at dctx -- own rows to the hand-over buffer a.dctx -- and the next one begins with the
+// attention backward of the WHOLE sequence, computed by both workgroups of the pair (a fifth of a phase; no exchange, no
+// second launch), each keeping its own rows of dq / dk / dv.  phase 0: output-layer dgrad .. out-proj dgrad of layer L-1;
+// phase p: attention backward + in-proj dgrad of layer L-p, then norm2 backward .. out-proj dgrad of layer L-p-1 (or the input
+// layer's backward).
+template <int DP, int HDC, bool EXACT, bool SPLIT>
 __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   using G = SeqGeo<DP>;
   constexpr int SX = G::SX, SH = G::SH, SQ = G::SQ, SRS = G::SRS, CW = G::CW, NK = G::NK;
   constexpr int HD = SeqHd<HDC>::HD;
   constexpr bool PAD = SeqHd<HDC>::PAD;
+  constexpr bool HALF = SPLIT;
+  constexpr int NROW = HALF ? 16 : 32;
   // sZ: gradient w.r.t. the last layer's output (first LayerNorm backward only), then dctx; sDZ: the LayerNorm backward's dz (residual
   // gradient); sC: dz * dropout mask (A operand of the next dgrad); sQ: the saved qkv tile of the layer, overwritten IN PLACE by
   // dq / dk / dv in the attention backward; sH: the FFN tile (hact, then dhid in place).  ALIAS (DP 128: 160 KB do not hold both):
@@ -936,7 +1026,8 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   float* const sQ = sU;
   float* const sH = ALIAS ? sU : sU + G::QKV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x, d = EXACT ? DP : a.d, F = a.F;
+  const int b = SPLIT ? blockIdx.x >> 1 : blockIdx.x, rb = SPLIT ? 16 * (blockIdx.x & 1) : 0;
+  const int d = EXACT ? DP : a.d, F = a.F;
   const size_t r0 = (size_t)b * 32;
   const float* const zp = gt_zero_ptr();
   const float* prm = a.prm;
@@ -945,48 +1036,45 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   const uint32_t idxd = (uint32_t)(r0 * d);
   const float mscale = dk.thr ? dk.scale : 1.0f;
   const float ascale = 1.0f / sqrtf((float)a.hd);
-  auto part_at = [&](int job) { return ws + a.ln_part + (int64_t)job * a.ln_part_stride + (size_t)b * 2 * d; };
-  // a [32][ncol] tile of this sequence, global -> LDS, 16 bytes per thread and pass
-  auto load_tile = [&](float* dst, const int str, const float* src, const int ncol) {
+  auto part_at = [&](int job) { return ws + a.ln_part + (int64_t)job * a.ln_part_stride + (size_t)blockIdx.x * 2 * d; };
+  // rows rb_ .. rb_ + nrows - 1 of a [32][ncol] tile of this sequence, global -> LDS, 16 bytes per thread and pass
+  auto load_rows = [&](float* dst, const int str, const float* src, const int ncol, const int rb_, const int nrows) {
     const int q4 = ncol >> 2;
-    for (int e = tid; e < 32 * q4; e += GT_SEQ_NT) {
-      const int r = e / q4, c = (e - r * q4) * 4;
+    for (int e = tid; e < nrows * q4; e += GT_SEQ_NT) {
+      const int r = rb_ + e / q4, c = (e % q4) * 4;
       *reinterpret_cast<float4*>(dst + r * str + c) = *reinterpret_cast<const float4*>(src + (unsigned)(r * ncol + c));
     }
   };
 
-#ifdef GT_SEQ_STAMPS
-  GT_SUBSET(false);
-  GT_BARRIER();
-#endif
-  GT_STAMP(100);
-  // ---- output layer dgrad: dmem = dlogits Wout   (A tile: 32 x 27 zero-padded to 32 columns)
-  for (int e = tid; e < 32 * 32; e += GT_SEQ_NT) {
-    const int r = e >> 5, c = e & 31;
-    sC[r * SX + c] = *(c < GT_TGT ? ws + a.dlogits + (r0 + r) * GT_TGT + c : zp);
-  }
-  load_tile(sH, SH, ws + a.w0.hact + (int64_t)(a.L - 1) * a.wstride + r0 * F, F);
-  GT_BARRIER();
-  seq_mm_edge<true, true, 2>(sC, SX, GT_TGT, prm + a.out_w, d, d, nullptr, wave, lane, zp,
-                          [&](int n0, const f32x4& c0, const f32x4& c1, const float (&)[4]) {
-    const int col = n0 + 4 * lg;
-    *reinterpret_cast<float4*>(&sZ[l16 * SX + col]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
-    *reinterpret_cast<float4*>(&sZ[(16 + l16) * SX + col]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
-  });
-  GT_BARRIER();
-  // ---- final norm backward -> gradient w.r.t. the last layer's output (sZ, in place); its dz is not a weight-gradient operand
-  {
-    SeqDropK nd = dk; nd.thr = 0u;
-    seq_ln_bwd<DP>([&](int row, int c0, float (&g)[CW]) { SeqVec<CW>::ld(g, &sZ[row * SX + c0]); }, sZ, sC, SX, d, ws + a.enc_xhat + r0 * d,
-                   ws + a.enc_rstd + r0, prm + a.encn_w, nd, 0u, 0u, nullptr, nullptr, sP, tid);
-  }
-  GT_BARRIER();
-  seq_ln_part<DP>(sP, part_at(0), d, tid);
-  GT_BARRIER();                                                 // (sP is rewritten by the first norm2 backward below)
-  GT_STAMP(101);
-
-  bool first = true;                                            // the first norm2 backward reads g from sG; later ones add the parts
-  for (int l = a.L - 1; l >= 0; --l) {
+  // ---- output layer dgrad: dmem = dlogits Wout (A tile: own rows x 27, zero-padded to 32 columns); final norm backward -> the
+  // gradient w.r.t. the last layer's output (sZ, in place; its dz is not a weight-gradient operand)
+  auto prologue = [&]() {
+    for (int e = tid; e < NROW * 32; e += GT_SEQ_NT) {
+      const int r = rb + (e >> 5), c = e & 31;
+      sC[r * SX + c] = *(c < GT_TGT ? ws + a.dlogits + (r0 + r) * GT_TGT + c : zp);
+    }
+    if (!SPLIT) load_rows(sH, SH, ws + a.w0.hact + (int64_t)(a.L - 1) * a.wstride + r0 * F, F, 0, 32);
+    GT_BARRIER();
+    seq_mm_edge<true, true, 2, HALF>(sC + rb * SX, SX, GT_TGT, prm + a.out_w, d, d, nullptr, wave, lane, zp,
+                                     [&](int n0, const f32x4& c0, const f32x4& c1, const float (&)[4]) {
+      const int col = n0 + 4 * lg;
+      *reinterpret_cast<float4*>(&sZ[(rb + l16) * SX + col]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+      if (!HALF) *reinterpret_cast<float4*>(&sZ[(16 + l16) * SX + col]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+    });
+    GT_BARRIER();
+    {
+      SeqDropK nd = dk; nd.thr = 0u;
+      seq_ln_bwd<DP, HALF>([&](int row, int c0, float (&g)[CW]) { SeqVec<CW>::ld(g, &sZ[row * SX + c0]); }, sZ, sC, SX, d, ws + a.enc_xhat + r0 * d,
+                           ws + a.enc_rstd + r0, prm + a.encn_w, nd, 0u, 0u, nullptr, nullptr, sP, tid, rb);
+    }
+    GT_BARRIER();
+    seq_ln_part<DP, HALF>(sP, part_at(0), d, tid);
+    GT_BARRIER();                                                 // (sP is rewritten by the first norm2 backward below)
+    GT_STAMP(101);
+  };
+  // ---- the row-local chain of layer l: norm2 backward .. out-proj dgrad -> dctx in sZ (own rows); ends with a barrier.
+  // fromg: g = gradient w.r.t. this layer's output comes from sZ (layer L-1); else g = the in-proj dgrad parts of layer l+1 + its dz1
+  auto chain = [&](const int l, const bool fromg) {
     const float* pl = prm + (int64_t)l * a.pstride;
     const float* kb = ws + a.pack_b + (int64_t)l * a.kstride;                    // dgrad-ordered weights: in_w, out_w, w1, w2
     const float* kb_out = kb + 3 * d * d, *kb_w1 = kb + 4 * d * d, *kb_w2 = kb_w1 + d * F;
@@ -994,14 +1082,12 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     float* tl = ws + (int64_t)l * a.tstride;
     const int site0 = GT_SITE_LAYER0 + 8 * l, jb = 1 + 2 * (a.L - 1 - l);
     const int sb = 102 + 10 * (a.L - 1 - l);
-    // ---- norm2 backward: g = gradient w.r.t. this layer's output (l == L-1: sZ; else the in-proj dgrad parts of layer l+1 + its
-    // dz1) -> dz2 -> sDZ, dz2 * mask(dropout on the FFN output) -> sC; both to global for the weight gradients
-    if (ALIAS && !first) load_tile(sH, SH, wl + a.w0.hact + r0 * F, F);          // (the in-proj dgrad above has read dqkv out of this storage)
+    // ---- norm2 backward -> dz2 -> sDZ, dz2 * mask(dropout on the FFN output) -> sC; both to global for the weight gradients
+    if (SPLIT || (ALIAS && !fromg)) load_rows(sH, SH, wl + a.w0.hact + r0 * F, F, rb, NROW);   // (whole, !ALIAS: requested a layer ahead)
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_DROPF);
       const int parts = seq_splitk_parts(d);
-      const bool fromg = first;
-      seq_ln_bwd<DP>([&](int row, int c0, float (&g)[CW]) {
+      seq_ln_bwd<DP, HALF>([&](int row, int c0, float (&g)[CW]) {
         if (fromg) SeqVec<CW>::ld(g, &sZ[row * SX + c0]);
         else {
           float r[CW];
@@ -1010,63 +1096,69 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
           for (int e = 0; e < CW; ++e) g[e] += r[e];
         }
       }, sDZ, sC, SX, d, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, pl + a.p0.n2w, dk, key, idxd, tl + a.t0.dzA + r0 * d,
-                     dk.thr ? tl + a.t0.dzAm + r0 * d : nullptr, sP, tid);
-      first = false;
+                           dk.thr ? tl + a.t0.dzAm + r0 * d : nullptr, sP, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb);
     // ---- FFN2 dgrad: dhid = (dz2m W2) * [hact != 0] * 1/(1-p), in place over the hact tile in sH
-    seq_ln_part<DP>(sP, part_at(jb), d, tid);
-    {
-      seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT>(sC, SX, d, kb_w2, F, nullptr, wave, lane,
-                                                [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
-        const int col = n0 + 4 * lg;
-        const float4 ha = *reinterpret_cast<const float4*>(&sH[l16 * SH + col]), hb = *reinterpret_cast<const float4*>(&sH[(16 + l16) * SH + col]);
-        const float4 o0 = make_float4(ha.x != 0.f ? c0[0] * mscale : 0.f, ha.y != 0.f ? c0[1] * mscale : 0.f, ha.z != 0.f ? c0[2] * mscale : 0.f,
-                                      ha.w != 0.f ? c0[3] * mscale : 0.f);
-        const float4 o1 = make_float4(hb.x != 0.f ? c1[0] * mscale : 0.f, hb.y != 0.f ? c1[1] * mscale : 0.f, hb.z != 0.f ? c1[2] * mscale : 0.f,
-                                      hb.w != 0.f ? c1[3] * mscale : 0.f);
-        *reinterpret_cast<float4*>(&sH[l16 * SH + col]) = o0;
-        *reinterpret_cast<float4*>(&sH[(16 + l16) * SH + col]) = o1;
-      });
-    }
+    seq_ln_part<DP, HALF>(sP, part_at(jb), d, tid);
+    seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT, HALF>(sC + rb * SX, SX, d, kb_w2, F, nullptr, wave, lane,
+                                                     [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
+      const int col = n0 + 4 * lg;
+#pragma unroll
+      for (int h2 = 0; h2 < (HALF ? 1 : 2); ++h2) {
+        float* hp = &sH[(rb + 16 * h2 + l16) * SH + col];
+        const f32x4& c = h2 ? c1 : c0;
+        const float4 ha = *reinterpret_cast<const float4*>(hp);
+        *reinterpret_cast<float4*>(hp) = make_float4(ha.x != 0.f ? c[0] * mscale : 0.f, ha.y != 0.f ? c[1] * mscale : 0.f,
+                                                     ha.z != 0.f ? c[2] * mscale : 0.f, ha.w != 0.f ? c[3] * mscale : 0.f);
+      }
+    });
     GT_BARRIER();
     GT_STAMP(sb + 1);
     // ---- FFN1 dgrad (K = F: split over the waves) -> partial tiles; dhid goes to global (operand of both FFN weight gradients)
-    seq_tile_out(tl + a.t0.dhid + r0 * F, sH, SH, F, tid);
-    seq_mm_splitk(sH, SH, F, kb_w1, d, sR, SRS, wave, lane);
+    seq_tile_out(tl + a.t0.dhid + r0 * F, sH, SH, F, tid, rb, NROW);
+    seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kb_w1, d, sR + rb * SRS, SRS, wave, lane);
     GT_BARRIER();
     GT_STAMP(sb + 2);
-    // ---- norm1 backward: g1 = parts + dz2 -> dz1 -> sDZ, dz1 * mask(dropout1) -> sC.  The saved qkv tile of this layer is
-    // requested now (ALIAS: over the FFN tile, which the FFN1 dgrad has finished reading)
-    load_tile(sQ, SQ, wl + a.w0.qkv + r0 * 3 * d, 3 * d);
+    // ---- norm1 backward: g1 = parts + dz2 -> dz1 -> sDZ, dz1 * mask(dropout1) -> sC.  Whole: the saved qkv tile of this layer is
+    // requested now (ALIAS: over the FFN tile, which the FFN1 dgrad has finished reading); SPLIT loads it at the next phase's start
+    if (!SPLIT) load_rows(sQ, SQ, wl + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_DROP1);
       const int parts = seq_splitk_parts(d);
-      seq_ln_bwd<DP>([&](int row, int c0, float (&g)[CW]) {
+      seq_ln_bwd<DP, HALF>([&](int row, int c0, float (&g)[CW]) {
         float r[CW];
         seq_parts_sum<CW>(g, sR, SRS, parts, row, c0); SeqVec<CW>::ld(r, &sDZ[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) g[e] += r[e];
       }, sDZ, sC, SX, d, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, pl + a.p0.n1w, dk, key, idxd, tl + a.t0.dzB + r0 * d,
-                     dk.thr ? tl + a.t0.dzBm + r0 * d : nullptr, sP, tid);
+                           dk.thr ? tl + a.t0.dzBm + r0 * d : nullptr, sP, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 3);
     // ---- out-proj dgrad: dctx = dz1m Wo -> sZ (LDS: the attention backward reads it there)
-    seq_ln_part<DP>(sP, part_at(jb + 1), d, tid);
+    seq_ln_part<DP, HALF>(sP, part_at(jb + 1), d, tid);
     if (DP <= 64) seq_mm_square(sC, SX, d, kb_out, sZ, SX, wave, lane);
     else
-      seq_mm_tiles<NK, 1, EXACT>(sC, SX, d, kb_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
-        *reinterpret_cast<float4*>(&sZ[l16 * SX + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
-        *reinterpret_cast<float4*>(&sZ[(16 + l16) * SX + n0 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+      seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kb_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
+        *reinterpret_cast<float4*>(&sZ[(rb + l16) * SX + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+        if (!HALF) *reinterpret_cast<float4*>(&sZ[(16 + l16) * SX + n0 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
       });
     GT_BARRIER();
     GT_STAMP(sb + 4);
-    // ---- attention backward, four heads at a time: q / k / v from the LDS tile, P from global (saved), dctx from LDS; dq / dk / dv
-    // replace q / k / v of the head in place (every wave of the round has finished reading before anyone stores: third barrier)
+  };
+  // ---- attention backward of the whole sequence (four heads at a time: q / k / v from the LDS tile, P from global (saved), dctx
+  // from LDS; dq / dk / dv replace q / k / v of the head in place -- every wave of the round has finished reading before anyone
+  // stores: third barrier), own rows of dqkv -> global (operand of the in-proj weight gradient), in-proj dgrad (K = 3 d: split over
+  // the waves) -> partial tiles; ends with a barrier
+  auto attn_inproj = [&](const int l) {
+    const float* kb = ws + a.pack_b + (int64_t)l * a.kstride;
+    float* wl = ws + (int64_t)l * a.wstride;
+    float* tl = ws + (int64_t)l * a.tstride;
+    const int sb = 102 + 10 * (a.L - 1 - l);
     {
-      const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
+      const uint32_t key = seq_key(dk, GT_SITE_LAYER0 + 8 * l + GT_SITE_ATTN);
       for (int h4 = 0; h4 < a.H; h4 += GT_SEQ_WAVES / 2) {
         const int h = h4 + (wave >> 1);
         const bool active = h < a.H;
@@ -1083,20 +1175,18 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     }
     GT_BARRIER();
     GT_STAMP(sb + 5);
-    // ---- dqkv tile -> global (operand of the in-proj weight gradient); in-proj dgrad (K = 3 d: split over the waves); the
-    // FFN tile of the next layer down is requested into sH (ALIAS: at the next layer's first stage instead)
-    seq_tile_out(tl + a.t0.dqkv + r0 * 3 * d, sQ, SQ, 3 * d, tid);
-    if (!ALIAS && l > 0) load_tile(sH, SH, ws + (int64_t)(l - 1) * a.wstride + a.w0.hact + r0 * F, F);
-    seq_mm_splitk(sQ, SQ, 3 * d, kb, d, sR, SRS, wave, lane);
+    seq_tile_out(tl + a.t0.dqkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
+    if (!SPLIT && !ALIAS && l > 0) load_rows(sH, SH, ws + (int64_t)(l - 1) * a.wstride + a.w0.hact + r0 * F, F, 0, 32);   // the next layer's FFN tile
+    seq_mm_splitk<HALF>(sQ + rb * SQ, SQ, 3 * d, kb, d, sR + rb * SRS, SRS, wave, lane);
     GT_BARRIER();
     GT_STAMP(sb + 6);
-  }
+  };
   // ---- InputLayer backward: da0 = (parts + dz1) * dropout mask * [a0 > 0] -> global (operand of the input layer's weight gradient)
-  {
+  auto input_bwd = [&]() {
     const uint32_t key = seq_key(dk, GT_SITE_PE_ENC);
     const int parts = seq_splitk_parts(d);
-    const int row = tid >> 4, c0 = (tid & 15) * CW;
-    if (c0 < d) {
+    const int row = rb + (tid >> 4), c0 = (tid & 15) * CW;
+    if (c0 < d && (!HALF || tid < 256)) {
       const unsigned o = (unsigned)(row * d + c0);
       float g[CW], r[CW], a0v[CW];
       seq_parts_sum<CW>(g, sR, SRS, parts, row, c0); SeqVec<CW>::ld(r, &sDZ[row * SX + c0]); SeqVec<CW>::ld(a0v, ws + a.a0 + r0 * d + o);
@@ -1104,6 +1194,35 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
       for (int e = 0; e < CW; ++e) { const float v = (g[e] + r[e]) * seq_dmul(dk, key, idxd + o + e); g[e] = a0v[e] > 0.f ? v : 0.f; }
       SeqVec<CW>::st(ws + a.da0 + r0 * d + o, g);
     }
+  };
+
+#ifdef GT_SEQ_STAMPS
+  GT_SUBSET(false);
+  GT_BARRIER();
+#endif
+  if (!SPLIT) {
+    GT_STAMP(100);
+    prologue();
+    for (int l = a.L - 1; l >= 0; --l) { chain(l, l == a.L - 1); attn_inproj(l); }
+    input_bwd();
+    GT_STAMP(102 + 10 * a.L);
+  } else if (a.phase == 0) {
+    prologue();
+    chain(a.L - 1, true);
+    seq_tile_out(ws + a.dctx + r0 * d, sZ, SX, d, tid, rb, NROW);
+  } else {
+    const int l = a.L - a.phase;
+    const int64_t hand = (int64_t)a.B * 32 * d;                                                             // floats per hand-over buffer
+    load_rows(sZ, SX, ws + a.dctx + ((a.phase - 1) & 1) * hand + r0 * d, d, 0, 32);                         // dctx of the whole sequence
+    load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                   // its saved q / k / v
+    load_rows(sDZ, SX, ws + (int64_t)l * a.tstride + a.t0.dzB + r0 * d, d, rb, NROW);                        // dz1 of layer l, own rows
+    GT_BARRIER();
+    attn_inproj(l);
+    if (l > 0) {
+      chain(l - 1, false);
+      seq_tile_out(ws + a.dctx + (a.phase & 1) * hand + r0 * d, sZ, SX, d, tid, rb, NROW);
+    } else {
+      input_bwd();
+    }
   }
-  GT_STAMP(102 + 10 * a.L);
 }
