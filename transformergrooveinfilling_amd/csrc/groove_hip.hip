@@ -691,8 +691,9 @@ static int encoder_fwd_chain(const Ctx& x, const float* pe, const float* src) {
 
 // ---- sequence-resident kernels (gt_seq.h): one workgroup per sequence walks the whole encoder -------------------------------
 // g_seq: 0 = off (GT_SEQ=0 / gt_set_seq(0)), 1 = every supported shape (GT_SEQ=1 / gt_set_seq(1): tests), 2 = by measurement (default):
-// always at d_model <= 64 (C1 1.9x, ClosedHH YAML 1.15x over one kernel per op); at d_model <= 128 a sequence's matmuls are bound
-// by the fp32 MFMA rate of the ONE CU its workgroup runs on, so from 64 sequences per GPU up (bs 64: tie, 96: 1.18x, 192: 1.53x).
+// always at d_model <= 64 (C1 1.9x, ClosedHH YAML 1.15x over one kernel per op) and at d_model 128 (two workgroups per sequence
+// while they fit the chip: bs 16 1.11x, 64 1.18x, 128 1.36x; one per sequence beyond: bs 192 1.53x); at the other widths of the
+// 128 class a sequence's matmuls are bound by the fp32 MFMA rate of the ONE CU its workgroup runs on: from 64 sequences per GPU up.
 static int g_seq = -1;
 extern "C" int gt_set_seq(int on) { g_seq = on != 0; return 0; }
 // SPLIT mode of the d_model-128 class: 2 x batch workgroups of 16 token rows, one launch per layer and direction (+1).  Default
@@ -725,7 +726,7 @@ static bool seq_supported(const gt_config& c) {
 }
 static bool use_seq(const gt_config& c) {
   if (g_seq < 0) { const char* e = getenv("GT_SEQ"); g_seq = !e ? 2 : e[0] == '0' ? 0 : 1; }
-  if (g_seq == 2 && c.d_model > 64 && c.batch < 64) return false;
+  if (g_seq == 2 && c.d_model > 64 && c.d_model != 128 && c.batch < 64) return false;   // (128 itself: the SPLIT kernels win from batch 16 up)
   return g_seq && seq_supported(c) && !(g_chain == 1);       // an explicit gt_set_chain(1) / GT_CHAIN=1 keeps the row-chain kernels
 }
 // kernel<DP, HDC, EXACT>: d_model class 32 / 64 / 128, head-dim class 0 (< 16) / 16 / 32 / 64, d_model == DP
