@@ -3,6 +3,9 @@ through GT_LIB_PATH).  usage: GT_LIB_PATH=.../libgroove_stamps.so python tools/s
 import os
 import sys
 
+os.environ.setdefault("GT_SEQ", "1")            # the whole-sequence kernels are the stamped ones
+os.environ.setdefault("GT_SEQ_SPLIT", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))

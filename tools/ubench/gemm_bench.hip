@@ -36,7 +36,7 @@ static void run32(const char* tag, GemmArgs g, int reps) {
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   const double us = 1e3 * ms / reps, tf = 2.0 * g.M * g.N * g.K / us / 1e6;
-  printf("%-44s grid %5d x %3d  LDS %6d B  %8.1f us  %6.1f TFLOP/s  (%.1f %% of 157.3)\n", tag, grid.y, grid.x, (int)(Gemm32Cfg::smem<BKM>() * 4), us, tf,
+  printf("%-44s grid %5d x %3d  LDS %6d B  %8.1f us  %6.1f TFLOP/s  (%.1f %% of 157.3)\n", tag, grid.y, grid.x, (int)(Gemm32Cfg::smem<false, BKM>() * 4), us, tf,
          100.0 * tf / 157.3);
 }
 

@@ -201,7 +201,7 @@ __device__ __forceinline__ float attn_ld1(const float* p, int col, int hd, const
   return *(col < hd ? p : zp);
 }
 // (body: one (sequence, head) pair `bh`, query tile `ti` (0 / 1) per wave -- the stand-alone kernel runs it with 2 waves per
-//  workgroup, the sequence-resident kernels of gt_seq.h with wave pairs of a 4-wave workgroup)
+//  workgroup; gt_seq.h carries the same scheme on LDS operands for the sequence-resident kernels)
 template <int HD, bool PAD>
 __device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const int bh, const int ti, const int lane) {
   constexpr int NQ = HD / 16;
