@@ -236,3 +236,20 @@ def test_indexed_train_step_and_voice_metrics():
         assert abs(m["Offset_MSE_" + v] - ((p[:, 18 + j] - t[:, 18 + j]) ** 2).mean()) < 1e-6
     assert abs(m["Velocity_MSE_Overall"] - ((p[:, 9:18] - t[:, 9:18]) ** 2).mean()) < 1e-6
     assert metrics.evaluate(model, xs, ys) == m                                             # bitwise reproducible
+
+
+def test_predict_walks_large_sets_in_chunks():
+    """engine.predict (ref:evaluator.py:173 hands over the whole evaluation set): any chunking gives the same HVO tensor, and the
+    default chunk grows with the set while the workspace fits (greedy decoding is launch-bound per call)."""
+    from transformergrooveinfilling_amd import layout
+    from transformergrooveinfilling_amd.engine import StepEngine, PREDICT_CHUNK
+    for Ld in (0, 1):
+        dims = dict(d_model=32, n_heads=4, dim_feedforward=64, num_encoder_layers=2, num_decoder_layers=Ld, dropout=0.1, embedding_size_src=16)
+        eng = StepEngine(batch_size=4, seed=2, **dims)
+        eng.load_named(layout.init_params(dims, seed=5))
+        x, _ = layout.synthetic_batch(70, 16, seed=9)
+        whole = eng.predict(x, chunk=128).cpu()
+        parts = eng.predict(x, chunk=32).cpu()                      # 32 + 32 + 6
+        assert torch.equal(whole, parts)
+        assert torch.equal(whole, eng.predict(x).cpu())
+        assert eng.predict_chunk(70) == PREDICT_CHUNK and eng.predict_chunk(4096) == 4096

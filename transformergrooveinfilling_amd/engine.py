@@ -22,7 +22,8 @@ from . import _lib, layout
 
 ALGO = {"sgd": 0, "adam": 1}
 OVERLAP_MIN_BYTES = 16 << 20
-PREDICT_CHUNK = 512                    # sequences per gt_predict call (workspace of one chunk is reused; C4: 3 GB)
+PREDICT_CHUNK = 512                    # floor of the sequences per gt_predict call
+PREDICT_WS_BYTES = 32 << 30            # ... the chunk grows (x2) while its workspace stays under this and under half the free HBM
 
 
 def _ptr(t):
@@ -320,13 +321,31 @@ class StepEngine:
                       None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(d_hvo), _ptr(s.ws), _ptr(self.state),
                       int(train), int(accumulate), self.stream)
 
-    def predict(self, x, use_thres=True, thres=0.5, chunk=PREDICT_CHUNK):
+    def predict_chunk(self, n):
+        """Sequences per gt_predict call for a set of n: as many as fit the workspace budget (greedy decoding is launch-bound --
+        2240 launches per call whatever the batch -- so 8 calls of 512 cost 2.4x one call of 4096)."""
+        d = self.dims
+        budget = PREDICT_WS_BYTES
+        if not self.on_host:
+            budget = min(budget, torch.cuda.mem_get_info(self.device)[0] // 2)
+        chunk = PREDICT_CHUNK
+        while chunk < n:
+            cfg = _lib.make_config(2 * chunk, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
+                                   d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
+            if 4 * self.lib.workspace_floats(cfg) > budget:
+                break
+            chunk *= 2
+        return chunk
+
+    def predict(self, x, use_thres=True, thres=0.5, chunk=None):
         """model.predict for ANY batch size (ref:evaluator.py:173 passes the whole evaluation set at once):
         returns a (N,32,27) HVO tensor on the device ([h | v | o], one D2H for the evaluator).  The set is walked in chunks
-        of `chunk` sequences over one cached workspace (sized for a chunk, not for N)."""
+        of `chunk` sequences (default: predict_chunk) over one cached workspace (sized for a chunk, not for N)."""
         x = torch.as_tensor(x, dtype=torch.float32).to(self.device).contiguous()
         n = x.shape[0]
         d = self.dims
+        if chunk is None:
+            chunk = self.predict_chunk(n)
         out = torch.empty(n, 32, 27, dtype=torch.float32, device=self.device)
         for i in range(0, n, chunk):
             m = min(chunk, n - i)
