@@ -52,3 +52,31 @@ sub = st[200:216]
 if sub[0]:
     print(" forward layer 1 in-proj, wave 0: issue first B loads %d; then per tile [wait + MFMAs, epilogue, gap]:" % (sub[1] - sub[0]),
           " ".join("[%d %d %d]" % (sub[3 + 3 * i] - sub[2 + 3 * i], sub[4 + 3 * i] - sub[3 + 3 * i], (sub[5 + 3 * i] - sub[4 + 3 * i]) if i < 2 else 0) for i in range(3)))
+
+if os.environ.get("GT_SEQ_SPLIT") == "1":
+    print(" SPLIT mode (two workgroups per sequence, one launch per phase): cycles of workgroup 0")
+    for ph in range(L + 1):
+        print("  forward phase %d: %d cycles" % (ph, st[61 + 2 * ph] - st[60 + 2 * ph]), end="")
+        if ph >= 1:
+            b = 2 + 10 * (ph - 1)
+            print("   load state %d  attention %d  out-proj %d  norm1 %d  FFN1 %d  FFN2 %d  norm2 %d  then %d" %
+                  (st[b + 1] - st[60 + 2 * ph], st[b + 2] - st[b + 1], st[b + 3] - st[b + 2], st[b + 4] - st[b + 3], st[b + 5] - st[b + 4],
+                   st[b + 6] - st[b + 5], st[b + 7] - st[b + 6], st[61 + 2 * ph] - st[b + 7]))
+        else:
+            print()
+    for ph in range(L + 1):
+        print("  backward phase %d: %d cycles" % (ph, st[161 + 2 * ph] - st[160 + 2 * ph]), end="")
+        if ph >= 1:
+            k = ph - 1                                   # attention / in-proj dgrad of layer L-ph use the stamp base of that layer
+            b = 102 + 10 * k
+            print("   load state + attention bwd %d  in-proj dgrad %d" % (st[b + 5] - st[160 + 2 * ph], st[b + 6] - st[b + 5]), end="")
+            if ph < L:
+                c = 102 + 10 * ph
+                print("  norm2 bwd %d  FFN2 dgrad %d  FFN1 dgrad %d  norm1 bwd %d  out-proj dgrad %d" %
+                      (st[c] - st[b + 6], st[c + 1] - st[c], st[c + 2] - st[c + 1], st[c + 3] - st[c + 2], st[c + 4] - st[c + 3]))
+            else:
+                print()
+        else:
+            c = 102
+            print("   prologue %d  norm2 bwd %d  FFN2 dgrad %d  FFN1 dgrad %d  norm1 bwd %d  out-proj dgrad %d" %
+                  (st[101] - st[160], st[c] - st[101], st[c + 1] - st[c], st[c + 2] - st[c + 1], st[c + 3] - st[c + 2], st[c + 4] - st[c + 3]))

@@ -980,14 +980,18 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     output_layer();
     GT_STAMP(2 + 10 * a.L);
   } else if (a.phase == 0) {
+    GT_STAMP(60);
     input_layer();
     in_proj(0);
     seq_tile_out(ws + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
+    GT_STAMP(61);
   } else {
     const int l = a.phase - 1;
+    GT_STAMP(60 + 2 * a.phase);
     load_rows(sX, SX, (l == 0 ? ws + a.x0 : ws + (int64_t)(l - 1) * a.wstride + a.w0.xout) + r0 * d, d, rb, NROW);   // own rows of the layer input
     load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                          // q / k / v of the whole sequence
     GT_BARRIER();
+    GT_STAMP(2 + 10 * l + 1);
     layer_rest(l, false);
     if (l + 1 < a.L) {
       in_proj(l + 1);
@@ -995,6 +999,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     } else {
       output_layer();
     }
+    GT_STAMP(61 + 2 * a.phase);
   }
 }
 
@@ -1207,11 +1212,14 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     input_bwd();
     GT_STAMP(102 + 10 * a.L);
   } else if (a.phase == 0) {
+    GT_STAMP(160);
     prologue();
     chain(a.L - 1, true);
     seq_tile_out(ws + a.dctx + r0 * d, sZ, SX, d, tid, rb, NROW);
+    GT_STAMP(161);
   } else {
     const int l = a.L - a.phase;
+    GT_STAMP(160 + 2 * a.phase);
     const int64_t hand = (int64_t)a.B * 32 * d;                                                             // floats per hand-over buffer
     load_rows(sZ, SX, ws + a.dctx + ((a.phase - 1) & 1) * hand + r0 * d, d, 0, 32);                         // dctx of the whole sequence
     load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                   // its saved q / k / v
@@ -1224,5 +1232,6 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     } else {
       input_bwd();
     }
+    GT_STAMP(161 + 2 * a.phase);
   }
 }
