@@ -190,6 +190,11 @@ int gt_set_seq(int on);
  * kernels: -1 = default (when 2 x batch workgroups fit the CUs once), 0 = off, 1 = on (env GT_SEQ_SPLIT=0/1 does the same).  Same
  * results bit for bit: the split is over token rows. */
 int gt_set_seq_split(int on);
+/* Bitwise-reproducible weight gradients: each output tile of a weight gradient is owned by ONE workgroup that walks all tokens
+ * (no split over the token dimension), so the fp32 atomic adds have a single contributor per element.  Everything else of the
+ * step is reproducible already (fixed-order reductions).  Off by default: the small shapes lose their token parallelism
+ * (env GT_DETERMINISTIC=1 does the same). */
+int gt_set_deterministic(int on);
 int gt_profile_report(char* buf, size_t buf_len, int max_rows);
 
 #ifdef __cplusplus

@@ -227,3 +227,31 @@ def test_random_odd_shapes():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     assert fuzz_parity.run(20, seed=11, verbose=False) == 0
+
+
+@pytest.mark.parametrize("cfg,B,p,seq", [(C2, 64, 0.24, True), (C2, 64, 0.24, False), (cfg_dict(256, 2, 512, 2), 32, 0.3, True),
+                                         (ENCDEC, 16, 0.2, True)])
+def test_deterministic_weight_gradients_repeat_bit_for_bit(cfg, B, p, seq):
+    """gt_set_deterministic(1): one workgroup per weight-gradient tile over all tokens -> the whole train step is bitwise
+    repeatable (default mode: the token-split partial sums meet in fp32 atomics, last bits vary run to run); and it still is the
+    same gradient (oracle parity in that mode)."""
+    from transformergrooveinfilling_amd import _lib
+    lib = _lib.get_lib()
+    lib.cdll.gt_set_deterministic(1)
+    try:
+        cfgp = dict(cfg, dropout=p)
+        dec = cfgp.get("num_decoder_layers", 0) > 0
+        P = ng.init_params(cfgp, seed=2)
+        x, y = ng.synthetic_batch(B, cfgp["embedding_size_src"], seed=77)
+        runs = []
+        for _ in range(2):
+            r = Runner(cfgp, B, "hip", rng=(9, 4, 0), lr=0.05, seq=seq)
+            r.set_params(P)
+            for _ in range(4):
+                r.train_step(x, y, 0.4)
+            runs.append(r.params.numpy().copy())
+        assert np.array_equal(runs[0], runs[1])
+        if not dec:
+            parity.check_step("hip", cfg, min(B, 8), p, seq=seq)
+    finally:
+        lib.cdll.gt_set_deterministic(0)

@@ -416,6 +416,7 @@ static hipEvent_t next_event() { return g_events[g_event_next++ % g_events.size(
 static hipStream_t side_stream() { return nullptr; }
 #endif
 extern "C" int gt_set_overlap(int on) { g_overlap = on != 0; return 0; }
+extern "C" int gt_set_deterministic(int on) { g_deterministic = on != 0; return 0; }
 
 // launch everything queued so far for the layer whose temporaries live in set `set` (call after the last producer of a
 // queued wgrad's inputs has been enqueued)

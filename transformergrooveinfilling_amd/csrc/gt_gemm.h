@@ -742,7 +742,16 @@ static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s)
 
 // wgrad: the output (N_w x K_w) is small, the contraction (tokens) is long -> split it over z so that the
 // problem yields about `target` 32x32-tile workgroups.  Sets g.k_chunk, returns the split count.
+// Deterministic mode (gt_set_deterministic / GT_DETERMINISTIC=1): ONE workgroup per output tile walks all tokens, so every
+// gradient element (and bias-gradient element) has exactly one contributor and the fp32 atomics add onto a known value in a fixed
+// order -- gradients, and with them the whole training run, repeat bit for bit.  Costs the small shapes their token parallelism.
+static int g_deterministic = -1;
+static inline bool gt_deterministic() {
+  if (g_deterministic < 0) { const char* e = getenv("GT_DETERMINISTIC"); g_deterministic = (e && e[0] == '1') ? 1 : 0; }
+  return g_deterministic != 0;
+}
 static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
+  if (gt_deterministic()) target = 1;
   const long tiles = (long)((g.M + tile - 1) / tile) * ((g.N + tile - 1) / tile);
   long want = (target + tiles - 1) / tiles;
   const long maxs = tile >= 128 ? (g.K + 511) / 512 : tile >= 64 ? (g.K + 255) / 256 : (g.K + 127) / 128;
