@@ -161,6 +161,8 @@ def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
 
 def test_sequence_resident_train_step_and_predict():
     parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.2)
+    parity.check_train_step("emu", cfg_dict(128, 4, 32, 2), 2, 0.2, seq="split")      # loss fused into the last forward phase, 4 workgroups
+    parity.check_train_step("emu", cfg_dict(128, 8, 48, 1), 3, 0.1, seq="whole")
     parity.check_bucketed_backward("emu", cfg_dict(32, 4, 16, 2), 2, 0.25, 1, exact=True)      # one bucket: the backward is one launch
     parity.check_predict("emu", cfg_dict(32, 4, 16, 2), 2, True)
 

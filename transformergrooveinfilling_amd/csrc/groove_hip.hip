@@ -233,7 +233,7 @@ static WLayout ws_layout(const gt_config& c) {
     W.y0 = W.b0 = W.dec_xhat = W.dec_rstd = W.dec_final = W.dmem = W.hvo_tmp = -1;
   }
   W.dlogits = add(M * GT_TGT);
-  W.loss_part = add(((M * GT_VOICES + 255) / 256) * 4);
+  W.loss_part = add(std::max<int64_t>(((M * GT_VOICES + 255) / 256) * 4, 8 * (int64_t)c.batch));   // loss_kernel's / the fused loss's workgroups x 4
   // dgamma/dbeta partials: one [row_tiles][2][d] block per LayerNorm instance (2 per encoder layer, 3 per decoder
   // layer, the final norms)
   W.ln_part_stride = ((M + 7) / 8) * 2 * d;
@@ -748,6 +748,9 @@ static bool use_seq(const gt_config& c) {
   if ((dm) <= 32) GT_SEQ_LAUNCH_DP(K, 32, dm, hc, grid, block, s, a)           \
   else if ((dm) <= 64) GT_SEQ_LAUNCH_DP(K, 64, dm, hc, grid, block, s, a)      \
   else GT_SEQ_LAUNCH_DP(K, 128, dm, hc, grid, block, s, a)
+// gt_train_step hands its loss over to the sequence-resident forward (one launch less): set around its gt_forward call
+struct SeqLoss { const float* y; float penalty; float* stats; unsigned* ticket; };
+static thread_local SeqLoss g_seq_loss = {nullptr, 0.f, nullptr, nullptr};
 static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hvo) {
   SeqArgs a;
   memset(&a, 0, sizeof(a));
@@ -770,11 +773,16 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.stamps = x.W.stamps;
   a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
   a.dctx = x.W.seq_dctx; a.phase = 0;
+  a.loss_y = nullptr; a.loss_penalty = 0.f; a.loss_stats = nullptr; a.loss_part = nullptr; a.loss_ticket = nullptr;
   return a;
 }
 // the whole forward (input layer ... output heads) of every sequence: ONE launch
 static int seq_forward(const Ctx& x, const float* pe, const float* src, float* hvo_out) {
-  const SeqArgs a = mk_seq(x, pe, src, hvo_out);
+  SeqArgs a = mk_seq(x, pe, src, hvo_out);
+  if (g_seq_loss.y != nullptr) {
+    a.loss_y = g_seq_loss.y; a.loss_penalty = g_seq_loss.penalty; a.loss_stats = g_seq_loss.stats; a.loss_ticket = g_seq_loss.ticket;
+    a.loss_part = x.ws + x.W.loss_part;
+  }
   const double fl = 2.0 * x.M * ((double)x.c.src_dim * x.d + x.c.n_enc_layers * (4.0 * x.d * x.d + 64.0 * x.d + 2.0 * x.d * x.F) + 27.0 * x.d);
   {   // fragment-ordered copies of this step's weights, for the forward and the backward kernel
     const int64_t frags = 2 * (int64_t)x.c.n_enc_layers * x.W.pack_stride / 256;
@@ -1298,15 +1306,22 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   if (skip_update == 3)                             // second half of a bucketed backward (tgt_scratch still holds the shifted y)
     return backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, 2);
   if (tgt_in) gt_launch(shift_right_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), s, y, tgt_scratch, M * GT_TGT);
-  if (gt_forward(cfg, params, pe, xin, tgt_in, hvo_out, ws, state, 1, stream)) return -1;
+  // sequence-resident path: the launch that runs the output layer computes the loss as well (one launch less)
+  const bool fuse_loss = use_seq(*cfg) && stats != nullptr && hvo_out != nullptr;
+  if (fuse_loss) g_seq_loss = SeqLoss{y, hit_loss_penalty, stats, reinterpret_cast<unsigned*>(&state->pad2[0])};
+  const int frc = gt_forward(cfg, params, pe, xin, tgt_in, hvo_out, ws, state, 1, stream);
+  g_seq_loss.y = nullptr;
+  if (frc) return -1;
   // loss + head-activation backward in one kernel: d loss / d logits straight into ws.dlogits; workgroup partials are
   // combined by the last-arriving workgroup (ticket in the step state), so there is no memset node and the stats are
   // bitwise reproducible.  grads: zero on entry (precondition), re-zeroed by the optimizer kernel.
   WLayout W = ws_layout(*cfg);
   if (!stats || !hvo_out) return gt_fail("gt_train_step: hvo_out / stats must not be NULL");
-  gt_prof_tag("loss", 0, 12.0 * M * GT_TGT);
-  gt_launch(loss_kernel<true, true>, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, (const float*)hvo_out, y, hit_loss_penalty, stats,
-            ws + W.dlogits, M, ws + W.loss_part, reinterpret_cast<unsigned*>(&state->pad2[0]));
+  if (!fuse_loss) {
+    gt_prof_tag("loss", 0, 12.0 * M * GT_TGT);
+    gt_launch(loss_kernel<true, true>, dim3((M * GT_VOICES + 255) / 256), dim3(256), s, (const float*)hvo_out, y, hit_loss_penalty, stats,
+              ws + W.dlogits, M, ws + W.loss_part, reinterpret_cast<unsigned*>(&state->pad2[0]));
+  }
   // whole step: the last launch of backward (the LayerNorm partials reduce -- every model has LayerNorms) also advances the
   // step counters, and the optimizer is told so: one launch less than update + step_inc
   if (backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, skip_update == 2 ? 1 : 0,

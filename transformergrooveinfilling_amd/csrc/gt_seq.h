@@ -54,6 +54,9 @@ struct SeqArgs {
                                                              // buffer p & 1 and reads the other: a fast workgroup must not overwrite rows its
                                                              // partner has yet to read)
   int phase;                                                 // SPLIT kernels: which phase this launch runs
+  // fused loss (gt_train_step): the launch that runs the output layer also computes the loss terms, d loss / d logits and the
+  // step's statistics (loss_y == nullptr: off).  Same arithmetic as loss_kernel<true, true> (gt_loss_elem), one partial per workgroup
+  const float* loss_y; float loss_penalty; float* loss_stats; float* loss_part; unsigned* loss_ticket;
 };
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md 7): workgroup 0, thread 0 records the shader clock at stage
 // boundaries into a buffer nothing else reads.  tools/seq_stamps.py prints the per-stage cycle counts.
@@ -963,10 +966,58 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
             if (col >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
             else if (col >= GT_VOICES) v = gt_sigmoid(v);
             a.hvo[(r0 + rb + 16 * h2 + l16) * GT_TGT + col] = v;
+            sR[(rb + 16 * h2 + l16) * 28 + col] = v;          // (sR is free here: the loss tail reads the [32][28] output tile from it)
           }
         }
       }
     });
+    if (a.loss_y == nullptr) return;
+    // ---- fused loss: one thread per (own row, voice); partial sums of this workgroup -> loss_part[blockIdx][4]; the last workgroup
+    // to arrive (ticket) adds all partials in a fixed order -> bitwise-reproducible statistics, as in loss_kernel
+    GT_BARRIER();
+    float* red = sX1;                                         // [8 waves][4] + flag (the x1 tile is dead)
+    const float invM = 1.0f / (float)(a.B * 32);
+    float bce = 0.f, mv = 0.f, mo = 0.f, ok = 0.f;
+    if (tid < NROW * GT_VOICES) {
+      const int row = rb + tid / GT_VOICES, j = tid % GT_VOICES;
+      const size_t base = (r0 + row) * GT_TGT + j;
+      float gh, gv, go;
+      gt_loss_elem<true>(sR[row * 28 + j], sR[row * 28 + j + GT_VOICES], sR[row * 28 + j + 2 * GT_VOICES], a.loss_y[base],
+                         a.loss_y[base + GT_VOICES], a.loss_y[base + 2 * GT_VOICES], a.loss_penalty, invM, bce, mv, mo, ok, gh, gv, go);
+      ws[a.dlogits + base] = gh; ws[a.dlogits + base + GT_VOICES] = gv; ws[a.dlogits + base + 2 * GT_VOICES] = go;
+    }
+    bce = gt_wave_sum(bce); mv = gt_wave_sum(mv); mo = gt_wave_sum(mo); ok = gt_wave_sum(ok);
+    if (lane == 0) { red[wave * 4 + 0] = bce; red[wave * 4 + 1] = mv; red[wave * 4 + 2] = mo; red[wave * 4 + 3] = ok; }
+    GT_BARRIER();
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = red[q];
+        for (int w = 1; w < GT_SEQ_WAVES; ++w) t += red[w * 4 + q];
+        a.loss_part[blockIdx.x * 4 + q] = t;
+      }
+      __threadfence();                                        // release: partials before the ticket
+      const unsigned t = atomicAdd(a.loss_ticket, 1u);
+      red[32] = (t == gridDim.x - 1) ? 1.0f : 0.0f;
+      if (t == gridDim.x - 1) __threadfence();                // acquire: the other workgroups' partials
+    }
+    GT_BARRIER();
+    if (red[32] == 0.0f) return;
+    if (wave < 4) {                                           // wave q sums quantity q: lane l takes workgroups l, l + 64, ..., then the xor tree
+      float acc = 0.f;
+      for (unsigned bk = lane; bk < gridDim.x; bk += 64) acc += a.loss_part[bk * 4 + wave];
+      acc = gt_wave_sum(acc);
+      if (lane == 0) red[40 + wave] = acc * invM;
+    }
+    GT_BARRIER();
+    if (tid == 0) {
+      const float b_ = red[40], v_ = red[41], o_ = red[42];
+      a.loss_stats[0] = b_ + v_ + o_;
+      a.loss_stats[1] = red[43] * (1.0f / GT_VOICES);
+      a.loss_stats[2] = 0.f;
+      a.loss_stats[3] = b_; a.loss_stats[4] = v_; a.loss_stats[5] = o_; a.loss_stats[6] = 0.f; a.loss_stats[7] = 0.f;
+      *a.loss_ticket = 0u;                                    // re-arm for the next step
+    }
   };
 
 #ifdef GT_SEQ_STAMPS
