@@ -797,7 +797,7 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
     for (int p = 0; p <= x.c.n_enc_layers; ++p) {
       SeqArgs ap = a;
       ap.phase = p;
-      if (p > 0) gt_prof_tag("seq_fwd", p == 1 ? fl : 0.0, 0.0);
+      if (p > 0) gt_prof_tag("seq_fwd", 0.0, 0.0);          // (flops and bytes of the whole forward are on the first phase's tag)
       GT_SEQ_LAUNCH_SPLIT(seq_fwd_kernel, hc, grid, block, x.s, ap)
     }
     return 0;
@@ -1057,7 +1057,9 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     if (!ok) return gt_fail("too many LayerNorm instances for the partials table");
     {
       const SeqArgs a = mk_seq(x, nullptr, xin, nullptr);
-      const double fl = 4.0 * M * ((double)cfg->src_dim * d * 0 + L * (4.0 * d * d + 64.0 * d + 2.0 * d * x.F) + 27.0 * d);
+      // dgrad products only (the weight gradients are the grouped dispatch): the four Linear dgrads = the forward's GEMM flops,
+      // attention backward (dP, dV, dQ, dK) = twice the forward's QK^T + PV; the SPLIT mode's second copy of it is not counted
+      const double fl = 2.0 * M * (L * (4.0 * d * d + 128.0 * d + 2.0 * d * x.F) + 27.0 * d);
       gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
       const dim3 block(GT_SEQ_NT);
       const int hc = x.hd < 16 ? 0 : x.hd;
