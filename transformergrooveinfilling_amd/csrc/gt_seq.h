@@ -17,7 +17,7 @@
 //   saved for backward / tests    written to the same workspace buffers the one-kernel-per-op path uses (gt_ws_find names)
 //   attention                     transposed-score MFMA bodies (the scheme of gt_attn.h) on LDS operands, four heads at a time
 //
-// What bounds these kernels (in-kernel stamps, profiles/r02_seq_stamps.txt): a workgroup is a chain of ~8 dependent stages per
+// What bounds these kernels (in-kernel stamps, profiles/r02_final_seq_stamps_*.txt): a workgroup is a chain of ~8 dependent stages per
 // layer and each stage is ONE wave's instruction stream per SIMD -- a wave64 VALU instruction occupies its SIMD for 4 cycles
 // (8 with the SIMD's second wave), a quarter-rate v_mul_lo_u32 for 16, a dependent ds_bpermute / LDS access ~100.  So the rules
 // here are instruction-count rules: 32-bit element offsets from wave-uniform bases (no 64-bit address arithmetic per load),
@@ -26,7 +26,9 @@
 //
 // Three instantiations by d_model class DP = 32 / 64 / 128 (d_model % 16 == 0, <= DP).  At DP 128 (the headline workload:
 // d_model 128, dim_feedforward 512) a sequence's layer is ~13 MFLOP: the matmul stages are bound by the fp32 MFMA rate of the
-// ONE CU the workgroup runs on (256 FLOP/clk), the whole step is 7 launches instead of 49.
+// ONE CU the workgroup runs on (256 FLOP/clk), the whole step is 7 launches instead of 49.  While twice the batch fits the CUs the
+// SPLIT instantiations take over there: two workgroups per sequence, 16 token rows each, one launch per phase (see seq_fwd_kernel) --
+// 12 launches, twice the CUs.  In gt_train_step the launch that runs the output layer also computes the loss (fused tail).
 //
 // Supported: encoder-only, fp32 operands, d_model % 16 == 0 and <= 128, dim_feedforward % 16 == 0 and <= 512, src_dim <= 32,
 // head_dim 16 / 32 / 64 or < 16 (seq_supported in groove_hip.hip).
