@@ -186,9 +186,9 @@ int gt_set_chain(int on);
  * win -- d_model <= 64 always, d_model <= 128 from batch 64 up.  on = 1 forces them wherever supported, on = 0 switches them off
  * (env GT_SEQ=1 / GT_SEQ=0 do the same; gt_set_chain(1) takes precedence).  Same results as the other paths to fp32 rounding. */
 int gt_set_seq(int on);
-/* Two workgroups per sequence (16 token rows each) and one launch per layer and direction for the d_model-128 sequence-resident
- * kernels: -1 = default (when 2 x batch workgroups fit the CUs once), 0 = off, 1 = on (env GT_SEQ_SPLIT=0/1 does the same).  Same
- * results bit for bit: the split is over token rows. */
+/* Two workgroups per sequence (16 token rows each) and one launch per layer and direction for the sequence-resident kernels at
+ * d_model 128 or 32: -1 = default (when 2 x batch workgroups fit the CUs once; d_model 32 only with dim_feedforward >= 256), 0 = off,
+ * 1 = on (env GT_SEQ_SPLIT=0/1 does the same).  Same results bit for bit: the split is over token rows. */
 int gt_set_seq_split(int on);
 /* Bitwise-reproducible weight gradients: each output tile of a weight gradient is owned by ONE workgroup that walks all tokens
  * (no split over the token dimension), so the fp32 atomic adds have a single contributor per element.  Everything else of the

@@ -152,9 +152,10 @@ def test_sequence_resident_kernels(cfg, B, p):
     parity.check_step("emu", cfg, B, p)
 
 
-@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(128, 4, 512, 2), 1, 0.24), (cfg_dict(128, 16, 48, 3), 2, 0.1), (cfg_dict(128, 2, 32, 1), 1, 0.0)])
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(128, 4, 512, 2), 1, 0.24), (cfg_dict(128, 16, 48, 3), 2, 0.1), (cfg_dict(128, 2, 32, 1), 1, 0.0),
+                                     (cfg_dict(32, 16, 512, 2), 2, 0.24), (cfg_dict(32, 2, 32, 1), 1, 0.1), (cfg_dict(32, 1, 16, 2), 3, 0.0)])
 def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
-    """d_model 128, SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels"""
+    """d_model 128 / 32, SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels"""
     parity.check_step("emu", cfg, B, p, seq="split")
     parity.check_step("emu", cfg, B, p, seq="whole")
 

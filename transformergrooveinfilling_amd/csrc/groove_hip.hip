@@ -253,7 +253,7 @@ static WLayout ws_layout(const gt_config& c) {
   if (seq_supported(c)) {
     W.pack_stride = (int64_t)4 * d * d + (int64_t)2 * d * F;
     W.pack_f = add(W.pack_stride * c.n_enc_layers); W.pack_b = add(W.pack_stride * c.n_enc_layers);
-    if (d > 64) W.seq_dctx = add(2 * M * d);
+    W.seq_dctx = add(2 * M * d);
   }
 #ifdef GT_SEQ_STAMPS
   W.stamps = add(2048);
@@ -697,8 +697,9 @@ static int encoder_fwd_chain(const Ctx& x, const float* pe, const float* src) {
 // 128 class a sequence's matmuls are bound by the fp32 MFMA rate of the ONE CU its workgroup runs on: from 64 sequences per GPU up.
 static int g_seq = -1;
 extern "C" int gt_set_seq(int on) { g_seq = on != 0; return 0; }
-// SPLIT mode of the d_model-128 class: 2 x batch workgroups of 16 token rows, one launch per layer and direction (+1).  Default
-// (-1): when the pairs fit the chip once (2 x batch <= CUs) -- there a sequence per CU leaves most of the MFMA rate idle.
+// SPLIT mode (d_model 128, and d_model 32 with dim_feedforward >= 256): 2 x batch workgroups of 16 token rows, one launch per layer
+// and direction (+1).  Default (-1): when the pairs fit the chip once (2 x batch <= CUs) -- there a sequence per CU leaves most of
+// the MFMA rate idle.
 static int g_seq_split = -1;
 extern "C" int gt_set_seq_split(int on) { g_seq_split = on < 0 ? -1 : on != 0; return 0; }
 static int seq_cu_count() {
@@ -715,9 +716,12 @@ static int seq_cu_count() {
   return n;
 }
 static bool seq_split(const gt_config& c) {
-  if (c.d_model != 128) return false;
+  if (c.d_model != 128 && c.d_model != 32) return false;
   if (g_seq_split < 0) { const char* e = getenv("GT_SEQ_SPLIT"); if (e) g_seq_split = e[0] != '0'; }
   if (g_seq_split >= 0) return g_seq_split != 0;
+  // d_model 32: only where a sequence's FFN is MFMA-issue-bound on its one CU (ClosedHH YAML, F 512, bs 16: 0.313 -> 0.290 ms); the
+  // testing YAML (F 16) is a latency chain that more launches only lengthen (0.141 -> 0.160)
+  if (c.d_model == 32 && c.dim_ff < 256) return false;
   return 2 * c.batch <= seq_cu_count();
 }
 static bool seq_supported(const gt_config& c) {
@@ -736,11 +740,15 @@ static bool use_seq(const gt_config& c) {
   else if ((hc) == 16) gt_launch(K<DP, 16, EX, false>, grid, block, s, a);               \
   else if ((hc) == 32 || (DP) == 32) gt_launch(K<DP, 32, EX, false>, grid, block, s, a); \
   else gt_launch(K<(DP) == 32 ? 64 : DP, 64, EX, false>, grid, block, s, a);
-// the SPLIT kernels (two workgroups per sequence, one launch per phase): d_model 128 exactly
-#define GT_SEQ_LAUNCH_SPLIT(K, hc, grid, block, s, a)                    \
-  if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);        \
-  else if ((hc) == 16) gt_launch(K<128, 16, true, true>, grid, block, s, a); \
-  else if ((hc) == 32) gt_launch(K<128, 32, true, true>, grid, block, s, a); \
+// the SPLIT kernels (two workgroups per sequence, one launch per phase): d_model 128 or 32 exactly
+#define GT_SEQ_LAUNCH_SPLIT(K, dm, hc, grid, block, s, a)                         \
+  if ((dm) == 32) {                                                                \
+    if ((hc) == 0) gt_launch(K<32, 0, true, true>, grid, block, s, a);             \
+    else if ((hc) == 16) gt_launch(K<32, 16, true, true>, grid, block, s, a);      \
+    else gt_launch(K<32, 32, true, true>, grid, block, s, a);                      \
+  } else if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);       \
+  else if ((hc) == 16) gt_launch(K<128, 16, true, true>, grid, block, s, a);       \
+  else if ((hc) == 32) gt_launch(K<128, 32, true, true>, grid, block, s, a);       \
   else gt_launch(K<128, 64, true, true>, grid, block, s, a);
 #define GT_SEQ_LAUNCH_DP(K, DP, dm, hc, grid, block, s, a)                                                  \
   { if ((dm) == (DP)) { GT_SEQ_LAUNCH_HD(K, DP, true, hc, grid, block, s, a) } else { GT_SEQ_LAUNCH_HD(K, DP, false, hc, grid, block, s, a) } }
@@ -798,7 +806,7 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
       SeqArgs ap = a;
       ap.phase = p;
       if (p > 0) gt_prof_tag("seq_fwd", 0.0, 0.0);          // (flops and bytes of the whole forward are on the first phase's tag)
-      GT_SEQ_LAUNCH_SPLIT(seq_fwd_kernel, hc, grid, block, x.s, ap)
+      GT_SEQ_LAUNCH_SPLIT(seq_fwd_kernel, x.d, hc, grid, block, x.s, ap)
     }
     return 0;
   }
@@ -1069,7 +1077,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
           SeqArgs ap = a;
           ap.phase = p;
           if (p > 0) gt_prof_tag("seq_bwd", 0.0, 0.0);
-          GT_SEQ_LAUNCH_SPLIT(seq_bwd_kernel, hc, grid, block, x.s, ap)
+          GT_SEQ_LAUNCH_SPLIT(seq_bwd_kernel, d, hc, grid, block, x.s, ap)
         }
       } else {
         const dim3 grid(cfg->batch);

@@ -886,7 +886,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     // ---- out-proj (raw product -> sR part 0); the ctx tile also goes to global here (operand of the out-proj weight gradient)
     {
       seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid, rb, NROW);
-      if (DP <= 64) seq_mm_square(sC, SX, d, kf_out, sR, SRS, wave, lane);
+      if (DP <= 64 && !SPLIT) seq_mm_square(sC, SX, d, kf_out, sR, SRS, wave, lane);
       else
         seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kf_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
           *reinterpret_cast<float4*>(&sR[(rb + l16) * SRS + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     GT_STAMP(sb + 3);
     // ---- out-proj dgrad: dctx = dz1m Wo -> sZ (LDS: the attention backward reads it there)
     seq_ln_part<DP, HALF>(sP, part_at(jb + 1), d, tid);
-    if (DP <= 64) seq_mm_square(sC, SX, d, kb_out, sZ, SX, wave, lane);
+    if (DP <= 64 && !SPLIT) seq_mm_square(sC, SX, d, kb_out, sZ, SX, wave, lane);
     else
       seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kb_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
         *reinterpret_cast<float4*>(&sZ[(rb + l16) * SX + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
