@@ -206,7 +206,7 @@ def run_rank(args):
             dist.init_process_group(backend, device_id=torch.device(dev))
 
     eng = StepEngine(batch_size=batch, optimizer="sgd", learning_rate=LR, hit_loss_penalty=PENALTY,
-                     seed=1234 | (rank << 32), device=dev, world_size=world, use_graph=not args.no_graph, lib=lib, **work)
+                     seed=1234 | (rank << 32), device=dev, world_size=world, use_graph=False if args.no_graph else "auto", lib=lib, **work)
     eng.force_dp = bool(args.force_dp)
     eng.load_named(layout.init_params(work, seed=0))                   # identical replicas
     x, y = layout.synthetic_batch(batch, work["embedding_size_src"], seed=1234 + rank)
@@ -242,7 +242,7 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: InfillingClosedHH_training.yaml + overrides d_model=128/4 heads/3 layers, "
                                    "dim_feedforward=512, bs=64 per GPU, dropout=0.24, SGD lr=0.07, hit_loss_penalty=0.38, S=16, encoder-only",
-                       "global_batch": world * batch, "parallelism": "dp%d" % world, "hipgraph": eng.use_graph},
+                       "global_batch": world * batch, "parallelism": "dp%d" % world, "hipgraph": bool(eng.graph_for(eng.slot(batch)))},
             # what the collective layer itself saw: the judge's "RCCL saw N ranks" check
             "distributed": {"world": world, "backend": dist.get_backend() if dist.is_initialized() else None,
                             "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,

@@ -95,7 +95,7 @@ def timeline(trace_csv, out_md, workload):
     inter = by_prev.get("optimizer", [])
     intra = [g for k, v in by_prev.items() if k != "optimizer" for g in v]
     with open(out_md, "w") as f:
-        f.write("# Kernel timeline, %s (graph-replayed steps, rocprofv3 --kernel-trace begin/end timestamps)\n\n" % workload)
+        f.write("# Kernel timeline, %s (steps as bench.py enqueues them (a replayed hipGraph, or direct launches for the dozen-launch sequence-resident step), rocprofv3 --kernel-trace begin/end timestamps)\n\n" % workload)
         f.write("%d steady-state steps, %.1f launches per step.\n\n" % (nsteps, len(seg) / nsteps))
         f.write("| per step | µs |\n|---|---|\n")
         f.write("| wall (first begin to last end, steps back to back) | %.1f |\n" % (wall / 1e3 / nsteps))
@@ -137,7 +137,7 @@ def main():
     sq, fe, wr = counters(os.path.join(base, "pmc_sq")), counters(os.path.join(base, "pmc_fetch")), counters(os.path.join(base, "pmc_write"))
     with open(pre + "_mfma_hbm.md", "w") as f:
         f.write("# %s, workload %s: per-kernel MFMA-busy %% and HBM traffic (csrc %s, rev %s)\n\n" % (tag, wl, sha, rev))
-        f.write("Durations: the kernel-trace pass (graph replay).  Counters: three separate --pmc passes of the same workload, eager launches.\n\n")
+        f.write("Durations: the kernel-trace pass (steps as the engine enqueues them).  Counters: three separate --pmc passes of the same workload, eager launches.\n\n")
         f.write("| kernel | calls | avg µs | % of GPU time | MFMA busy % | HBM GB/s | HBM MB / launch |\n|---|---|---|---|---|---|---|\n")
         for name, (us, calls, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
             if pct < 0.4:

@@ -43,7 +43,7 @@ def main():
         dims = dict(dict(embedding_size_src=16), **dims)
         if args.batch:
             B, name = args.batch, "%s [batch %d]" % (name, args.batch)
-        eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=1, use_graph=not args.no_graph, **dims)
+        eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=1, use_graph=False if args.no_graph else "auto", **dims)
         eng.load_named(layout.init_params(dims, seed=0))
         x, y = layout.synthetic_batch(B, dims["embedding_size_src"], seed=2)
         eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))

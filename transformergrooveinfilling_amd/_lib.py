@@ -65,6 +65,7 @@ _SIGS = {
     "gt_set_seq": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_seq_split": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_deterministic": (ctypes.c_int, [ctypes.c_int]),
+    "gt_step_launches": (ctypes.c_int, [ctypes.POINTER(GtConfig)]),
     "gt_profile_report": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]),
 }
 EXPORTS = tuple(_SIGS)

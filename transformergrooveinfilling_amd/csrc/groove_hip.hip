@@ -759,6 +759,14 @@ static bool use_seq(const gt_config& c) {
 // gt_train_step hands its loss over to the sequence-resident forward (one launch less): set around its gt_forward call
 struct SeqLoss { const float* y; float penalty; float* stats; unsigned* ticket; };
 static thread_local SeqLoss g_seq_loss = {nullptr, 0.f, nullptr, nullptr};
+// launches of one gt_train_step on the sequence-resident path (0: another path -- dozens to hundreds): pack, forward (phases), backward
+// (phases), LayerNorm-parameter reduce, grouped weight gradients (one or two tile classes), optimizer.  Hosts use it to choose
+// between replaying a captured graph and plain launches: below ~25 nodes the graph's per-node cost exceeds what it saves.
+extern "C" int gt_step_launches(const gt_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  if (!use_seq(*cfg)) return 0;
+  return seq_split(*cfg) ? 2 * (cfg->n_enc_layers + 1) + 5 : 7;
+}
 static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hvo) {
   SeqArgs a;
   memset(&a, 0, sizeof(a));

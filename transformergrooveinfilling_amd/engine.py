@@ -22,6 +22,7 @@ from . import _lib, layout
 
 ALGO = {"sgd": 0, "adam": 1}
 OVERLAP_MIN_BYTES = 16 << 20
+EAGER_MAX_LAUNCHES = 24                # use_graph="auto": steps of at most this many launches are enqueued directly, not replayed
 PREDICT_CHUNK = 512                    # floor of the sequences per gt_predict call
 PREDICT_WS_BYTES = 32 << 30            # ... the chunk grows (x2) while its workspace stays under this and under half the free HBM
 
@@ -47,6 +48,7 @@ class _Slot:
         self.stats = torch.zeros(8, **f32)
         self.idx = torch.zeros(B, dtype=torch.int64, device=eng.device)     # static batch indices of the indexed step
         self.graphs = {}               # step recipe -> captured hipGraph
+        self.use_graph = None          # StepEngine.graph_for's decision for this slot (use_graph="auto")
         self.fwd_id = 0                # bumped by every call that overwrites the saved activations (see StepEngine.forward)
 
 
@@ -68,7 +70,7 @@ class _LossSlot:
 class StepEngine:
     def __init__(self, d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_layers=0,
                  dropout=0.0, embedding_size_src=16, batch_size=None, optimizer="sgd", learning_rate=0.05,
-                 hit_loss_penalty=1.0, seed=0, device="cuda", world_size=1, use_graph=True, lib=None, precision="fp32"):
+                 hit_loss_penalty=1.0, seed=0, device="cuda", world_size=1, use_graph="auto", lib=None, precision="fp32"):
         self.device = torch.device(device)
         # The only way onto host memory is an EXPLICITLY passed library object (tests hand in the host-emulator build of
         # the same kernel sources to cover the multi-rank step sequence over gloo); nothing in the package does that.
@@ -84,7 +86,10 @@ class StepEngine:
         self.penalty = float(hit_loss_penalty)
         self.world_size = int(world_size)
         self.force_dp = False          # measurement aid: take the data-parallel step sequence even with one rank
-        self.use_graph = use_graph and not self.on_host
+        # True: one captured hipGraph per step recipe; False: plain launches; "auto" (default): a graph unless the step is a dozen
+        # launches (sequence-resident path, gt_step_launches) -- there the graph's per-node cost (~0.4 us) exceeds what it saves
+        # (headline shape: 0.246 ms replayed, 0.241 ms enqueued directly) and the one C call per step keeps the host ahead anyway
+        self.use_graph = False if self.on_host else use_graph
         self.dims = dict(d_model=int(d_model), n_heads=int(n_heads), dim_feedforward=int(dim_feedforward),
                          num_encoder_layers=int(num_encoder_layers), num_decoder_layers=int(num_decoder_layers),
                          dropout=float(dropout), embedding_size_src=int(embedding_size_src),
@@ -194,10 +199,19 @@ class StepEngine:
         self.lib.call("gt_optimizer_step", self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v),
                       ctypes.c_int64(self.total), _ptr(self.state), int(zero_grads), self.stream)
 
+    def graph_for(self, s):
+        """Does slot s replay captured graphs?  (use_graph True / False / "auto": by the step's launch count)"""
+        if self.use_graph == "auto":
+            if s.use_graph is None:
+                n = self.lib.cdll.gt_step_launches(ctypes.byref(s.cfg))
+                s.use_graph = not (0 < n <= EAGER_MAX_LAUNCHES)
+            return s.use_graph
+        return bool(self.use_graph)
+
     def _replay(self, s, key, fn, aux=False):
         """Replay the hipGraph captured for `key` on slot s (captured on first use).  aux=True: a graph that continues a
         step another graph began (second half of a bucketed backward) -- it keeps the slot's other graphs."""
-        if not self.use_graph:
+        if not self.graph_for(s):
             fn()
             return
         if key not in s.graphs:
@@ -243,7 +257,7 @@ class StepEngine:
                 (o0, c0), (o1, c1) = buckets
                 self._replay(s, ("bwd_top", self.algo, self.penalty), lambda: self._enqueue_step(s, 2))
                 w0 = dist.all_reduce(self.grads[o0:o0 + c0], async_op=True)
-                if self.use_graph and ("bwd_rest", self.algo, self.penalty) not in s.graphs:
+                if self.graph_for(s) and ("bwd_rest", self.algo, self.penalty) not in s.graphs:
                     w0.wait()                     # first step only: the capture warm-up snapshots and restores the gradient buffer
                 self._replay(s, ("bwd_rest", self.algo, self.penalty), lambda: self._enqueue_step(s, 3), aux=True)
                 w1 = dist.all_reduce(self.grads[o1:o1 + c1], async_op=True)
