@@ -175,16 +175,12 @@ int gt_profile_enable(int on);
  * the backward chain; recorded as fork/join edges when the call is being captured into a hipGraph.  off (default;
  * env GT_OVERLAP=1 switches the default): a single stream -- measured faster on ROCm 7.2, see DESIGN.md. */
 int gt_set_overlap(int on);
-/* Fused row-chain kernels (one launch per layer and direction besides attention; wave-specialised loader / MFMA waves) for
- * encoder-only models with d_model <= 256 and dim_feedforward <= 512.  Default (neither this call nor env GT_CHAIN): used
- * automatically only where they win -- d_model <= 64 and dim_feedforward <= 64.  on = 1 forces them wherever supported,
- * on = 0 switches them off (env GT_CHAIN=1 / GT_CHAIN=0 do the same).  Results are the same on both paths. */
-int gt_set_chain(int on);
 /* Sequence-resident kernels (csrc/gt_seq.h): for encoder-only fp32 models with d_model <= 128 (% 16), dim_feedforward <= 512
  * (% 16), src_dim <= 32 and head_dim 16 / 32 / 64 or below 16, ONE workgroup per sequence runs the whole forward (and one the
- * whole backward) in a single launch; a train step is 7-8 launches.  Default (neither this call nor env GT_SEQ): used where they
- * win -- d_model <= 64 always, d_model <= 128 from batch 64 up.  on = 1 forces them wherever supported, on = 0 switches them off
- * (env GT_SEQ=1 / GT_SEQ=0 do the same; gt_set_chain(1) takes precedence).  Same results as the other paths to fp32 rounding. */
+ * whole backward) in a single launch -- or, in the SPLIT mode below, two workgroups per sequence and one launch per layer and
+ * direction; gt_step_launches() gives the launch count of a train step.  Default (neither this call nor env GT_SEQ): d_model <= 64
+ * and d_model == 128 always, the other widths of the 128 class from batch 64 up.  on = 1 forces them wherever supported, on = 0
+ * switches them off (env GT_SEQ=1 / GT_SEQ=0 do the same).  Same results as the one-kernel-per-op path to fp32 rounding. */
 int gt_set_seq(int on);
 /* Two workgroups per sequence (16 token rows each) and one launch per layer and direction for the sequence-resident kernels at
  * d_model 128 or 32: -1 = default (when 2 x batch workgroups fit the CUs once; d_model 32 only with dim_feedforward >= 256), 0 = off,

@@ -14,7 +14,8 @@ from transformergrooveinfilling_amd import _lib, layout  # noqa: E402
 
 EMU_SO = os.environ.get("GT_EMU_LIB_PATH") or os.path.join(ROOT, "tests", "emu", "libgroove_emu.so")   # override: tile-rule variants
 _SRC = [os.path.join(ROOT, "transformergrooveinfilling_amd", "csrc", f)
-        for f in ("groove_hip.hip", "gt_common.h", "gt_gemm.h", "gt_gemm32.h", "gt_seq.h", "gt_attn.h", "gt_misc.h", "gt_chain.h")] + \
+        for f in ("groove_hip.hip", "groove_seq_fwd.hip", "groove_seq_bwd.hip", "gt_common.h", "gt_gemm.h", "gt_gemm32.h", "gt_seq.h",
+                  "gt_seq_api.h", "gt_attn.h", "gt_misc.h")] + \
        [os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "include", "groove_hip.h")]
 
 
@@ -58,11 +59,10 @@ def cfg_dict(d_model, n_heads, dim_feedforward, num_encoder_layers, num_decoder_
 class Runner:
     """One model instance behind the C ABI.  backend = 'emu' | 'hip'."""
 
-    def __init__(self, cfg, B, backend="emu", rng=(1234, 99, 0), lr=0.094, chain=False, seq=True):
+    def __init__(self, cfg, B, backend="emu", rng=(1234, 99, 0), lr=0.094, seq=True):
         self.cfgd, self.B, self.backend = cfg, B, backend
         self.lib = emu_lib() if backend == "emu" else _lib.get_lib()
-        self.lib.cdll.gt_set_chain(int(chain))          # process-global switch: fused row-chain kernels on / off
-        self.lib.cdll.gt_set_seq(int(bool(seq) and not chain))  # process-global switch: sequence-resident kernels (default where supported)
+        self.lib.cdll.gt_set_seq(int(bool(seq)))  # process-global switch: sequence-resident kernels (default where supported)
         # seq = "split" / "whole": force / forbid their two-workgroups-per-sequence mode (d_model 128); True: the library's choice
         self.lib.cdll.gt_set_seq_split(1 if seq == "split" else 0 if seq == "whole" else -1)
         self.Buf = NpBuf if backend == "emu" else CudaBuf

@@ -49,7 +49,7 @@ def adopt_device_kinks(r, C, cfg):
     return adopted
 
 
-def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chain=False, seq=True):
+def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, seq=True):
     """forward + loss + backward (+ saved activations) against the fp64 numpy oracle."""
     cfg = dict(cfg, dropout=p)
     P = ng.init_params(cfg, seed=seed, perturb=0.05)
@@ -57,7 +57,7 @@ def check_step(backend, cfg, B, p=0.0, penalty=0.47, seed=3, check_ws=True, chai
     Ld = cfg.get("num_decoder_layers", 0)
     tgt = shift_right(y) if Ld else None
     rng = (1234, 99, 7)
-    r = Runner(cfg, B, backend, rng=rng, chain=chain, seq=seq)
+    r = Runner(cfg, B, backend, rng=rng, seq=seq)
     r.set_params(P)
     hvo = r.forward(x, tgt, train=p > 0)
     (h, v, o), C = ng.forward(P, cfg, x, tgt=tgt, rng=rng if p > 0 else None, dtype=np.float64)
@@ -366,14 +366,14 @@ def check_optimizers(backend, cfg, B):
             assert np.abs(got[k] - cur[k]).max() < 2e-6, (t, k)
 
 
-def check_train_step(backend, cfg, B, p, algo=0, chain=False, seq=True):
+def check_train_step(backend, cfg, B, p, algo=0, seq=True):
     """gt_train_step == forward+loss+backward+update with the oracle's masks; second step uses step+1."""
     cfg = dict(cfg, dropout=p)
     P = ng.init_params(cfg, seed=9, perturb=0.05)
     x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=4)
     Ld = cfg.get("num_decoder_layers", 0)
     tgt = shift_right(y) if Ld else None
-    r = Runner(cfg, B, backend, rng=(77, 5, 0), lr=0.05, chain=chain, seq=seq)
+    r = Runner(cfg, B, backend, rng=(77, 5, 0), lr=0.05, seq=seq)
     r.set_params(P)
     cur = {k: v.astype(np.float64) for k, v in P.items()}
     for step in range(2):

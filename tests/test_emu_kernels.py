@@ -26,17 +26,6 @@ def test_step_parity_d512():
     parity.check_step("emu", cfg_dict(512, 8, 16, 1), 1, 0.0)             # row-tile 512, head_dim 64
 
 
-@pytest.mark.parametrize("cfg,B,p", [(ENC, 3, 0.25), (SYM, 1, 0.0), (cfg_dict(16, 1, 24, 1), 1, 0.0), (cfg_dict(64, 2, 40, 2), 1, 0.1),
-                                     (cfg_dict(128, 4, 48, 2), 1, 0.2), (cfg_dict(256, 2, 16, 1), 1, 0.0)])
-def test_step_parity_row_chain_kernels(cfg, B, p):
-    """the opt-in fused row-chain path (gt_chain.h: loader waves + MFMA waves), every DPAD instantiation"""
-    parity.check_step("emu", cfg, B, p, chain=True)
-
-
-def test_train_step_row_chain_kernels():
-    parity.check_train_step("emu", ENC, 2, 0.2, chain=True)
-
-
 def test_optimizers():
     parity.check_optimizers("emu", ENC, 2)
 

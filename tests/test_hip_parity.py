@@ -29,13 +29,6 @@ def test_step_parity(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 
 
-@pytest.mark.parametrize("cfg,B,p", [(ENC, 5, 0.25), (C1, 32, 0.18), (YAML_HH, 16, 0.24), (SYM, 3, 0.1), (C2, 64, 0.24), (YAML_KS, 4, 0.3),
-                                     (cfg_dict(16, 16, 16, 1), 1, 0.0)])
-def test_step_parity_row_chain_kernels(cfg, B, p):
-    """the opt-in fused row-chain kernels (GT_CHAIN=1): same parity bar as the default one-kernel-per-op path"""
-    parity.check_step("hip", cfg, B, p, chain=True)
-
-
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(32, 4, 16, 1), 256, 0.1), (cfg_dict(64, 4, 64, 1), 256, 0.2), (cfg_dict(128, 4, 512, 1), 256, 0.24),
                                      (cfg_dict(256, 2, 512, 1), 256, 0.3), (cfg_dict(512, 8, 512, 1), 256, 0.15),
                                      (cfg_dict(256, 2, 512, 1, 1), 256, 0.1), (cfg_dict(512, 8, 512, 1), 512, 0.1),
@@ -53,10 +46,6 @@ def test_bucketed_backward(cfg, B, p, nb, seq):
     """data-parallel overlap: the first half of a bucketed backward leaves bucket 0 final, both halves equal the whole
     (sequence-resident path: the backward is one launch, hence one bucket)"""
     parity.check_bucketed_backward("hip", cfg, B, p, nb, exact=False, seq=seq)
-
-
-def test_train_step_row_chain_kernels():
-    parity.check_train_step("hip", C2, 16, 0.24, chain=True)
 
 
 @pytest.mark.parametrize("path", parity.golden_files())

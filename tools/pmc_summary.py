@@ -16,8 +16,8 @@ EPI = {0: None, 1: "gemm_wgrad", 2: "gemm_fwd_input", 3: "gemm_fwd_ffn1", 4: "ge
 PLAIN = {"wgrad_group_kernel": "gemm_wgrad", "attn_fwd_mfma_kernel": "attn_fwd", "attn_bwd_mfma_kernel": "attn_bwd",
          "attn_fwd_kernel": "attn_fwd", "attn_bwd_kernel": "attn_bwd", "attn_decode_kernel": "attn_decode",
          "ln_bwd_kernel": "ln_bwd", "ln_fwd_kernel": "ln_fwd", "loss_kernel": "loss", "sgd_kernel": "optimizer",
-         "adam_kernel": "optimizer", "ln_param_reduce_kernel": "ln_param_reduce", "chain_fwd_kernel": "chain_fwd",
-         "chain_bwd_kernel": "chain_bwd"}
+         "adam_kernel": "optimizer", "ln_param_reduce_kernel": "ln_param_reduce",
+         }
 
 
 def klass(name):

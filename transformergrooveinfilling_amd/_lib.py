@@ -61,7 +61,6 @@ _SIGS = {
     "gt_grad_buckets": (ctypes.c_int, [_cfgp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "gt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_overlap": (ctypes.c_int, [ctypes.c_int]),
-    "gt_set_chain": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_seq": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_seq_split": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_deterministic": (ctypes.c_int, [ctypes.c_int]),

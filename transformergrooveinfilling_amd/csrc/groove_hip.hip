@@ -16,11 +16,10 @@
 #include <vector>
 
 #include "gt_attn.h"
-#include "gt_chain.h"
 #include "gt_common.h"
 #include "gt_gemm.h"
 #include "gt_misc.h"
-#include "gt_seq.h"
+#include "gt_seq_api.h"
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -180,7 +179,6 @@ struct LayerW {
   int64_t qkv, P, ctx, xhat1, rstd1, x1;            // self-attention block
   int64_t qx, kvx, Px, ctxx, xhatx, rstdx, x2;      // decoder cross-attention block
   int64_t hact, xhat2, rstd2, xout;                 // FFN block (xhat2/rstd2 = the layer's LAST norm)
-  int64_t c_dz2m, c_dz1, c_dz1m, c_dhid, c_dqkv;    // row-chain path: per-layer gradients kept for the deferred wgrads
 };
 struct WLayout {
   int64_t x0, a0, enc_xhat, enc_rstd, memory, y0, b0, dec_xhat, dec_rstd, dec_final;
@@ -219,11 +217,6 @@ static WLayout ws_layout(const gt_config& c) {
       w.qx = w.kvx = w.Px = w.ctxx = w.xhatx = w.rstdx = w.x2 = -1;
     }
     w.hact = add(M * F); w.xhat2 = add(M * d); w.rstd2 = add(M); w.xout = add(M * d);
-    if (c.n_dec_layers == 0 && c.precision == 0 && chain_supported(c.d_model, c.dim_ff)) {
-      w.c_dz2m = add(M * d); w.c_dz1 = add(M * d); w.c_dz1m = add(M * d); w.c_dhid = add(M * F); w.c_dqkv = add(M * 3 * d);
-    } else {
-      w.c_dz2m = w.c_dz1 = w.c_dz1m = w.c_dhid = w.c_dqkv = -1;
-    }
   }
   W.enc_xhat = add(M * d); W.enc_rstd = add(M); W.memory = add(M * d);
   if (c.n_dec_layers > 0) {
@@ -304,20 +297,7 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   return 0;
 }
 
-// Row-chain kernels (gt_chain.h) can serve encoder-only models with d_model <= 256 and dim_feedforward <= 512 (every
-// shipped YAML and BASELINE configs[0..1]).  Parity-green, but they only pay where the weights a 16-row tile has to stream
-// are tiny: by default they serve d_model <= 64 with dim_feedforward <= 64 (the testing YAML: 0.366 -> 0.329 ms per step),
-// nothing else -- at the headline size (128 row tiles on 256 CUs, 768 KB of weights per workgroup) they are slower than
-// one kernel per op (0.404 vs 0.307 ms), because a CU's global->LDS rate bounds a 16-row tile well below its MFMA rate.
-// GT_CHAIN=1 / gt_set_chain(1) forces them wherever they are supported, GT_CHAIN=0 / gt_set_chain(0) switches them off.
-static int g_chain = -1;                            // -1: read GT_CHAIN; 0 off; 1 forced on; 2 automatic (by shape)
-extern "C" int gt_set_chain(int on) { g_chain = on != 0; return 0; }
 static thread_local int g_bf16 = 0;                  // precision of the call being enqueued (set by make_ctx / the entry points)
-static bool chain_enabled(int d, int F) {
-  if (g_bf16) return false;                         // the row-chain kernels are fp32 only
-  if (g_chain < 0) { const char* e = getenv("GT_CHAIN"); g_chain = (e && e[0] == '1') ? 1 : (e && e[0] == '0') ? 0 : 2; }
-  return g_chain == 1 || (g_chain == 2 && d <= 64 && F <= 64);
-}
 
 // ------------------------------------------------------------------------------------ launch helpers
 struct Ctx {
@@ -642,54 +622,6 @@ static int self_attn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const f
 }
 
 static bool use_seq(const gt_config& c);
-static bool use_chain(const Ctx& x) { return !use_seq(x.c) && x.c.n_dec_layers == 0 && chain_supported(x.d, x.F) && chain_enabled(x.d, x.F); }
-static bool chain_path_for(const gt_config& c) {
-  return !use_seq(c) && c.precision == 0 && c.n_dec_layers == 0 && chain_supported(c.d_model, c.dim_ff) && chain_enabled(c.d_model, c.dim_ff);
-}
-
-template <typename Args>
-static void chain_launch(void (*k64)(Args), void (*k128)(Args), void (*k256)(Args), const Ctx& x, const Args& a) {
-  const dim3 grid((x.M + 15) / 16), block(512);       // 4 compute + 4 loader waves
-  const int dp = chain_dpad(x.d);
-  if (dp == 64) gt_launch(k64, grid, block, x.s, a);
-  else if (dp == 128) gt_launch(k128, grid, block, x.s, a);
-  else gt_launch(k256, grid, block, x.s, a);
-}
-
-// encoder-only forward on the row-chain kernels: per layer ONE attention launch + ONE chain launch
-static int encoder_fwd_chain(const Ctx& x, const float* pe, const float* src) {
-  float* ws = x.ws;
-  const int d = x.d, L = x.c.n_enc_layers;
-  input_layer_fwd(x, src, x.c.src_dim, x.P.in_w, x.P.in_b, pe, ws + x.W.a0, ws + x.W.x0, GT_SITE_PE_ENC);
-  linear_fwd(x, ws + x.W.x0, d, x.prm + x.P.enc[0].sa.in_w, x.prm + x.P.enc[0].sa.in_b, ws + x.W.layers[0].qkv, 3 * d, 3 * d, d);
-  for (int l = 0; l < L; ++l) {
-    const LayerP& p = x.P.enc[l];
-    const LayerW& w = x.W.layers[l];
-    attention_fwd(x, ws + w.qkv, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.P, ws + w.ctx, 0, lsite(l, GT_SITE_ATTN));
-    ChainFwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.M = x.M; a.d = d; a.F = x.F;
-    a.ctx = ws + w.ctx; a.xin = (l == 0) ? ws + x.W.x0 : ws + x.W.layers[l - 1].xout;
-    a.Wo = x.prm + p.sa.out_w; a.bo = x.prm + p.sa.out_b;
-    a.g1 = x.prm + p.n1w; a.be1 = x.prm + p.n1b;
-    a.W1 = x.prm + p.w1; a.b1 = x.prm + p.b1; a.W2 = x.prm + p.w2; a.b2 = x.prm + p.b2;
-    a.g2 = x.prm + p.n2w; a.be2 = x.prm + p.n2b;
-    a.x1 = ws + w.x1; a.xhat1 = ws + w.xhat1; a.rstd1 = ws + w.rstd1; a.hact = ws + w.hact;
-    a.xout = ws + w.xout; a.xhat2 = ws + w.xhat2; a.rstd2 = ws + w.rstd2;
-    if (l == L - 1) {
-      a.gf = x.prm + x.P.encn_w; a.bef = x.prm + x.P.encn_b;
-      a.fin = ws + x.W.memory; a.xhatf = ws + x.W.enc_xhat; a.rstdf = ws + x.W.enc_rstd;
-    } else {
-      a.Wqkv = x.prm + x.P.enc[l + 1].sa.in_w; a.bqkv = x.prm + x.P.enc[l + 1].sa.in_b; a.qkv = ws + x.W.layers[l + 1].qkv;
-    }
-    a.drop1 = mk_drop(x, lsite(l, GT_SITE_DROP1)); a.dropH = mk_drop(x, lsite(l, GT_SITE_FFN)); a.dropF = mk_drop(x, lsite(l, GT_SITE_DROPF));
-    const double fl = 2.0 * x.M * ((double)d * d + 2.0 * d * x.F + (l == L - 1 ? 0.0 : 3.0 * d * d));
-    gt_prof_tag("chain_fwd", fl, 4.0 * x.M * (6.0 * d + x.F));
-    chain_launch(chain_fwd_kernel<64>, chain_fwd_kernel<128>, chain_fwd_kernel<256>, x, a);
-  }
-  return 0;
-}
-
 // ---- sequence-resident kernels (gt_seq.h): one workgroup per sequence walks the whole encoder -------------------------------
 // g_seq: 0 = off (GT_SEQ=0 / gt_set_seq(0)), 1 = every supported shape (GT_SEQ=1 / gt_set_seq(1): tests), 2 = by measurement (default):
 // always at d_model <= 64 (C1 1.9x, ClosedHH YAML 1.15x over one kernel per op) and at d_model 128 (two workgroups per sequence
@@ -732,30 +664,8 @@ static bool seq_supported(const gt_config& c) {
 static bool use_seq(const gt_config& c) {
   if (g_seq < 0) { const char* e = getenv("GT_SEQ"); g_seq = !e ? 2 : e[0] == '0' ? 0 : 1; }
   if (g_seq == 2 && c.d_model > 64 && c.d_model != 128 && c.batch < 64) return false;   // (128 itself: the SPLIT kernels win from batch 16 up)
-  return g_seq && seq_supported(c) && !(g_chain == 1);       // an explicit gt_set_chain(1) / GT_CHAIN=1 keeps the row-chain kernels
+  return g_seq && seq_supported(c);
 }
-// kernel<DP, HDC, EXACT>: d_model class 32 / 64 / 128, head-dim class 0 (< 16) / 16 / 32 / 64, d_model == DP
-#define GT_SEQ_LAUNCH_HD(K, DP, EX, hc, grid, block, s, a)                              \
-  if ((hc) == 0) gt_launch(K<DP, 0, EX, false>, grid, block, s, a);                      \
-  else if ((hc) == 16) gt_launch(K<DP, 16, EX, false>, grid, block, s, a);               \
-  else if ((hc) == 32 || (DP) == 32) gt_launch(K<DP, 32, EX, false>, grid, block, s, a); \
-  else gt_launch(K<(DP) == 32 ? 64 : DP, 64, EX, false>, grid, block, s, a);
-// the SPLIT kernels (two workgroups per sequence, one launch per phase): d_model 128 or 32 exactly
-#define GT_SEQ_LAUNCH_SPLIT(K, dm, hc, grid, block, s, a)                         \
-  if ((dm) == 32) {                                                                \
-    if ((hc) == 0) gt_launch(K<32, 0, true, true>, grid, block, s, a);             \
-    else if ((hc) == 16) gt_launch(K<32, 16, true, true>, grid, block, s, a);      \
-    else gt_launch(K<32, 32, true, true>, grid, block, s, a);                      \
-  } else if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);       \
-  else if ((hc) == 16) gt_launch(K<128, 16, true, true>, grid, block, s, a);       \
-  else if ((hc) == 32) gt_launch(K<128, 32, true, true>, grid, block, s, a);       \
-  else gt_launch(K<128, 64, true, true>, grid, block, s, a);
-#define GT_SEQ_LAUNCH_DP(K, DP, dm, hc, grid, block, s, a)                                                  \
-  { if ((dm) == (DP)) { GT_SEQ_LAUNCH_HD(K, DP, true, hc, grid, block, s, a) } else { GT_SEQ_LAUNCH_HD(K, DP, false, hc, grid, block, s, a) } }
-#define GT_SEQ_DISPATCH(K, dm, hc, grid, block, s, a)                         \
-  if ((dm) <= 32) GT_SEQ_LAUNCH_DP(K, 32, dm, hc, grid, block, s, a)           \
-  else if ((dm) <= 64) GT_SEQ_LAUNCH_DP(K, 64, dm, hc, grid, block, s, a)      \
-  else GT_SEQ_LAUNCH_DP(K, 128, dm, hc, grid, block, s, a)
 // gt_train_step hands its loss over to the sequence-resident forward (one launch less): set around its gt_forward call
 struct SeqLoss { const float* y; float penalty; float* stats; unsigned* ticket; };
 static thread_local SeqLoss g_seq_loss = {nullptr, 0.f, nullptr, nullptr};
@@ -803,10 +713,9 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
   {   // fragment-ordered copies of this step's weights, for the forward and the backward kernel
     const int64_t frags = 2 * (int64_t)x.c.n_enc_layers * x.W.pack_stride / 256;
     gt_prof_tag("seq_pack", 0.0, 12.0 * x.c.n_enc_layers * x.W.pack_stride);
-    gt_launch(seq_pack_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), x.s, a);
+    gt_seq_launch_pack(a, (unsigned)((frags + 3) / 4), x.s);
   }
   gt_prof_tag("seq_fwd", fl, 4.0 * x.M * (x.c.src_dim + x.c.n_enc_layers * (9.0 * x.d + x.F) + 27.0));
-  const dim3 block(GT_SEQ_NT);
   const int hc = x.hd < 16 ? 0 : x.hd;             // head-dim class (one instantiation each: the attention bodies' registers differ 4x)
   if (seq_split(x.c)) {
     const dim3 grid(2 * x.c.batch);
@@ -814,17 +723,16 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
       SeqArgs ap = a;
       ap.phase = p;
       if (p > 0) gt_prof_tag("seq_fwd", 0.0, 0.0);          // (flops and bytes of the whole forward are on the first phase's tag)
-      GT_SEQ_LAUNCH_SPLIT(seq_fwd_kernel, x.d, hc, grid, block, x.s, ap)
+      gt_seq_launch_fwd(ap, x.d, hc, true, 2 * x.c.batch, x.s);
     }
     return 0;
   }
   const dim3 grid(x.c.batch);
-  GT_SEQ_DISPATCH(seq_fwd_kernel, x.d, hc, grid, block, x.s, a)
+  gt_seq_launch_fwd(a, x.d, hc, false, x.c.batch, x.s);
   return 0;
 }
 
 static int encoder_fwd(const Ctx& x, const float* pe, const float* src) {
-  if (use_chain(x)) return encoder_fwd_chain(x, pe, src);
   float* ws = x.ws;
   input_layer_fwd(x, src, x.c.src_dim, x.P.in_w, x.P.in_b, pe, ws + x.W.a0, ws + x.W.x0, GT_SITE_PE_ENC);
   const float* cur = ws + x.W.x0;
@@ -994,14 +902,13 @@ static void input_layer_bwd(const Ctx& x, const LayerP& first, const Tmp& t, con
 // "everything from tensor X to the end" is final early: X = the decoder input layer of an encoder-decoder model, else
 // encoder layer L/2.  split_layer: first encoder layer of the upper bucket (enc-dec: L, i.e. no encoder layer).
 struct GradSplit { int nb; int split_layer; int64_t off[2], cnt[2]; };
-static bool chain_path_for(const gt_config& c);
 static GradSplit grad_split(const gt_config& c, const PLayout& P) {
   GradSplit g;
   g.nb = 1; g.split_layer = 0; g.off[0] = 0; g.cnt[0] = P.total; g.off[1] = g.cnt[1] = 0;
   int64_t cut = 0;
   if (c.n_dec_layers > 0) { cut = P.din_w; g.split_layer = c.n_enc_layers; }
   else if (c.n_enc_layers >= 2) { g.split_layer = c.n_enc_layers / 2; cut = P.enc[g.split_layer].sa.in_w; }
-  if (cut > 0 && !chain_path_for(c) && !use_seq(c)) {
+  if (cut > 0 && !use_seq(c)) {
     g.nb = 2; g.off[0] = cut; g.cnt[0] = P.total - cut; g.off[1] = 0; g.cnt[1] = cut;
   }
   return g;
@@ -1077,7 +984,6 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
       // attention backward (dP, dV, dQ, dK) = twice the forward's QK^T + PV; the SPLIT mode's second copy of it is not counted
       const double fl = 2.0 * M * (L * (4.0 * d * d + 128.0 * d + 2.0 * d * x.F) + 27.0 * d);
       gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
-      const dim3 block(GT_SEQ_NT);
       const int hc = x.hd < 16 ? 0 : x.hd;
       if (split) {
         const dim3 grid(2 * cfg->batch);
@@ -1085,11 +991,11 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
           SeqArgs ap = a;
           ap.phase = p;
           if (p > 0) gt_prof_tag("seq_bwd", 0.0, 0.0);
-          GT_SEQ_LAUNCH_SPLIT(seq_bwd_kernel, d, hc, grid, block, x.s, ap)
+          gt_seq_launch_bwd(ap, d, hc, true, 2 * cfg->batch, x.s);
         }
       } else {
         const dim3 grid(cfg->batch);
-        GT_SEQ_DISPATCH(seq_bwd_kernel, d, hc, grid, block, x.s, a)
+        gt_seq_launch_bwd(a, d, hc, false, cfg->batch, x.s);
       }
     }
     wgrad(x, ws + W.dlogits, GT_TGT, ws + W.memory, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
@@ -1106,65 +1012,6 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     wgrad(x, ws + W.dctx, d, xin, cfg->src_dim, grads + P.in_w, grads + P.in_b, d, cfg->src_dim);
     return finish();
   }
-  if (use_chain(x)) {
-    // ---- row-chain path: per layer ONE chain launch + ONE attention-backward launch; every weight gradient of the
-    // step is deferred to grouped dispatches at the end (their inputs are kept per layer in the workspace).
-    x.side = nullptr;
-    if (d_hvo != nullptr) {
-      gt_prof_tag("heads_bwd", 0, 12.0 * M * GT_TGT);
-      gt_launch(heads_bwd_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, d_hvo, hvo, ws + W.dlogits, M * GT_TGT);
-    }
-    const int ntile = (M + 15) / 16;
-    for (int j = L - 1; j >= 0; --j) {
-      const LayerP& p = P.enc[j];
-      const LayerW& w = W.layers[j];
-      ChainBwdArgs a;
-      memset(&a, 0, sizeof(a));
-      a.M = M; a.d = d; a.F = x.F;
-      if (j == L - 1) {
-        a.A0 = ws + W.dlogits; a.K0 = GT_TGT; a.W0 = params + P.out_w; a.res0 = nullptr;
-        a.xhatf = ws + W.enc_xhat; a.rstdf = ws + W.enc_rstd; a.gf = params + P.encn_w; a.partf = ln_job(x, P.encn_w, ntile);
-      } else {
-        const LayerW& wu = W.layers[j + 1];
-        a.A0 = ws + wu.c_dqkv; a.K0 = 3 * d; a.W0 = params + P.enc[j + 1].sa.in_w; a.res0 = ws + wu.c_dz1;
-      }
-      a.xhat2 = ws + w.xhat2; a.rstd2 = ws + w.rstd2; a.g2 = params + p.n2w; a.part2 = ln_job(x, p.n2w, ntile);
-      a.dropF = mk_drop(x, lsite(j, GT_SITE_DROPF)); a.dz2m_out = ws + w.c_dz2m;
-      a.W2 = params + p.w2; a.hact = ws + w.hact; a.mask_scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f; a.dhid_out = ws + w.c_dhid;
-      a.W1 = params + p.w1;
-      a.xhat1 = ws + w.xhat1; a.rstd1 = ws + w.rstd1; a.g1 = params + p.n1w; a.part1 = ln_job(x, p.n1w, ntile);
-      a.drop1 = mk_drop(x, lsite(j, GT_SITE_DROP1)); a.dz1_out = ws + w.c_dz1; a.dz1m_out = ws + w.c_dz1m;
-      a.Wo = params + p.sa.out_w; a.dctx_out = ws + W.dctx;
-      if (!a.part2 || !a.part1 || (j == L - 1 && !a.partf)) return gt_fail("too many LayerNorm instances for the partials table");
-      gt_prof_tag("chain_bwd", 2.0 * M * ((double)a.K0 * d + 2.0 * d * x.F + (double)d * d), 4.0 * M * (8.0 * d + 2.0 * x.F));
-      chain_launch(chain_bwd_kernel<64>, chain_bwd_kernel<128>, chain_bwd_kernel<256>, x, a);
-      attention_bwd(x, ws + w.qkv, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.P, ws + W.dctx, ws + w.c_dqkv, 3 * d,
-                    ws + w.c_dqkv + d, ws + w.c_dqkv + 2 * d, 3 * d, lsite(j, GT_SITE_ATTN));
-    }
-    {   // InputLayer: da0 = (dqkv_0 Win_0 + dz1_0) * dropout mask * relu'
-      const LayerW& w0 = W.layers[0];
-      GemmArgs g = mk_gemm(ws + w0.c_dqkv, 3 * d, params + P.enc[0].sa.in_w, d, ws + W.dctx, d, M, d, 3 * d);
-      g.res = ws + w0.c_dz1; g.ldres = d; g.aux_in = ws + W.a0; g.drop = mk_drop(x, GT_SITE_PE_ENC);
-      gemm_launch<false, true, EPI_ADD_RELUMASK_DROP>(g, x.s);
-    }
-    wgrad(x, ws + W.dlogits, GT_TGT, ws + W.memory, d, grads + P.out_w, grads + P.out_b, GT_TGT, d);
-    for (int j = L - 1; j >= 0; --j) {
-      const LayerP& p = P.enc[j];
-      const LayerW& w = W.layers[j];
-      const float* lin = (j == 0) ? ws + W.x0 : ws + W.layers[j - 1].xout;
-      wgrad(x, ws + w.c_dz2m, d, ws + w.hact, x.F, grads + p.w2, grads + p.b2, d, x.F);
-      wgrad(x, ws + w.c_dhid, x.F, ws + w.x1, d, grads + p.w1, grads + p.b1, x.F, d);
-      wgrad(x, ws + w.c_dz1m, d, ws + w.ctx, d, grads + p.sa.out_w, grads + p.sa.out_b, d, d);
-      wgrad(x, ws + w.c_dqkv, 3 * d, lin, d, grads + p.sa.in_w, grads + p.sa.in_b, 3 * d, d);
-    }
-    wgrad(x, ws + W.dctx, d, xin, cfg->src_dim, grads + P.in_w, grads + P.in_b, d, cfg->src_dim);
-    if (!wbatch.empty()) wgrad_flush(wbatch, x.s);
-    lnjobs.bump = bump_state;
-    gt_prof_tag("ln_param_reduce", 0, 4.0 * lnjobs.n * W.ln_part_stride);
-    gt_launch(ln_param_reduce_kernel, dim3((2 * d + 63) / 64, lnjobs.n), dim3(1024), x.s, lnjobs);
-    return launch_status("gt_backward");
-  }
-
   bool top_norm_done = false;                       // the top layer's closing norm was folded into the final norm's pass
   if (phase != 2) {
   // OutputLayer: dlogits, dW_out, then d(final) fused with the final norm's backward

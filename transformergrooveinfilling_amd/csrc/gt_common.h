@@ -36,8 +36,8 @@ __host__ __device__ static inline float gt_bf2f(uint16_t h) {
 
 #include "../../include/groove_hip.h"
 
-// GT_BARRIER(): workgroup barrier of the wave-specialised chain kernels (gt_chain.h): waits for this wave's LDS traffic
-// only -- __syncthreads() would also drain its vector-memory queue (vmcnt(0)), which the loader waves must keep in flight
+// GT_BARRIER(): stage barrier of the sequence-resident kernels (gt_seq.h): waits for this wave's LDS traffic
+// only -- __syncthreads() would also drain its vector-memory queue (vmcnt(0)), which prefetches and saves keep in flight
 // across barriers (cdna_hip_programming.md 5, "Pipelining across barriers").
 // (The LDS-DMA staging path this file once carried -- global_load_lds + inline-asm LDS reads -- measured ~27 GB/s per CU
 // against 46-70 GB/s through registers and was removed; DESIGN.md 3, rejected experiments.)
@@ -122,3 +122,27 @@ __device__ static inline float gt_wave_sum(float v) {
   return v;
 }
 __device__ static inline float gt_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// scheduling hints (no-ops in the host emulator): GT_SGB = sched_group_barrier, GT_SCHED_FENCE = sched_barrier(0)
+#ifdef GT_EMU
+#define GT_SGB(mask, n)
+#define GT_SCHED_FENCE()
+#else
+#define GT_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define GT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0);
+#endif
+
+// one (row, voice) element: the three loss terms, the hit-accuracy indicator and d loss / d (h, v, o)
+template <bool WRT_LOGITS>
+__device__ __forceinline__ void gt_loss_elem(const float h, const float v, const float o, const float yh, const float yv, const float yo,
+                                             const float penalty, const float invM, float& bce, float& mv, float& mo, float& ok, float& dh,
+                                             float& dv, float& dO) {
+  const float pen = (yh == 1.0f) ? 1.0f : penalty;
+  bce = (fmaxf(h, 0.f) - h * yh + log1pf(expf(-fabsf(h)))) * pen;
+  mv = (v - yv) * (v - yv) * pen;
+  mo = (o - yo) * (o - yo) * pen;
+  ok = (((h > 0.f) ? 1.0f : 0.0f) == yh) ? 1.0f : 0.0f;      // sigmoid(h) > 0.5  <=>  h > 0
+  dv = 2.0f * (v - yv) * pen * invM; dO = 2.0f * (o - yo) * pen * invM;
+  if (WRT_LOGITS) { dv *= v * (1.0f - v); dO *= (0.5f - 2.0f * o * o); }
+  dh = (gt_sigmoid(h) - yh) * pen * invM;
+}

@@ -18,13 +18,6 @@
 #pragma once
 // (included at the end of gt_gemm.h: GemmArgs, gemm_label and the EPI_* constants come from there)
 
-#ifdef GT_EMU
-#define GT_SGB(mask, n)
-#define GT_SCHED_FENCE()
-#else
-#define GT_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
-#define GT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0);
-#endif
 // n times: one MFMA, then one instruction of class `mask` (0x20 VMEM read, 0x100 DS read, 0x200 DS write)
 #define GT_IL(mask, n) _Pragma("unroll") for (int z_ = 0; z_ < (n); ++z_) { GT_SGB(0x8, 1) GT_SGB(mask, 1) }
 

@@ -312,20 +312,6 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnJobs jobs) {
 //   TICKET=true : every workgroup stores its 4 partial sums, the last one to arrive (agent-scope release /
 //                 acquire around a ticket counter, cdna_hip_programming.md G16) adds them in a FIXED order ->
 //                 bitwise-reproducible stats and no memset node.  The ticket word re-arms itself.
-// one (row, voice) element: the three loss terms, the hit-accuracy indicator and d loss / d (h, v, o)
-template <bool WRT_LOGITS>
-__device__ __forceinline__ void gt_loss_elem(const float h, const float v, const float o, const float yh, const float yv, const float yo,
-                                             const float penalty, const float invM, float& bce, float& mv, float& mo, float& ok, float& dh,
-                                             float& dv, float& dO) {
-  const float pen = (yh == 1.0f) ? 1.0f : penalty;
-  bce = (fmaxf(h, 0.f) - h * yh + log1pf(expf(-fabsf(h)))) * pen;
-  mv = (v - yv) * (v - yv) * pen;
-  mo = (o - yo) * (o - yo) * pen;
-  ok = (((h > 0.f) ? 1.0f : 0.0f) == yh) ? 1.0f : 0.0f;      // sigmoid(h) > 0.5  <=>  h > 0
-  dv = 2.0f * (v - yv) * pen * invM; dO = 2.0f * (o - yo) * pen * invM;
-  if (WRT_LOGITS) { dv *= v * (1.0f - v); dO *= (0.5f - 2.0f * o * o); }
-  dh = (gt_sigmoid(h) - yh) * pen * invM;
-}
 template <bool TICKET, bool WRT_LOGITS>
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ hvo, const float* __restrict__ y, float penalty,
                                                    float* __restrict__ stats, float* __restrict__ d_out, int M,

@@ -33,33 +33,8 @@
 // Supported: encoder-only, fp32 operands, d_model % 16 == 0 and <= 128, dim_feedforward % 16 == 0 and <= 512, src_dim <= 32,
 // head_dim 16 / 32 / 64 or < 16 (seq_supported in groove_hip.hip).
 #pragma once
-#include "gt_attn.h"
-#include "gt_gemm.h"
+#include "gt_seq_api.h"
 
-#define GT_SEQ_FMAX 512
-struct SeqLayerP { int64_t in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
-struct SeqLayerW { int64_t qkv, P, ctx, xhat1, rstd1, x1, hact, xhat2, rstd2, xout; };
-struct SeqTmp { int64_t dzA, dzAm, dzB, dzBm, dhid, dqkv; };
-struct SeqArgs {
-  const float* prm; float* ws; const float* pe; const float* xin; float* hvo;
-  int B, S, d, F, H, L, hd;
-  const gt_step_state* st; uint32_t thr; float dscale;     // dropout (st == nullptr or thr == 0: off)
-  SeqLayerP p0; int64_t pstride;                             // layer l: p0.* + l * pstride (encoder layers are laid out uniformly)
-  SeqLayerW w0; int64_t wstride;
-  SeqTmp t0; int64_t tstride;
-  int64_t in_w, in_b, encn_w, encn_b, out_w, out_b;          // parameter offsets of the input layer, final norm, output layer
-  int64_t x0, a0, memory, enc_xhat, enc_rstd, dlogits, da0;  // workspace offsets
-  int64_t ln_part, ln_part_stride;                           // LayerNorm dgamma/dbeta partials: job j at ln_part + j * stride, [B][2][d]
-  int64_t stamps;                                            // diagnostic builds (-DGT_SEQ_STAMPS) only: workspace offset of the stamp buffer
-  int64_t pack_f, pack_b, kstride;                           // fragment-ordered weight copies (seq_pack_kernel): workspace offsets, floats per layer
-  int64_t dctx;                                              // SPLIT kernels: two [M][d] hand-over buffers of the backward phases (phase p writes
-                                                             // buffer p & 1 and reads the other: a fast workgroup must not overwrite rows its
-                                                             // partner has yet to read)
-  int phase;                                                 // SPLIT kernels: which phase this launch runs
-  // fused loss (gt_train_step): the launch that runs the output layer also computes the loss terms, d loss / d logits and the
-  // step's statistics (loss_y == nullptr: off).  Same arithmetic as loss_kernel<true, true> (gt_loss_elem), one partial per workgroup
-  const float* loss_y; float loss_penalty; float* loss_stats; float* loss_part; unsigned* loss_ticket;
-};
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md 7): workgroup 0, thread 0 records the shader clock at stage
 // boundaries into a buffer nothing else reads.  tools/seq_stamps.py prints the per-stage cycle counts.
 #ifdef GT_SEQ_STAMPS
@@ -177,6 +152,7 @@ __device__ __forceinline__ void seq_b_load(SeqB<NK>& b, const float* __restrict_
 #pragma unroll
   for (int u = 0; u < NK; ++u) { if (FULL || u < nk) b.v[u] = *reinterpret_cast<const float4*>(p + 256 * u); }
 }
+#ifdef GT_SEQ_TU_FWD   // (non-template kernel: defined in the forward translation unit only)
 // one wave per fragment: 4 fragments per 256-thread block, 2 packs x L layers x (3 d^2 + d^2 + 2 d F) / 256 fragments
 __global__ __launch_bounds__(256) void seq_pack_kernel(SeqArgs a) {
   const int lane = threadIdx.x & 63, l16 = lane & 15, lg = lane >> 4;
@@ -203,6 +179,7 @@ __global__ __launch_bounds__(256) void seq_pack_kernel(SeqArgs a) {
   }
   *reinterpret_cast<float4*>(a.ws + (pack ? a.pack_b : a.pack_f) + (int64_t)l * a.kstride + moff + (int64_t)f * 256 + lane * 4) = v;
 }
+#endif
 // acc0 / acc1 (rows l16 / 16 + l16) += A[:, k0 .. k0 + 16 nk) * B; ap = sA + l16 * lda + k0 + 4 lg (the A fragments are re-read from
 // acc0 / acc1 (rows l16 / 16 + l16 from ap's row) += A[:, k0 .. k0 + 16 nk) * B; the A fragments are re-read from LDS per tile
 // (two 16-byte reads per 8 MFMAs).  HALF: only acc0.
