@@ -138,7 +138,12 @@ int gt_grad_buckets(const gt_config* cfg, int64_t* offsets, int64_t* counts);
  * 2 = as 1 but backward stops as soon as bucket 0 of gt_grad_buckets() is final; 3 = ONLY the rest of that backward
  * (same buffers, directly after a skip_update=2 call) -- the caller all-reduces bucket 0 while 3 runs.
  * PRECONDITION: grads is all zeros on entry (zero it once after allocation; the update this call -- or the
- * caller's gt_optimizer_step(zero_grads=1) -- leaves it zeroed again, so no per-step memset is enqueued). */
+ * caller's gt_optimizer_step(zero_grads=1) -- leaves it zeroed again, so no per-step memset is enqueued).
+ * skip_update | GT_STEP_PACKS_CURRENT: on the sequence-resident path (gt_step_launches() > 0) a whole step (skip_update 0) ends with an
+ * update that also writes the NEXT step's fragment-ordered weight copies into ws; a caller that knows the previous call on this ws was
+ * such a step and that nobody has written params since may set this bit, and the packing launch at the head of the step is skipped.
+ * Ignored on the other paths. */
+#define GT_STEP_PACKS_CURRENT 4
 int gt_train_step(const gt_config* cfg, int algo, float* params, float* grads, float* m, float* v,
                   const float* pe, const float* x, const float* y, float hit_loss_penalty,
                   float* hvo_out, float* stats, float* tgt_scratch, float* ws, gt_step_state* state,
@@ -186,6 +191,17 @@ int gt_set_seq(int on);
  * d_model 128 or 32: -1 = default (when 2 x batch workgroups fit the CUs once; d_model 32 only with dim_feedforward >= 256), 0 = off,
  * 1 = on (env GT_SEQ_SPLIT=0/1 does the same).  Same results bit for bit: the split is over token rows. */
 int gt_set_seq_split(int on);
+/* Weight gradients as RIDER workgroups (csrc/gt_seq_wg.h): in the SPLIT mode at d_model 128 the backward phases' launches carry, on
+ * the CUs their 2 x batch sequence workgroups leave idle, the weight gradients whose operands the earlier phases completed; one
+ * workgroup owns a 32 x 64 gradient tile over ALL tokens (no atomics: bitwise reproducible), and a tail launch does what cannot ride
+ * (layer 0's in-proj, the input layer), the LayerNorm parameter gradients and the step-counter bump.  -1 = default (when at least 64
+ * CUs are idle beside the sequence workgroups), 0 = off (the grouped dispatch at the end of backward), 1 = on wherever supported
+ * (env GT_SEQ_RIDE=0/1 does the same).  Same results to fp32 rounding (another summation order over the tokens). */
+int gt_set_seq_ride(int on);
+/* Measurement aid (tools/wg_unit_bench.py): the rider units of backward phase `phase` as a launch of their own (token range split
+ * `ksplit` ways), ADDING into grads; operands = what the last backward on this workspace left there. */
+int gt_debug_seq_wg_phase(const gt_config* cfg, const float* params, float* grads, const float* x, float* ws, int phase, int ksplit,
+                          gt_stream_t stream);
 /* Bitwise-reproducible weight gradients: each output tile of a weight gradient is owned by ONE workgroup that walks all tokens
  * (no split over the token dimension), so the fp32 atomic adds have a single contributor per element.  Everything else of the
  * step is reproducible already (fixed-order reductions).  Off by default: the small shapes lose their token parallelism

@@ -52,6 +52,7 @@ extern dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 extern unsigned char* dyn_smem_;
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 void block_sync();
+void wave_rendezvous();     // all live lanes of the calling wave (hardware: lanes run in lock-step; the emulator: fibers do not)
 float wave_shfl(float v, int src_lane);
 f32x4 mfma16(float a, float b, f32x4 c);
 }  // namespace emu
@@ -184,6 +185,7 @@ void run_block() {
 void wave_sync() { fibers[cur].state = WAIT_WAVE; yield_to_sched(); }
 }  // namespace
 
+void wave_rendezvous() { wave_sync(); }
 void block_sync() { fibers[cur].state = WAIT_BLOCK; ++fibers[cur].nbar; yield_to_sched(); }
 
 float wave_shfl(float v, int src_lane) {

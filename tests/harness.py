@@ -64,7 +64,10 @@ class Runner:
         self.lib = emu_lib() if backend == "emu" else _lib.get_lib()
         self.lib.cdll.gt_set_seq(int(bool(seq)))  # process-global switch: sequence-resident kernels (default where supported)
         # seq = "split" / "whole": force / forbid their two-workgroups-per-sequence mode (d_model 128); True: the library's choice
-        self.lib.cdll.gt_set_seq_split(1 if seq == "split" else 0 if seq == "whole" else -1)
+        self.lib.cdll.gt_set_seq_split(1 if seq in ("split", "split-noride") else 0 if seq == "whole" else -1)
+        # "split": weight gradients as rider workgroups of the backward phases where the library chooses to (idle CUs); "split-noride":
+        # the grouped dispatch at the end of backward
+        self.lib.cdll.gt_set_seq_ride(0 if seq == "split-noride" else -1)
         self.Buf = NpBuf if backend == "emu" else CudaBuf
         self.c = _lib.make_config(B, cfg["embedding_size_src"], cfg["d_model"], cfg["n_heads"], cfg["dim_feedforward"],
                                   cfg["num_encoder_layers"], cfg.get("num_decoder_layers", 0), cfg.get("dropout", 0.0),

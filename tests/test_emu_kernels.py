@@ -144,15 +144,24 @@ def test_sequence_resident_kernels(cfg, B, p):
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(128, 4, 512, 2), 1, 0.24), (cfg_dict(128, 16, 48, 3), 2, 0.1), (cfg_dict(128, 2, 32, 1), 1, 0.0),
                                      (cfg_dict(32, 16, 512, 2), 2, 0.24), (cfg_dict(32, 2, 32, 1), 1, 0.1), (cfg_dict(32, 1, 16, 2), 3, 0.0)])
 def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
-    """d_model 128 / 32, SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels"""
+    """d_model 128 / 32, SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels.
+    At d_model 128 "split" also means: weight gradients as rider workgroups of the backward phases + the tail launch (gt_seq_wg.h)"""
     parity.check_step("emu", cfg, B, p, seq="split")
     parity.check_step("emu", cfg, B, p, seq="whole")
+
+
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(128, 4, 64, 2, embedding_size_src=27), 3, 0.2),    # packed staging of the 27-wide input / output layer
+                                     (cfg_dict(128, 8, 80, 1), 5, 0.0)])                          # partial column tiles, odd slab count
+def test_rider_weight_gradients_edge_shapes(cfg, B, p):
+    parity.check_step("emu", cfg, B, p, seq="split")
+    parity.check_step("emu", cfg, B, p, seq="split-noride")
 
 
 def test_sequence_resident_train_step_and_predict():
     parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.2)
     parity.check_train_step("emu", cfg_dict(128, 4, 32, 2), 2, 0.2, seq="split")      # loss fused into the last forward phase, 4 workgroups
     parity.check_train_step("emu", cfg_dict(128, 8, 48, 1), 3, 0.1, seq="whole")
+    parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.0, algo=1)               # the fused update + pack kernel, Adam branch
     parity.check_bucketed_backward("emu", cfg_dict(32, 4, 16, 2), 2, 0.25, 1, exact=True)      # one bucket: the backward is one launch
     parity.check_predict("emu", cfg_dict(32, 4, 16, 2), 2, True)
 

@@ -98,7 +98,8 @@ def test_train_loop_fast_path_checkpoint_and_resume(tmp_path):
                        mse_fn=mse, device="cuda", test_inputs=x[:16], test_gt=y[:16], hit_loss_penalty=0.38, save=(ep == 2),
                        save_dir=str(tmp_path), run_id="abc", log_every=4, on_log=logs.append)
         first = first or m["train/loss"]
-    assert m["train/loss"] < first and any("test/loss" in r for r in logs) and any("train/loss" in r for r in logs)
+    assert m["train/loss"] < first, (first, m, [r.get("train/loss") for r in logs if "train/loss" in r])
+    assert any("test/loss" in r for r in logs) and any("train/loss" in r for r in logs)
     assert model.engine.state_struct().step == 3 * 8                                 # one fused update per batch
     ck = tmp_path / "transformer_run_abc_Epoch_2.Model"
     assert ck.exists()

@@ -63,7 +63,10 @@ _SIGS = {
     "gt_set_overlap": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_seq": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_seq_split": (ctypes.c_int, [ctypes.c_int]),
+    "gt_set_seq_ride": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_deterministic": (ctypes.c_int, [ctypes.c_int]),
+    # cfg, params, grads, x, ws, phase, ksplit, stream
+    "gt_debug_seq_wg_phase": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "gt_step_launches": (ctypes.c_int, [ctypes.POINTER(GtConfig)]),
     "gt_profile_report": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]),
 }

@@ -656,6 +656,24 @@ static bool seq_split(const gt_config& c) {
   if (c.d_model == 32 && c.dim_ff < 256) return false;
   return 2 * c.batch <= seq_cu_count();
 }
+// Riders (gt_seq_wg.h): the SPLIT backward phases of the d_model-128 kernels carry the weight gradients on the CUs the sequence
+// workgroups leave idle.  g_seq_ride: -1 = by shape (enough idle CUs that a phase's units get a rider each or nearly), 0 off, 1 on
+// wherever the kernels support it (GT_SEQ_RIDE=0/1, gt_set_seq_ride).
+static int g_seq_ride = -1;
+extern "C" int gt_set_seq_ride(int on) { g_seq_ride = on < 0 ? -1 : on != 0; return 0; }
+#ifndef GT_SEQ_RIDE_MIN_IDLE
+#define GT_SEQ_RIDE_MIN_IDLE 96      /* batch <= 80: a phase's units find a rider each (bs 96, 64 idle CUs: 0.324 ms riding vs 0.270 grouped) */
+#endif
+#ifndef GT_SEQ_RIDE_LAST_PCT
+#define GT_SEQ_RIDE_LAST_PCT 50
+#endif
+static bool seq_ride(const gt_config& c) {
+  if (c.d_model != 128 || c.dim_ff % 16 != 0 || !seq_split(c)) return false;
+  if (g_seq_ride < 0) { const char* e = getenv("GT_SEQ_RIDE"); if (e) g_seq_ride = e[0] != '0'; }
+  const int idle = seq_cu_count() - 2 * c.batch;
+  if (g_seq_ride >= 0) return g_seq_ride != 0 && idle >= 1;
+  return idle >= GT_SEQ_RIDE_MIN_IDLE;
+}
 static bool seq_supported(const gt_config& c) {
   const int hd = c.d_model / c.n_heads;
   return c.n_dec_layers == 0 && c.precision == 0 && c.d_model % 16 == 0 && c.d_model <= 128 && c.dim_ff % 16 == 0 &&
@@ -669,13 +687,17 @@ static bool use_seq(const gt_config& c) {
 // gt_train_step hands its loss over to the sequence-resident forward (one launch less): set around its gt_forward call
 struct SeqLoss { const float* y; float penalty; float* stats; unsigned* ticket; };
 static thread_local SeqLoss g_seq_loss = {nullptr, 0.f, nullptr, nullptr};
+// gt_train_step with GT_STEP_PACKS_CURRENT: the fragment-ordered weight copies in ws are the previous fused update's (seq_update_pack_kernel)
+static thread_local bool g_seq_packs_current = false;
 // launches of one gt_train_step on the sequence-resident path (0: another path -- dozens to hundreds): pack, forward (phases), backward
 // (phases), LayerNorm-parameter reduce, grouped weight gradients (one or two tile classes), optimizer.  Hosts use it to choose
 // between replaying a captured graph and plain launches: below ~25 nodes the graph's per-node cost exceeds what it saves.
 extern "C" int gt_step_launches(const gt_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (!use_seq(*cfg)) return 0;
-  return seq_split(*cfg) ? 2 * (cfg->n_enc_layers + 1) + 5 : 7;
+  // (with GT_STEP_PACKS_CURRENT one less: no packing launch)
+  if (!seq_split(*cfg)) return 7;
+  return 2 * (cfg->n_enc_layers + 1) + (seq_ride(*cfg) ? 3 : 5);   // pack, phases, [grouped weight gradients x 2,] reduce / tail, update
 }
 static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hvo) {
   SeqArgs a;
@@ -686,7 +708,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.dscale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
   const LayerP& p = x.P.enc[0];
   a.p0 = SeqLayerP{p.sa.in_w, p.sa.in_b, p.sa.out_w, p.sa.out_b, p.w1, p.b1, p.w2, p.b2, p.n1w, p.n1b, p.n2w, p.n2b};
-  a.pstride = x.c.n_enc_layers > 1 ? x.P.enc[1].sa.in_w - p.sa.in_w : 0;
+  a.pstride = x.c.n_enc_layers > 1 ? x.P.enc[1].sa.in_w - p.sa.in_w : x.P.encn_w - p.sa.in_w;   // (one layer: its span -- the update kernel's range test)
   const LayerW& w = x.W.layers[0];
   a.w0 = SeqLayerW{w.qkv, w.P, w.ctx, w.xhat1, w.rstd1, w.x1, w.hact, w.xhat2, w.rstd2, w.xout};
   a.wstride = x.c.n_enc_layers > 1 ? x.W.layers[1].qkv - w.qkv : 0;
@@ -700,6 +722,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
   a.dctx = x.W.seq_dctx; a.phase = 0;
   a.loss_y = nullptr; a.loss_penalty = 0.f; a.loss_stats = nullptr; a.loss_part = nullptr; a.loss_ticket = nullptr;
+  a.grd = nullptr; a.nseq = 0; a.wg_accumulate = 0; a.ride_last_k = x.M; a.tail_phase = 0; a.tail_ksplit = 1; a.ln_nwg = 0; a.bump = nullptr;
   return a;
 }
 // the whole forward (input layer ... output heads) of every sequence: ONE launch
@@ -710,7 +733,7 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
     a.loss_part = x.ws + x.W.loss_part;
   }
   const double fl = 2.0 * x.M * ((double)x.c.src_dim * x.d + x.c.n_enc_layers * (4.0 * x.d * x.d + 64.0 * x.d + 2.0 * x.d * x.F) + 27.0 * x.d);
-  {   // fragment-ordered copies of this step's weights, for the forward and the backward kernel
+  if (!g_seq_packs_current) {   // fragment-ordered copies of this step's weights, for the forward and the backward kernel
     const int64_t frags = 2 * (int64_t)x.c.n_enc_layers * x.W.pack_stride / 256;
     gt_prof_tag("seq_pack", 0.0, 12.0 * x.c.n_enc_layers * x.W.pack_stride);
     gt_seq_launch_pack(a, (unsigned)((frags + 3) / 4), x.s);
@@ -926,7 +949,7 @@ extern "C" int gt_grad_buckets(const gt_config* cfg, int64_t* offsets, int64_t* 
 // same workspace -- the hand-over temporaries live there)
 static int backward_impl(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
                          const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
-                         gt_stream_t stream, int phase = 0, gt_step_state* bump_state = nullptr) {
+                         gt_stream_t stream, int phase = 0, gt_step_state* bump_state = nullptr, bool grads_zero = false) {
   Ctx x;
   if (make_ctx(x, cfg, params, grads, ws, state, train, stream)) return -1;
   if (!grads || !xin) return gt_fail("gt_backward: grads / x must not be NULL");
@@ -978,15 +1001,48 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
     bool ok = ln_job(x, P.encn_w, nwg) != nullptr;
     for (int j = L - 1; j >= 0; --j) ok = ok && ln_job(x, P.enc[j].n2w, nwg) && ln_job(x, P.enc[j].n1w, nwg);
     if (!ok) return gt_fail("too many LayerNorm instances for the partials table");
+    const bool ride = split && seq_ride(*cfg);
     {
-      const SeqArgs a = mk_seq(x, nullptr, xin, nullptr);
-      // dgrad products only (the weight gradients are the grouped dispatch): the four Linear dgrads = the forward's GEMM flops,
-      // attention backward (dP, dV, dQ, dK) = twice the forward's QK^T + PV; the SPLIT mode's second copy of it is not counted
-      const double fl = 2.0 * M * (L * (4.0 * d * d + 128.0 * d + 2.0 * d * x.F) + 27.0 * d);
-      gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
+      SeqArgs a = mk_seq(x, nullptr, xin, nullptr);
+      // dgrad products (the four Linear dgrads = the forward's GEMM flops; attention backward (dP, dV, dQ, dK) = twice the forward's
+      // QK^T + PV; the SPLIT mode's second copy of it is not counted) -- plus, with riders, the weight gradients these launches carry
+      double fl = 2.0 * M * (L * (4.0 * d * d + 128.0 * d + 2.0 * d * x.F) + 27.0 * d);
       const int hc = x.hd < 16 ? 0 : x.hd;
+      if (ride) {
+        // rider workgroups behind the 2 x batch sequence workgroups: as many as the busiest phase has units, at most the idle CUs
+        a.grd = grads; a.nseq = 2 * cfg->batch; a.wg_accumulate = (accumulate && !grads_zero) ? 1 : 0;
+        const int per_layer = gt_seq_wg_tiles(d, x.F) + gt_seq_wg_tiles(x.F, d) + gt_seq_wg_tiles(d, d), win = gt_seq_wg_tiles(3 * d, d);
+        const int idle = seq_cu_count() - a.nseq, busiest = per_layer + (L > 1 ? win : 0);
+        const int R = idle < busiest ? (idle > 0 ? idle : 1) : busiest;
+        // the last phase's sequence work is short (attention backward + in-proj dgrad of layer 0): its riders take only the first
+        // GT_SEQ_RIDE_LAST_PCT % of the tokens of each tile, the tail launch -- the whole chip -- adds the rest
+        static const int last_pct = [] { const char* e = getenv("GT_SEQ_RIDE_LAST_PCT"); const int v = e ? atoi(e) : GT_SEQ_RIDE_LAST_PCT; return v < 0 ? 0 : v > 100 ? 100 : v; }();
+        a.ride_last_k = (int)((int64_t)M * last_pct / 100) / 64 * 64;
+        if (last_pct == 100) a.ride_last_k = M;
+        fl += 2.0 * M * ((L - 1) * 3.0 * d * d + L * ((double)d * d + 2.0 * d * x.F)) - 2.0 * (M - a.ride_last_k) * busiest * 2048.0;
+        gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
+        for (int p = 0; p <= L; ++p) {
+          SeqArgs ap = a;
+          ap.phase = p;
+          if (p > 0) gt_prof_tag("seq_bwd", 0.0, 0.0);
+          gt_seq_launch_bwd(ap, d, hc, true, a.nseq + (p == 0 ? 0 : R), x.s);
+        }
+        // the tail: the rest of the last phase's tiles, then in-proj of layer 0 + output layer + input layer (token range split in two:
+        // two partial tiles adding onto zero commute, so this stays reproducible; GT_SEQ_TAIL_KS for experiments), the LayerNorm
+        // parameter gradients, the step-counter bump
+        static const int tail_ks = [] { const char* e = getenv("GT_SEQ_TAIL_KS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+        const int tiles = win + gt_seq_wg_tiles(GT_TGT, d) + gt_seq_wg_tiles(d, cfg->src_dim);
+        int ks = (gt_deterministic() && tail_ks > 2) ? 2 : tail_ks;
+        if (ks > M / 8) ks = M / 8;
+        a.phase = L + 1; a.tail_phase = L + 1; a.tail_ksplit = ks; a.ln_nwg = nwg; a.bump = bump_state;
+        const int nrest = a.ride_last_k < M ? busiest : 0;
+        gt_prof_tag("seq_tail", 2.0 * M * (3.0 * d * d + 27.0 * d + (double)d * cfg->src_dim) + 2.0 * (M - a.ride_last_k) * busiest * 2048.0,
+                    4.0 * M * (4.0 * d + cfg->src_dim));
+        gt_seq_launch_tail(a, (unsigned)(nrest + tiles * ks + (2 * L + 1) * ((2 * d + 63) / 64)), x.s);
+        return launch_status("gt_backward");
+      }
+      gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
       if (split) {
-        const dim3 grid(2 * cfg->batch);
         for (int p = 0; p <= L; ++p) {
           SeqArgs ap = a;
           ap.phase = p;
@@ -994,7 +1050,6 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
           gt_seq_launch_bwd(ap, d, hc, true, 2 * cfg->batch, x.s);
         }
       } else {
-        const dim3 grid(cfg->batch);
         gt_seq_launch_bwd(a, d, hc, false, cfg->batch, x.s);
       }
     }
@@ -1122,6 +1177,25 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   return finish();
 }
 
+// Measurement aid: the weight-gradient units of backward phase `phase` (gt_seq_wg.h) as a launch of their own, token range split
+// `ksplit` ways, adding into grads -- operands are whatever the last backward left in ws.  tools/wg_unit_bench.py times it.
+extern "C" int gt_debug_seq_wg_phase(const gt_config* cfg, const float* params, float* grads, const float* xin, float* ws, int phase,
+                                     int ksplit, gt_stream_t stream) {
+  Ctx x;
+  if (make_ctx(x, cfg, params, grads, ws, nullptr, 0, stream)) return -1;
+  if (!seq_supported(*cfg) || cfg->d_model != 128) return gt_fail("gt_debug_seq_wg_phase: d_model 128 sequence-resident shapes only");
+  const int L = cfg->n_enc_layers, d = x.d;
+  if (phase < 0 || phase > L + 1 || ksplit < 1) return gt_fail("gt_debug_seq_wg_phase: phase / ksplit out of range");
+  SeqArgs a = mk_seq(x, nullptr, xin, nullptr);
+  a.grd = grads; a.nseq = 0; a.wg_accumulate = 1; a.phase = phase; a.tail_phase = phase; a.tail_ksplit = ksplit; a.ln_nwg = 0; a.bump = nullptr;
+  if (phase == 0 || phase > L) return gt_fail("gt_debug_seq_wg_phase: phases 1..L carry riders");
+  const int per_layer = gt_seq_wg_tiles(d, x.F) + gt_seq_wg_tiles(x.F, d) + gt_seq_wg_tiles(d, d), win = gt_seq_wg_tiles(3 * d, d);
+  const int tiles = per_layer + (phase >= 2 ? win : 0);
+  gt_prof_tag("seq_tail", 0.0, 0.0);
+  gt_seq_launch_tail(a, (unsigned)(tiles * ksplit), x.s);
+  return launch_status("gt_debug_seq_wg_phase");
+}
+
 extern "C" int gt_backward(const gt_config* cfg, const float* params, float* grads, const float* xin, const float* tgt_in,
                            const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
                            gt_stream_t stream) {
@@ -1160,7 +1234,9 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
                              float* tgt_scratch, float* ws, gt_step_state* state, int skip_update, gt_stream_t stream) {
   if (check_cfg(cfg)) return -1;
   if (!y || !state) return gt_fail("gt_train_step: y / state must not be NULL");
-  if (skip_update < 0 || skip_update > 3) return gt_fail("gt_train_step: skip_update %d outside 0..3", skip_update);
+  if (skip_update < 0 || skip_update > 7) return gt_fail("gt_train_step: skip_update %d outside 0..7", skip_update);
+  const bool packs_current = (skip_update & GT_STEP_PACKS_CURRENT) != 0;
+  skip_update &= 3;
   const int M = cfg->batch * 32;
   hipStream_t s = (hipStream_t)stream;
   const float* tgt_in = nullptr;
@@ -1174,8 +1250,10 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   // sequence-resident path: the launch that runs the output layer computes the loss as well (one launch less)
   const bool fuse_loss = use_seq(*cfg) && stats != nullptr && hvo_out != nullptr;
   if (fuse_loss) g_seq_loss = SeqLoss{y, hit_loss_penalty, stats, reinterpret_cast<unsigned*>(&state->pad2[0])};
+  g_seq_packs_current = packs_current && use_seq(*cfg);
   const int frc = gt_forward(cfg, params, pe, xin, tgt_in, hvo_out, ws, state, 1, stream);
   g_seq_loss.y = nullptr;
+  g_seq_packs_current = false;
   if (frc) return -1;
   // loss + head-activation backward in one kernel: d loss / d logits straight into ws.dlogits; workgroup partials are
   // combined by the last-arriving workgroup (ticket in the step state), so there is no memset node and the stats are
@@ -1190,10 +1268,22 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   // whole step: the last launch of backward (the LayerNorm partials reduce -- every model has LayerNorms) also advances the
   // step counters, and the optimizer is told so: one launch less than update + step_inc
   if (backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, skip_update == 2 ? 1 : 0,
-                    skip_update == 0 ? state : nullptr))
+                    skip_update == 0 ? state : nullptr, true))
     return -1;
   if (!skip_update) {
     PLayout P = param_layout(*cfg);
+    if (use_seq(*cfg)) {
+      // sequence-resident path: the update also writes the NEXT step's fragment-ordered weights (its caller may then pass
+      // GT_STEP_PACKS_CURRENT and the packing launch at the head of the step disappears)
+      if (algo != 0 && algo != 1) return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
+      if (algo == 1 && (!m || !v)) return gt_fail("gt_optimizer_step: adam needs m and v");
+      Ctx x;
+      if (make_ctx(x, cfg, params, grads, ws, state, 1, stream)) return -1;
+      const SeqArgs a = mk_seq(x, pe, xin, hvo_out);
+      gt_prof_tag("optimizer", 0, (algo ? 28.0 : 12.0) * P.total + 8.0 * cfg->n_enc_layers * x.W.pack_stride);
+      gt_seq_launch_update_pack(a, algo, params, grads, m, v, P.total, state, 1, (hipStream_t)stream);
+      return launch_status("gt_train_step");
+    }
     if (optimizer_step_impl(algo, params, grads, m, v, P.total, state, 1, stream, 1)) return -1;
   }
   return 0;

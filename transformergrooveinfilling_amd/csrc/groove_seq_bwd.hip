@@ -1,4 +1,5 @@
 // Translation unit of the sequence-resident backward kernels (gt_seq.h): every instantiation + its launcher.
+#define GT_SEQ_TU_BWD
 #include "gt_seq.h"
 
 // kernel<DP, HDC, EXACT>: d_model class 32 / 64 / 128, head-dim class 0 (< 16) / 16 / 32 / 64, d_model == DP
@@ -28,3 +29,4 @@ void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsign
   if (split) { GT_SEQ_LAUNCH_SPLIT(seq_bwd_kernel, d_model, hc, grid, block, s, a) }
   else { GT_SEQ_DISPATCH(seq_bwd_kernel, d_model, hc, grid, block, s, a) }
 }
+void gt_seq_launch_tail(const SeqArgs& a, unsigned nblocks, hipStream_t s) { gt_launch(seq_tail_kernel, dim3(nblocks), dim3(GT_SEQ_NT), s, a); }

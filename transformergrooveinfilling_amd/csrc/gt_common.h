@@ -47,6 +47,15 @@ __host__ __device__ static inline float gt_bf2f(uint16_t h) {
 #define GT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// GT_WAVE_SYNC(): lanes of one wave exchange data through LDS without a workgroup barrier (wave-private staging, gt_seq_wg.h).  The
+// hardware runs a wave's lanes in lock-step and its LDS instructions in order, so this is only a compiler scheduling barrier; the host
+// emulator's lanes are independent fibers and rendezvous here.
+#ifdef GT_EMU
+#define GT_WAVE_SYNC() emu::wave_rendezvous()
+#else
+#define GT_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 #define GT_LN_EPS 1e-5f
 
 // A 16-byte zero page.  Out-of-range staging loads select THIS ADDRESS instead of zero-selecting the

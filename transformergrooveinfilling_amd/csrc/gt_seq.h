@@ -55,6 +55,8 @@ __shared__ long long* gt_sub_ptr;      // sub-stage stamps of ONE matmul stage (
 // outstanding global stores.
 #define GT_SEQ_WAVES 8
 #define GT_SEQ_NT (GT_SEQ_WAVES * 64)
+#define GT_SEQ_NT_WG GT_SEQ_NT
+#include "gt_seq_wg.h"
 
 // ---- dropout: the step state is read ONCE per kernel (three scalars); keys and multipliers are the ones of gt_common.h ------------
 struct SeqDropK { uint32_t thr; float scale; uint32_t s_lo, s_hi; };
@@ -179,6 +181,82 @@ __global__ __launch_bounds__(256) void seq_pack_kernel(SeqArgs a) {
   }
   *reinterpret_cast<float4*>(a.ws + (pack ? a.pack_b : a.pack_f) + (int64_t)l * a.kstride + moff + (int64_t)f * 256 + lane * 4) = v;
 }
+
+// The optimizer update of the fused train step, folded with the packing of the NEXT step's weights (round 3: the update touches every
+// weight anyway).  Part A, one wave per 16 x 16 block of a layer matrix (in_w, out_w, w1, w2 of every encoder layer): new weight ->
+// the parameter buffer, the forward fragment (the block as loaded: lane (l16, lg) = row l16, columns 4 lg ..) and -- transposed through
+// 1 KB of LDS -- the dgrad fragment; the gradient is consumed and zeroed.  Part B: every other parameter (biases, LayerNorms, input /
+// output layer), the flat sweep of sgd_kernel / adam_kernel.  Same arithmetic as those kernels, element for element.
+struct SeqUpd { float* prm; float* g; float* m; float* v; int64_t n; const gt_step_state* st; int algo, step_advanced, nblk_a; };
+__device__ __forceinline__ float seq_upd_elem(const SeqUpd& u, const int64_t i, const float w, const float g, const float k, const float b1,
+                                              const float b2, const float step_size, const float inv_sqrt_bc2, const float gs, const float eps) {
+  if (u.algo == 0) return w - k * g;
+  const float gi = g * gs;
+  const float mi = b1 * u.m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * u.v[i] + (1.0f - b2) * gi * gi;
+  u.m[i] = mi; u.v[i] = vi;
+  return w - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+}
+__global__ __launch_bounds__(256) void seq_update_pack_kernel(SeqArgs a, SeqUpd u) {
+  __shared__ float tr[4][16][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, lg = lane >> 4;
+  const float k = u.st->lr * u.st->grad_scale;
+  float b1 = 0.f, b2 = 0.f, step_size = 0.f, inv_sqrt_bc2 = 0.f, gs = u.st->grad_scale, eps = 0.f;
+  if (u.algo == 1) {
+    b1 = u.st->beta1; b2 = u.st->beta2; eps = u.st->eps;
+    const float t = (float)(u.st->opt_step + (u.step_advanced ? 0u : 1u));
+    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    step_size = u.st->lr / bc1; inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  }
+  const int d = a.d, F = a.F, d16 = d >> 4, f16 = F >> 4;
+  const int nf0 = 3 * d16 * d16, nf1 = d16 * d16, nf2 = f16 * d16, T = nf0 + nf1 + 2 * nf2;
+  if ((int)blockIdx.x < u.nblk_a) {
+    const int gidx = blockIdx.x * 4 + wave;
+    if (gidx >= a.L * T) return;
+    const int l = gidx / T;
+    int f = gidx % T, R, C;
+    int64_t src, moff;
+    if (f < nf0) { src = a.p0.in_w; R = 3 * d; C = d; moff = 0; }
+    else if (f < nf0 + nf1) { f -= nf0; src = a.p0.out_w; R = d; C = d; moff = (int64_t)3 * d * d; }
+    else if (f < nf0 + nf1 + nf2) { f -= nf0 + nf1; src = a.p0.w1; R = F; C = d; moff = (int64_t)4 * d * d; }
+    else { f -= nf0 + nf1 + nf2; src = a.p0.w2; R = d; C = F; moff = (int64_t)4 * d * d + (int64_t)d * F; }
+    const int nkt = C >> 4, br = f / nkt, bc = f % nkt;
+    const int64_t e0 = src + (int64_t)l * a.pstride + (int64_t)(16 * br + l16) * C + 16 * bc + 4 * lg;
+    const float4 w = *reinterpret_cast<const float4*>(u.prm + e0), g = *reinterpret_cast<const float4*>(u.g + e0);
+    float4 nw;
+    nw.x = seq_upd_elem(u, e0, w.x, g.x, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
+    nw.y = seq_upd_elem(u, e0 + 1, w.y, g.y, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
+    nw.z = seq_upd_elem(u, e0 + 2, w.z, g.z, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
+    nw.w = seq_upd_elem(u, e0 + 3, w.w, g.w, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
+    *reinterpret_cast<float4*>(u.prm + e0) = nw;
+    *reinterpret_cast<float4*>(u.g + e0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* pf = a.ws + a.pack_f + (int64_t)l * a.kstride + moff;
+    float* pb = a.ws + a.pack_b + (int64_t)l * a.kstride + moff;
+    *reinterpret_cast<float4*>(pf + (int64_t)f * 256 + lane * 4) = nw;
+    tr[wave][l16][4 * lg] = nw.x; tr[wave][l16][4 * lg + 1] = nw.y; tr[wave][l16][4 * lg + 2] = nw.z; tr[wave][l16][4 * lg + 3] = nw.w;
+    GT_WAVE_SYNC();
+    // dgrad fragment (tile over the columns of W = bc, k-step = br): lane (l16, lg) holds W[16 br + 4 lg + j][16 bc + l16]
+    const float4 tv = make_float4(tr[wave][4 * lg][l16], tr[wave][4 * lg + 1][l16], tr[wave][4 * lg + 2][l16], tr[wave][4 * lg + 3][l16]);
+    *reinterpret_cast<float4*>(pb + (int64_t)(bc * (R >> 4) + br) * 256 + lane * 4) = tv;
+    return;
+  }
+  // part B: four consecutive floats per thread; tensors are 64-float aligned, so a quad lies inside a layer matrix or outside as a whole
+  const int64_t i = ((int64_t)(blockIdx.x - u.nblk_a) * 256 + threadIdx.x) * 4;
+  if (i >= u.n) return;
+  const int64_t rel = i - a.p0.in_w;
+  if (rel >= 0 && rel < (int64_t)a.L * a.pstride) {
+    const int64_t r = rel % a.pstride;
+    const int64_t o1 = a.p0.out_w - a.p0.in_w, o2 = a.p0.w1 - a.p0.in_w, o3 = a.p0.w2 - a.p0.in_w;
+    if (r < (int64_t)3 * d * d || (r >= o1 && r < o1 + (int64_t)d * d) || (r >= o2 && r < o2 + (int64_t)d * F) || (r >= o3 && r < o3 + (int64_t)d * F)) return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (i + e < u.n) {
+      u.prm[i + e] = seq_upd_elem(u, i + e, u.prm[i + e], u.g[i + e], k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
+      u.g[i + e] = 0.f;
+    }
+  }
+}
 #endif
 // acc0 / acc1 (rows l16 / 16 + l16) += A[:, k0 .. k0 + 16 nk) * B; ap = sA + l16 * lda + k0 + 4 lg (the A fragments are re-read from
 // acc0 / acc1 (rows l16 / 16 + l16 from ap's row) += A[:, k0 .. k0 + 16 nk) * B; the A fragments are re-read from LDS per tile
@@ -243,6 +321,30 @@ __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda
   const int l16 = lane & 15, lg = lane >> 4, ntile = N >> 4, nk = K >> 4;
   if (wave >= ntile) return;                             // wave-uniform
   const float* ap = sA + l16 * lda + 4 * lg;
+#ifdef GT_SEQ_PFALL
+  // experiment: the B fragments of ALL the wave's tiles requested up front (tile indices clamped: no branch around a load), so the
+  // stage has one memory round trip in front and exact vmcnt counts after it
+  if constexpr (FULL && HALF) {
+    SeqB<NK> ball[MAXT];
+    float4 biall[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wave + i * GT_SEQ_WAVES, tc = t < ntile ? t : ntile - 1;
+      seq_b_load<NK, true>(ball[i], Wp, nk, tc, 0, nk, lane);
+      biall[i] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * tc + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wave + i * GT_SEQ_WAVES;
+      if (t < ntile) {
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        seq_b_mma<NK, true, true>(acc0, acc1, ball[i], ap, lda, nk);
+        epi(16 * t, acc0, acc1, biall[i]);
+      }
+    }
+    return;
+  }
+#endif
   SeqB<NK> b[2];
   float4 bi[2];
   GT_SUBSTAMP(0);
@@ -312,6 +414,16 @@ __device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, co
   const float* ap = sA + l16 * lda + 4 * lg;
   f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
   SeqB<8> b[2];
+#ifdef GT_SEQ_PFALL
+  if (HALF && (ks1 - ks0 == 32 || ks1 - ks0 == 24)) {             // experiment: every chunk of the wave requested up front
+    SeqB<8> ball[4];
+    const int nch = (ks1 - ks0) >> 3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) seq_b_load<8, true>(ball[c], Wp, nks, t, ks0 + 8 * (c < nch ? c : nch - 1), 8, lane);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { if (c < nch) seq_b_mma<8, true, HALF>(acc0, acc1, ball[c], ap + 16 * (ks0 + 8 * c), lda, 8); }
+  } else
+#endif
   if (ks1 > ks0 && ((ks1 - ks0) & 7) == 0) {                       // whole chunks only (F and 3 d multiples of 128 per part): branch-free bodies
     seq_b_load<8, true>(b[0], Wp, nks, t, ks0, 8, lane);
     for (int c0 = ks0; c0 < ks1; c0 += 16) {                       // two chunks per trip: the buffer index stays compile-time
@@ -1064,6 +1176,15 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   const int b = SPLIT ? blockIdx.x >> 1 : blockIdx.x, rb = SPLIT ? 16 * (blockIdx.x & 1) : 0;
   const int d = EXACT ? DP : a.d, F = a.F;
   const size_t r0 = (size_t)b * 32;
+  if constexpr (SPLIT && DP == 128) {
+    // rider workgroups (gt_seq_wg.h): the blocks behind the sequence workgroups compute the weight gradients whose operands the
+    // earlier phases left in the workspace -- same kernel, same LDS footprint, hence always on a CU no sequence workgroup occupies
+    if (a.grd != nullptr && (int)blockIdx.x >= a.nseq) {
+      static_assert(sizeof(sU) >= GT_WG_LDS * sizeof(float) && sizeof(sP) >= 8 * 64 * sizeof(float), "rider LDS");
+      seq_wg_riders(a, a.phase, (int)blockIdx.x - a.nseq, (int)gridDim.x - a.nseq, sU, sP, tid);
+      return;
+    }
+  }
   const float* const zp = gt_zero_ptr();
   const float* prm = a.prm;
   float* ws = a.ws;

@@ -26,8 +26,23 @@ struct SeqArgs {
   // fused loss (gt_train_step): the launch that runs the output layer also computes the loss terms, d loss / d logits and the
   // step's statistics (loss_y == nullptr: off).  Same arithmetic as loss_kernel<true, true> (gt_loss_elem), one partial per workgroup
   const float* loss_y; float loss_penalty; float* loss_stats; float* loss_part; unsigned* loss_ticket;
+  // weight gradients as rider workgroups of the SPLIT backward phases + the tail kernel (gt_seq_wg.h); grd == nullptr: off
+  float* grd;                                                // gradient buffer (parameter layout)
+  int nseq;                                                  // sequence workgroups of the launch; blocks beyond them are riders
+  int wg_accumulate;                                         // 1: add into grd (gt_backward's accumulate), 0: overwrite (grd is zero or dead)
+  int ride_last_k;                                           // riders of the last phase cover the tokens [0, ride_last_k); the tail adds the rest
+  int tail_phase;                                            // tail kernel: L + 1 (debug launches: another phase's list alone)
+  int tail_ksplit;                                           // tail kernel: token chunks per tile (> 1: partial tiles meet in atomics)
+  int ln_nwg;                                                // tail kernel: partial rows per LayerNorm instance
+  gt_step_state* bump;                                       // tail kernel: advance step / opt_step (fused train step), or nullptr
 };
+// tiles of one weight-gradient problem in the rider decomposition (32 x 64 outputs per workgroup)
+static inline int gt_seq_wg_tiles(int rows, int cols) { return ((rows + 31) / 32) * ((cols + 63) / 64); }
 // launchers (one instantiation per d_model class / head-dim class / EXACT / SPLIT); hc = head-dim class 0 (< 16) / 16 / 32 / 64
 void gt_seq_launch_pack(const SeqArgs& a, unsigned nblocks, hipStream_t s);
+// optimizer update (algo 0 sgd / 1 adam, the arithmetic of gt_misc.h's kernels) + the next step's fragment-ordered weights
+void gt_seq_launch_update_pack(const SeqArgs& a, int algo, float* params, float* grads, float* m, float* v, int64_t n, const gt_step_state* st,
+                               int step_advanced, hipStream_t s);
 void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s);
 void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s);
+void gt_seq_launch_tail(const SeqArgs& a, unsigned nblocks, hipStream_t s);

@@ -50,6 +50,7 @@ class _Slot:
         self.graphs = {}               # step recipe -> captured hipGraph
         self.use_graph = None          # StepEngine.graph_for's decision for this slot (use_graph="auto")
         self.fwd_id = 0                # bumped by every call that overwrites the saved activations (see StepEngine.forward)
+        self.pack_epoch = -1           # StepEngine._pepoch at which this workspace's fragment-ordered weight copies were written
 
 
 class _LossSlot:
@@ -115,6 +116,11 @@ class StepEngine:
         self.overlap_allreduce = (env == "1") if env in ("0", "1") else (4 * self.total >= OVERLAP_MIN_BYTES)
         self.reduce_stats = True       # data-parallel: the logged 8-float stats are averaged over ranks (one tiny all-reduce)
         self._slots = {}
+        # Fused whole steps on the sequence-resident path end with an update that also writes the next step's fragment-ordered
+        # weights into the slot's workspace (GT_STEP_PACKS_CURRENT): valid while nothing else has written the parameters --
+        # _pepoch counts the engine's own writes, params._version torch's (load_state_dict, init, in-place ops on the Parameters)
+        self._pepoch, self._pver = 0, -1
+        self.fold_pack = os.environ.get("GT_PACK_FOLD", "1") != "0"
         self._loss_slots = {}
         self._predict_ws = {}          # chunk size -> (cfg, workspace, tgt scratch) of predict()
         self.B = int(batch_size) if batch_size else None
@@ -188,6 +194,13 @@ class StepEngine:
 
     # ---- the hot path ----------------------------------------------------------------------------
     def _enqueue_step(self, s, skip_update):
+        if skip_update == 0 and self.fold_pack and not self.graph_for(s):     # (a captured graph would replay the flag blindly)
+            if s.pack_epoch == self._pepoch and self._pver == self.params._version:
+                skip_update |= 4           # GT_STEP_PACKS_CURRENT
+            self._pepoch += 1
+            s.pack_epoch, self._pver = self._pepoch, self.params._version
+        else:
+            self._pepoch += 1              # parameters change (or may) without this slot's copies following
         self.lib.call("gt_train_step", ctypes.byref(s.cfg), self.algo, _ptr(self.params), _ptr(self.grads),
                       _ptr(self.m), _ptr(self.v), _ptr(self.pe), _ptr(s.x), _ptr(s.y),
                       ctypes.c_float(self.penalty), _ptr(s.hvo), _ptr(s.stats), _ptr(s.tgt), _ptr(s.ws),
@@ -196,6 +209,7 @@ class StepEngine:
     def enqueue_update(self, zero_grads=True):
         """Fused update over the flat buffers.  zero_grads=True also clears the consumed gradients (fused step path);
         the torch.optim-style front keeps them until zero_grad() like torch does."""
+        self._pepoch += 1
         self.lib.call("gt_optimizer_step", self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v),
                       ctypes.c_int64(self.total), _ptr(self.state), int(zero_grads), self.stream)
 
