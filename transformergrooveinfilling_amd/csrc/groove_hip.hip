@@ -441,7 +441,15 @@ static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, 
 #define GT_ROW_FUSE_MIN_M 8192
 #endif
 // (bf16 operands: always the tiled GEMM + row pass -- the row-owning tiles exist in fp32 only)
-static bool row_fused(const Ctx& x) { return !x.c.precision && (x.d <= GT_ROW_FUSE_MAX_D || x.M >= GT_ROW_FUSE_MIN_M); }
+// Round 3: at d_model 512 the row-owning tiles never pay -- 64 x 512 tiles on the one-deep 16x16x4 body run at 52 % (forward) / 65 %
+// (backward) of the MFMA peak where the 128 x 128 ring GEMM + an HBM-bound row pass make 80 % + 25 us (C4 bs512: 9.28 -> 8.91 ms;
+// d_model 256 at 8192 tokens keeps the fused tiles: 5.57 vs 5.66 ms)
+#ifndef GT_ROW_FUSE_BIG_MAX_D
+#define GT_ROW_FUSE_BIG_MAX_D 256
+#endif
+static bool row_fused(const Ctx& x) {
+  return !x.c.precision && (x.d <= GT_ROW_FUSE_MAX_D || (x.M >= GT_ROW_FUSE_MIN_M && x.d <= GT_ROW_FUSE_BIG_MAX_D));
+}
 static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float* xhat, const float* rstd, int64_t gamma_off, float* dz,
                    float* dzm, int site);
 static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, int K, const float* res, const float* xhat,

@@ -780,6 +780,12 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
 #ifndef GT_WGRAD32_SPLIT
 #define GT_WGRAD32_SPLIT 1024   /* A/B on C4 bs512: 64 / 128 / 256 / 1024 -> 10.6 / 10.9 / 10.5 / 9.76 ms: many short chunks balance the grouped launch */
 #endif
+#ifndef GT_WGRAD32_CHUNK
+#define GT_WGRAD32_CHUNK 2048
+#endif
+#ifndef GT_WGRAD32_UNIFORM_MIN
+#define GT_WGRAD32_UNIFORM_MIN 16384
+#endif
 struct WgradBatch {
   GemmGroup grp[4];            // [0]: 32x32-tile problems, [1]: 64x64, [2]: 128x128, [3]: 128x128 on the big-tile body (gt_gemm32.h)
   double flops[4], bytes[4];
@@ -820,7 +826,13 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   if (wb.grp[cls].n == GT_GROUP_MAX) wgrad_flush_one(wb, cls, s);
   // (big-tile body: fewer, longer token chunks -- every chunk ends in 64 KB of fp32 atomics per tile, and the chip adds
   //  ~1.3 TB/s of atomic bytes at most; a grouped launch has 16 problems' worth of workgroups anyway)
-  const int splitk = wgrad_split(g, cls == 3 ? GT_WGRAD32_SPLIT : cls ? GT_WGRAD_SPLIT_BIG : GT_WGRAD_SPLIT_SMALL, tile);
+  // From GT_WGRAD32_UNIFORM_MIN tokens up every big-tile problem is cut into the SAME token-chunk length (GT_WGRAD32_CHUNK): all
+  // workgroups of the grouped launch are then equal (no straggling problem) and every gradient tile takes 8 rounds of fp32 atomics
+  // instead of 22-32 -- at 16384 tokens the per-problem target count had the d_model-512 step add ~1 GB of atomic bytes against
+  // the chip's ~1.3 TB/s (C4 bs512: 9.79 -> 9.28 ms; at 2048 / 8192 tokens the shorter uneven chunks stay ahead: A/B in DESIGN 3a)
+  int splitk;
+  if (cls == 3 && !gt_deterministic() && g.K >= GT_WGRAD32_UNIFORM_MIN) { g.k_chunk = GT_WGRAD32_CHUNK; splitk = (g.K + g.k_chunk - 1) / g.k_chunk; }
+  else splitk = wgrad_split(g, cls == 3 ? GT_WGRAD32_SPLIT : cls ? GT_WGRAD_SPLIT_BIG : GT_WGRAD_SPLIT_SMALL, tile);
   GemmGroup& G = wb.grp[cls];
   const int i = G.n++;
   G.p[i] = g;
@@ -860,7 +872,7 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
     else        gemm_launch_cfg<2, 2, 1, 1, 64, AKM, BKM, EPI>(g, splitk, s);
     return;
   }
-  if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ)) {
+  if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP)) {
     const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     if (g.bf16 && b128 >= GT_T128_BIG_MIN && gemm32_ok(g, EPI, BKM)) { gemm32_launch<BKM, EPI>(g, s); return; }
   }
@@ -875,7 +887,7 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   }
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-  if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ)) {
+  if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP)) {
     if (t128 >= GT_T128_BIG_MIN && gemm32_ok(g, EPI, BKM)) { gemm32_launch<BKM, EPI>(g, s); return; }
   }
   // 128x128 tiles once they still fill the chip twice over: a 64x64x64 slab needs ~38 GB/s of L2->LDS staging per

@@ -36,7 +36,8 @@ static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm) {
   if (g.M % 128 || g.N % 128 || g.K % 64 || g.K < 64) return false;
   if ((g.lda & 3) || (g.ldb & 3) || (g.ldc & 3) || !al16(g.A) || !al16(g.B) || !al16(g.C)) return false;
   if (epi == EPI_STORE || epi == EPI_RELU_DROP) { if (g.bias && !al16(g.bias)) return false; }
-  if (epi == EPI_MASK_NZ && ((g.ldres & 3) || !al16(g.res))) return false;
+  if ((epi == EPI_MASK_NZ || epi == EPI_ADD_RELUMASK_DROP) && ((g.ldres & 3) || !al16(g.res))) return false;
+  if (epi == EPI_ADD_RELUMASK_DROP && ((g.N & 3) || !al16(g.aux_in))) return false;
   (void)bkm;
   return true;
 }
@@ -226,7 +227,7 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
   const uint32_t dkey = gt_drop_key(g.drop);
 #pragma unroll
   for (int tb = 0; tb < 2; ++tb) {
-    f32x4 bia[4], rin[2][4];
+    f32x4 bia[4], rin[2][4], rin2[2][4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
@@ -237,7 +238,8 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
         const int row = m0 + wm * 64 + ta * 32 + r32;
         rin[ta][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI == EPI_STORE && g.accumulate) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.C + (size_t)row * g.ldc + col);
-        if (EPI == EPI_MASK_NZ) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + col);
+        if (EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + col);
+        if (EPI == EPI_ADD_RELUMASK_DROP) rin2[ta][q4] = *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.N + col);
       }
     }
 #pragma unroll
@@ -253,6 +255,10 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
           if (EPI == EPI_STORE) v = v + bia[q4][r] + rin[ta][q4][r];
           else if (EPI == EPI_RELU_DROP) v = fmaxf(v + bia[q4][r], 0.f) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
           else if (EPI == EPI_MASK_NZ) v = (rin[ta][q4][r] != 0.f) ? v * g.mask_scale : 0.f;
+          else if (EPI == EPI_ADD_RELUMASK_DROP) {
+            v = (v + rin[ta][q4][r]) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
+            v = (rin2[ta][q4][r] > 0.f) ? v : 0.f;
+          }
           o[r] = v;
         }
         *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = o;
