@@ -31,6 +31,7 @@ WORK = dict(d_model=128, n_heads=4, dim_feedforward=512, num_encoder_layers=3, n
 BATCH, LR, PENALTY = 64, 0.07, 0.38
 FP32_MATRIX_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PROFILE_STEPS = 20
+BLOCKS = 5                                                 # back-to-back timed blocks of --steps steps each: the median one is reported
 
 
 def f_train_per_seq(w, T=32):
@@ -95,16 +96,16 @@ def cpu_baseline(budget_s=15.0):
             best = (dt, th)
         if dt > 4 * best[0]:
             break
-    cores = best[1]
-    torch.set_num_threads(cores)
+    threads = best[1]
+    torch.set_num_threads(threads)
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         tg.train_step(m, opt, x, y, PENALTY)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": BATCH * n / dt, "unit": "sequences/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps of the same workload (bs %d) in %.1f s, torch %s CPU fp32, %d threads (fastest of a 4..%d sweep)"
-                      % (n, BATCH, dt, torch.__version__, cores, ncpu)}
+    return {"value": BATCH * n / dt, "unit": "sequences/s", "cores": ncpu, "threads": threads, "kind": "port",
+            "sample": "%d train steps of the same workload (bs %d) in %.1f s, torch %s CPU fp32, %d threads (fastest of a 4..%d sweep) on a %d-core host"
+                      % (n, BATCH, dt, torch.__version__, threads, ncpu, ncpu)}
 
 
 def parse_args(argv=None):
@@ -218,19 +219,55 @@ def run_rank(args):
         if not emu:
             torch.cuda.synchronize()
 
+    def timed_block(step, steps):
+        """EXACTLY `steps` steps between two barrier + device-synchronize brackets: wall clock (max over ranks) and, beside it,
+        the HIP-event time of the same region on the stream the steps are launched on (hipEvent + wall cross-check)"""
+        sync()
+        if not emu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if not emu:
+            e1.record()
+        sync()
+        dt = time.perf_counter() - t0
+        ev = e0.elapsed_time(e1) * 1e-3 if not emu else dt
+        if world > 1:
+            t = torch.tensor([dt, ev], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, ev = float(t[0].item()), float(t[1].item())
+        return dt, ev
+
     for _ in range(args.warmup):
         eng.train_step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.train_step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    blocks = [timed_block(eng.train_step, args.steps) for _ in range(1 if emu else BLOCKS)]
+    walls = sorted(b[0] for b in blocks)
+    dt = walls[len(walls) // 2]                                          # the median block
+    ev = sorted(b[1] for b in blocks)[len(blocks) // 2]
     loss = float(eng.stats[0].item())
+
+    # the same steps with the batch coming from pinned host memory every step (SURVEY 8d: "report both with / without H2D")
+    h2d = None
+    if not emu:
+        xh, yh = torch.from_numpy(x).pin_memory(), torch.from_numpy(y).pin_memory()
+        for _ in range(min(args.warmup, 10)):
+            eng.train_step(xh, yh)
+        h2d = sorted(timed_block(lambda: eng.train_step(xh, yh), args.steps)[0] for _ in range(3))[1]
+        eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))
+    # data-parallel step sequence vs the fused single-process step on the same GPU: what the split into
+    # fwd+bwd / all-reduce / update costs besides the communication itself
+    fused_dt = None
+    if (world > 1 or args.force_dp) and not emu:
+        e1 = StepEngine(batch_size=batch, optimizer="sgd", learning_rate=LR, hit_loss_penalty=PENALTY, seed=1234 | (rank << 32), device=dev,
+                        world_size=1, use_graph=False if args.no_graph else "auto", **work)
+        e1.load_named(layout.init_params(work, seed=0))
+        e1.x.copy_(torch.from_numpy(x)); e1.y.copy_(torch.from_numpy(y))
+        for _ in range(args.warmup):
+            e1.train_step()
+        fused_dt = sorted(timed_block(e1.train_step, args.steps)[0] for _ in range(3))[1]
+        del e1
 
     out = None
     if rank == 0:
@@ -239,6 +276,9 @@ def run_rank(args):
         out = {
             "metric": "HVO sequences/sec (32-step, d_model=128) per train step", "value": seq_s, "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            # BLOCKS back-to-back blocks of exactly `steps` steps, each bracketed by barrier + synchronize; value = the median block
+            "timing": {"blocks": len(walls), "ms_per_step_min": 1e3 * walls[0] / args.steps, "ms_per_step_max": 1e3 * walls[-1] / args.steps,
+                       "hip_event_ms_per_step": 1e3 * ev / args.steps},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: InfillingClosedHH_training.yaml + overrides d_model=128/4 heads/3 layers, "
                                    "dim_feedforward=512, bs=64 per GPU, dropout=0.24, SGD lr=0.07, hit_loss_penalty=0.38, S=16, encoder-only",
@@ -247,12 +287,19 @@ def run_rank(args):
             "distributed": {"world": world, "backend": dist.get_backend() if dist.is_initialized() else None,
                             "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                             "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if not emu else None,
-                            "overlap_allreduce": bool(eng.overlap_allreduce) if world > 1 else None,
+                            "overlap_allreduce": bool(eng.overlap_allreduce) if (world > 1 or args.force_dp) else None,
+                            "grad_buckets": len(eng.lib.grad_buckets(eng.slot(batch).cfg)),
                             "grad_bytes": 4 * eng.total},
             "step_roofline": {"f_train_mflop_per_seq": ftrain / 1e6, "achieved_tflops": seq_s * ftrain / 1e12,
                               "frac_of_fp32_mfma_peak": seq_s * ftrain / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world)},
             "final_loss": loss,
         }
+        if h2d is not None:       # batch copied from pinned host memory each step (never `value`: inputs resident in HBM is the metric)
+            out["value_h2d_inclusive"] = world * batch * args.steps / h2d
+            out["ms_per_step_h2d_inclusive"] = 1e3 * h2d / args.steps
+        if fused_dt is not None:
+            out["distributed"]["fused_single_process_ms_per_step"] = 1e3 * fused_dt / args.steps
+            out["distributed"]["dp_overhead_us"] = 1e6 * (dt - fused_dt) / args.steps
         if emu:
             out["config"]["workload"] = "HOST-EMULATOR TEST RUN (not a measurement): %s bs %d" % (json.dumps(work, sort_keys=True), batch)
         # dominant kernel, measured live: eager pass with HIP events around every launch on the launch stream

@@ -126,10 +126,18 @@ int gt_backward(const gt_config* cfg, const float* params, float* grads, const f
 int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n,
                       gt_step_state* state, int zero_grads, gt_stream_t stream);
 
+/* gt_optimizer_step for the data-parallel step sequence (gt_train_step(skip_update = 1..3), all-reduce, update): with the
+ * configuration and its workspace at hand the update on the sequence-resident path also writes the next step's fragment-ordered
+ * weight copies (see GT_STEP_PACKS_CURRENT below); on other paths, or with zero_grads == 0, identical to gt_optimizer_step. */
+int gt_optimizer_step_ws(const gt_config* cfg, int algo, float* params, float* grads, float* m, float* v, float* ws,
+                         gt_step_state* state, int zero_grads, gt_stream_t stream);
+
 /* Gradient buckets for overlapping the data-parallel all-reduce with backward (no reference counterpart: the
  * reference is single-device).  Writes up to two [offset, offset+count) ranges of the flat gradient buffer in the order
  * backward completes them and returns their number: 2 when the model splits (encoder-decoder: decoder half first;
- * encoder-only with >= 2 layers: upper half of the layers first), else 1 (the whole buffer). */
+ * encoder-only with >= 2 layers: upper half of the layers first; sequence-resident path: only while the weight gradients ride in
+ * the SPLIT backward phases -- gt_set_seq_ride -- where everything from encoder layer L - p + 1 on is final after phase p), else 1
+ * (the whole buffer). */
 int gt_grad_buckets(const gt_config* cfg, int64_t* offsets, int64_t* counts);
 
 /* One whole train step of train_loop's batch body (ref:train.py:195-215): [shift y for the decoder]

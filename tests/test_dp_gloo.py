@@ -77,7 +77,20 @@ def test_dp2_matches_single_process(tmp_path):
         assert np.abs(a[k] - ref[k]).max() < 1e-6, k                         # == one process on the whole batch
 
 
-def _engine_worker(rank, world, port, out, overlap):
+ENGINE_CASES = {
+    # name: (model dims, sequences in the global batch, gradient buckets the overlapped step must use)
+    "seq_d32": (dict(d_model=32, n_heads=4, dim_feedforward=16, num_encoder_layers=2), 4, 1),      # sequence-resident, one launch per direction: one bucket
+    "op_d48": (dict(d_model=48, n_heads=4, dim_feedforward=24, num_encoder_layers=2), 4, 2),       # outside the sequence kernels: one kernel per op, bucketed backward
+    "ride_d128": (dict(d_model=128, n_heads=4, dim_feedforward=64, num_encoder_layers=3), 4, 2),   # SPLIT phases with rider weight gradients: cut after phase 2
+}
+
+
+def _engine_dims(case):
+    dims, B, nb = ENGINE_CASES[case]
+    return dict(dims, num_decoder_layers=0, dropout=0.0, embedding_size_src=16), B, nb
+
+
+def _engine_worker(rank, world, port, out, overlap, case):
     """the PRODUCT's data-parallel step sequence (StepEngine.train_step: fwd+loss+bwd, all-reduce(s) of the flat gradient
     buffer, fused update averaging by grad_scale) on host memory: explicit emulator library + gloo"""
     sys.path.insert(0, ROOT)
@@ -88,11 +101,12 @@ def _engine_worker(rank, world, port, out, overlap):
     from transformergrooveinfilling_amd import layout, parallel
     from transformergrooveinfilling_amd.engine import StepEngine
     parallel.init_distributed("gloo")
-    dims = dict(d_model=32, n_heads=4, dim_feedforward=16, num_encoder_layers=2, num_decoder_layers=0, dropout=0.0, embedding_size_src=16)
-    B = 4
+    dims, B, nb = _engine_dims(case)
     eng = StepEngine(batch_size=B // world, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3 | (rank << 32),
                      device="cpu", world_size=world, lib=emu_lib(), **dims)
     assert eng.overlap_allreduce == bool(overlap)
+    if overlap:                                   # the bucketed branch of StepEngine.train_step must really be the one that runs
+        assert len(eng.lib.grad_buckets(eng.slot(B // world).cfg)) == nb
     eng.load_named(layout.init_params(dims, seed=5))
     x, y = layout.synthetic_batch(B, 16, seed=9)
     sl = slice(rank * (B // world), (rank + 1) * (B // world))
@@ -107,20 +121,20 @@ def _engine_worker(rank, world, port, out, overlap):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("overlap", [0, 1])
-def test_engine_dp2_matches_single_process(tmp_path, overlap):
+@pytest.mark.parametrize("case,overlap", [("seq_d32", 0), ("seq_d32", 1), ("op_d48", 1), ("op_d48", 0), ("ride_d128", 1)])
+def test_engine_dp2_matches_single_process(tmp_path, case, overlap):
     world, port = 2, _free_port()
     out = str(tmp_path / "eng%d.pt")
-    mp.start_processes(_engine_worker, args=(world, port, out, overlap), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_engine_worker, args=(world, port, out, overlap, case), nprocs=world, join=True, start_method="spawn")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from harness import emu_lib
     from transformergrooveinfilling_amd import layout
     from transformergrooveinfilling_amd.engine import StepEngine
     a, b = torch.load(out % 0), torch.load(out % 1)
-    dims = dict(d_model=32, n_heads=4, dim_feedforward=16, num_encoder_layers=2, num_decoder_layers=0, dropout=0.0, embedding_size_src=16)
-    eng = StepEngine(batch_size=4, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3, device="cpu", lib=emu_lib(), **dims)
+    dims, B, _ = _engine_dims(case)
+    eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3, device="cpu", lib=emu_lib(), **dims)
     eng.load_named(layout.init_params(dims, seed=5))
-    x, y = layout.synthetic_batch(4, 16, seed=9)
+    x, y = layout.synthetic_batch(B, 16, seed=9)
     for _ in range(2):
         eng.train_step(torch.from_numpy(x), torch.from_numpy(y))
     assert torch.equal(a["params"], b["params"])                              # replicas stay identical

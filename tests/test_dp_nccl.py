@@ -34,6 +34,8 @@ def _worker(rank, world, port, out, overlap):
     eng = StepEngine(batch_size=B // world, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3 | (rank << 32),
                      device="cuda:%d" % local, world_size=world, **DIMS)
     eng.load_named(layout.init_params(DIMS, seed=5))
+    if overlap:        # sequence-resident SPLIT phases with rider weight gradients: the bucketed branch of StepEngine.train_step runs
+        assert len(eng.lib.grad_buckets(eng.slot(B // world).cfg)) == 2
     x, y = layout.synthetic_batch(B, 16, seed=9)
     sl = slice(rank * (B // world), (rank + 1) * (B // world))
     for _ in range(3):

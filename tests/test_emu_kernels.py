@@ -163,6 +163,10 @@ def test_sequence_resident_train_step_and_predict():
     parity.check_train_step("emu", cfg_dict(128, 8, 48, 1), 3, 0.1, seq="whole")
     parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.0, algo=1)               # the fused update + pack kernel, Adam branch
     parity.check_bucketed_backward("emu", cfg_dict(32, 4, 16, 2), 2, 0.25, 1, exact=True)      # one bucket: the backward is one launch
+    # riders: after backward phase p everything from layer L - p + 1 on is final -> two buckets, bit-exact (one owner per gradient tile)
+    parity.check_bucketed_backward("emu", cfg_dict(128, 4, 64, 3), 2, 0.2, 2, exact=True, seq="split")
+    parity.check_bucketed_backward("emu", cfg_dict(128, 4, 64, 2), 1, 0.0, 2, exact=True, seq="split")
+    parity.check_bucketed_backward("emu", cfg_dict(128, 4, 64, 2), 2, 0.1, 1, exact=False, seq="split-noride")
     parity.check_predict("emu", cfg_dict(32, 4, 16, 2), 2, True)
 
 

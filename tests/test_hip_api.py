@@ -159,6 +159,37 @@ def test_train_py_cli_runs_a_reference_yaml(tmp_path):
     assert sum(p.numel() for p in model.parameters()) == 34043         # BASELINE.md C1 parameter count
 
 
+def test_train_py_cli_evaluation_leg(tmp_path):
+    """ref:train.py:219-250 / ref:evaluator.py:516-525: on the epochs of the save schedule every enabled set is predicted and scored per
+    voice on the device (metrics.evaluate), the flags select the sets, the scalars are dumped; train_loop also gets the test / validation
+    tensors for its end-of-epoch losses."""
+    import json
+    import train as train_cli
+    from transformergrooveinfilling_amd import metrics
+    cfg = dict(experiment="InfillingClosedHH_testing", batch_size=32, d_model=32, dim_feedforward=16, dropout=0.18, optimizer_algorithm="sgd",
+               learning_rate=0.094, n_heads=4, num_encoder_decoder_layers=2, epochs=2, encoder_only=1, hit_loss_penalty=0.47, load_model=None)
+    f = tmp_path / "cfg.yaml"
+    f.write_text(yaml.safe_dump(cfg))
+    xe, ye = train_cli.synthetic_tensors(96, 16, 77)
+    npz = tmp_path / "eval.npz"
+    np.savez(npz, test_inputs=xe.numpy(), test_gt=ye.numpy(), validation_inputs=xe[:40].numpy(), validation_gt=ye[:40].numpy())
+    model = train_cli.main(["--config", str(f), "--synthetic", "128", "--wandb", "False", "--save-dir", str(tmp_path), "--eval-npz", str(npz),
+                            "--eval_train", "False", "--eval_test", "True", "--eval_validation", "True", "--eval-size", "64"])
+    recs = model.eval_log
+    assert [r["epoch"] for r in recs] == [0, 0, 1, 1]                                       # two enabled sets x two epochs (both on the schedule)
+    assert all(any(k.startswith("Test_Set/") for k in r) or any(k.startswith("Validation_Set/") for k in r) for r in recs)
+    assert not any(k.startswith("Train_Set/") for r in recs for k in r)                     # --eval_train False is honoured
+    last = [r for r in recs if r["epoch"] == 1 and "Test_Set/Hits_Accuracy_Overall" in r][0]
+    want = metrics.evaluate(model, xe, ye)                                                  # the same numbers, recomputed on the final weights
+    assert abs(last["Test_Set/Hits_Accuracy_Overall"] - want["Hits_Accuracy_Overall"]) < 1e-6
+    assert abs(last["Test_Set/Velocity_MSE_KICK"] - want["Velocity_MSE_KICK"]) < 1e-6
+    dumped = json.load(open(tmp_path / "eval_Test_Set_Epoch_1.json"))
+    assert dumped["epoch"] == 1 and abs(dumped["Offset_MSE_Overall"] - want["Offset_MSE_Overall"]) < 1e-6
+    # against numpy on the host, from the predictions themselves
+    pred = model.predict_hvo(xe).cpu().numpy()
+    assert abs(want["Hits_Accuracy_Overall"] - float((pred[..., :9] == ye.numpy()[..., :9]).mean())) < 1e-6
+
+
 def test_engine_bucketed_data_parallel_sequence_matches_fused_step():
     """StepEngine's data-parallel sequence (graph A, async all-reduce of bucket 0 under graph B, all-reduce of bucket 1,
     update) on a 1-rank process group must train exactly like the fused single-GPU step."""

@@ -41,6 +41,38 @@ def test_reference_yaml_keys_load_unchanged(tmp_path, name):
     assert p["training"] == {"learning_rate": hp["learning_rate"], "batch_size": hp["batch_size"], "hit_loss_penalty": hp["hit_loss_penalty"]}
 
 
+REF_CONFIGS = "/root/reference/configs"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="the reference checkout is only present in the build container")
+def test_the_reference_s_own_yaml_files_load_in_place():
+    """Every *_training.yaml of the reference, read where it lies (never copied): the CLI takes it unchanged, the model parameters
+    follow ref:train.py:115-143, and the retyped table above agrees with the real files."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REF_CONFIGS, "*_training.yaml")))
+    assert len(files) >= 4
+    seen = set()
+    for f in files:
+        args = train_cli.build_parser().parse_args(["--config", f])
+        hp = train_cli.load_hyperparameters(args)
+        raw = yaml.safe_load(open(f))
+        for k in raw:
+            assert hp[k] == raw[k], (f, k)
+        p = train_cli.model_params(hp, "cuda")
+        m = p["model"]
+        assert m["d_model"] == raw["d_model"] and m["n_heads"] == raw["n_heads"] and m["dim_feedforward"] == raw["dim_feedforward"]
+        assert m["num_encoder_layers"] == raw["num_encoder_decoder_layers"]
+        assert m["num_decoder_layers"] == (0 if raw["encoder_only"] else raw["num_encoder_decoder_layers"])
+        assert m["embedding_size_src"] == (27 if raw["experiment"] == "InfillingClosedHH_Symbolic" else 16)     # ref:train.py:129-131
+        assert m["d_model"] % m["n_heads"] == 0
+        name = os.path.splitext(os.path.basename(f))[0]
+        if name in REF_YAMLS:
+            seen.add(name)
+            for k, v in REF_YAMLS[name].items():
+                assert raw.get(k) == v, (name, k, raw.get(k), v)
+    assert seen >= {"InfillingClosedHH_training", "InfillingKicksAndSnares_training", "InfillingClosedHH_Symbolic_training"}
+
+
 def test_cli_without_config_and_overrides(tmp_path):
     args = train_cli.build_parser().parse_args(["--experiment", "InfillingRandom", "--encoder_only", "0", "--d_model", "128",
                                                 "--testing", "1", "--override", "n_heads=4"])

@@ -33,13 +33,15 @@ def build_parser():
     p.add_argument("--testing", default=False, help="testing mode (1 epoch)")
     p.add_argument("--wandb", default=True, help="log to wandb (when installed)")
     p.add_argument("--only_final_eval", default=False)
-    # which sets the reference's GrooveEvaluator scores and whether it dumps them (ref:train.py:18-24).  The evaluator is
-    # host-side and outside the hot path: the flags are accepted so that sweep YAMLs / command lines written
-    # for the reference run unchanged; the device-side per-voice metrics it consumes come from `transformergrooveinfilling_amd.metrics`.
+    # which sets are scored per epoch and whether the scores are dumped (ref:train.py:18-24, 219-250).  The reference's
+    # GrooveEvaluator (host-side plots / audio, un-vendored) is outside the hot path; its SCALAR leg -- predict the set,
+    # per-voice hit accuracy / velocity / offset errors (ref:evaluator.py:516-525) -- runs here on the device
+    # (transformergrooveinfilling_amd.metrics.evaluate: chunked predict + gt_voice_metrics, ONE 30-float D2H per set) on the epochs of
+    # the reference's save schedule, logged under the reference's set identifiers (Train_Set / Test_Set / Validation_Set).
     p.add_argument("--eval_train", default=True, help="evaluator train set")
     p.add_argument("--eval_test", default=False, help="evaluator test set")
     p.add_argument("--eval_validation", default=True, help="evaluator validation set")
-    p.add_argument("--dump_eval", default=True, help="dump evaluator file")
+    p.add_argument("--dump_eval", default=True, help="dump the per-epoch evaluation scalars (eval_<Set>_Epoch_<n>.json beside the checkpoints)")
     p.add_argument("--load_model", default=None)
     p.add_argument("--notes", default=None)
     p.add_argument("--tags", default=None)
@@ -59,6 +61,11 @@ def build_parser():
     # build-side additions
     p.add_argument("--data-npz", default=None, help="npz with inputs (N,32,S) and outputs (N,32,27)")
     p.add_argument("--synthetic", default=0, type=int, help="train on N synthetic sequences")
+    p.add_argument("--eval-npz", default=None,
+                   help="npz with the evaluation subsets: train_inputs/train_gt, test_inputs/test_gt, validation_inputs/validation_gt "
+                        "((n,32,S) / (n,32,27): the evaluators' processed_inputs / processed_gt, ref:evaluator.py:509-511); missing sets are "
+                        "skipped.  With --synthetic and no file: three seeded synthetic subsets")
+    p.add_argument("--eval-size", default=1024, type=int, help="sequences per synthetic / train-derived evaluation subset")
     p.add_argument("--host-loader", action="store_true",
                    help="feed batches through torch's DataLoader from host memory (the reference's way) instead of keeping the "
                         "dataset in HBM and gathering batches on the device")
@@ -135,12 +142,42 @@ def load_data(args, hp, src_dim):
     return ds.processed_inputs, ds.processed_outputs
 
 
+def _flag(v):
+    """the reference's boolean flags arrive as strings from sweep command lines (`--eval_test False`)"""
+    return bool(v) and str(v).lower() not in ("false", "0", "no", "none")
+
+
+def load_eval_sets(args, x, y, src_dim):
+    """{"Train_Set" | "Test_Set" | "Validation_Set": (inputs, gt)} for the sets the flags enable (ref:train.py:160-174: three
+    pickled evaluators, each holding processed_inputs / processed_gt of a subset).  Sources: --eval-npz; else, with --synthetic,
+    seeded synthetic subsets; the train subset defaults to the head of the training tensors."""
+    import numpy as np
+    import torch
+    want = {"Train_Set": _flag(args.eval_train), "Test_Set": _flag(args.eval_test), "Validation_Set": _flag(args.eval_validation)}
+    key = {"Train_Set": "train", "Test_Set": "test", "Validation_Set": "validation"}
+    sets = {}
+    z = np.load(args.eval_npz) if args.eval_npz else None
+    for i, (name, on) in enumerate(want.items()):
+        if not on:
+            continue
+        k = key[name]
+        if z is not None and k + "_inputs" in z.files:
+            sets[name] = (torch.from_numpy(z[k + "_inputs"]).float(), torch.from_numpy(z[k + "_gt"]).float())
+        elif name == "Train_Set":
+            n = min(args.eval_size, len(x))
+            sets[name] = (x[:n], y[:n])
+        elif args.synthetic:
+            sets[name] = synthetic_tensors(args.eval_size, src_dim, args.seed + 100 + i)
+    return sets
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     hp = load_hyperparameters(args)
     import torch
     from torch.utils.data import DataLoader, TensorDataset
     from transformergrooveinfilling_amd import parallel
+    from transformergrooveinfilling_amd import metrics
     from transformergrooveinfilling_amd.training import calculate_loss, initialize_model, save_schedule, train_loop
     rank, local, world = parallel.init_distributed()
     if rank == 0:
@@ -160,6 +197,7 @@ def main(argv=None):
     params["model"]["precision"] = hp.get("precision", args.precision)
     params["seed"] = args.seed                # dropout stream of this run (the data-parallel rank is mixed in by the model)
     model, optimizer, initial_epoch = initialize_model(params)
+    model.eval_log = []                       # the evaluation leg's records (also what the tests read)
     if args.deterministic:
         model.engine.lib.cdll.gt_set_deterministic(1)
     parallel.broadcast_parameters(model.engine.params)
@@ -170,6 +208,9 @@ def main(argv=None):
             return self.tensors[0][i], self.tensors[1][i], i
 
     ds = _Triples(x, y)
+    eval_sets = load_eval_sets(args, x, y, params["model"]["embedding_size_src"]) if rank == 0 else {}
+    test = eval_sets.get("Test_Set", (None, None))
+    val = eval_sets.get("Validation_Set", (None, None))
     if not args.host_loader:
         # the whole dataset in HBM, batches gathered on the device
         sampler = loader = parallel.DeviceBatchLoader(x, y, hp["batch_size"], device, rank, world, seed=args.seed)
@@ -189,6 +230,8 @@ def main(argv=None):
         t0 = time.perf_counter()
         m = train_loop(dataloader=loader, groove_transformer=model, encoder_only=hp["encoder_only"], opt=optimizer, epoch=ep,
                        loss_fn=calculate_loss, bce_fn=bce, mse_fn=mse, device=device, hit_loss_penalty=hp["hit_loss_penalty"],
+                       # test / validation LOSS after the epoch's batches, as the reference's train_loop arguments (ref:train.py:204-212)
+                       test_inputs=test[0], test_gt=test[1], validation_inputs=val[0], validation_gt=val[1],
                        save=(rank == 0 and (ep in part or ep in full)), save_dir=save_dir,
                        run_id=(wb.run.id if wb else "local"))
         torch.cuda.synchronize()
@@ -196,6 +239,21 @@ def main(argv=None):
             n = min(len(loader) * hp["batch_size"], len(ds) // world) * world
             print("Epoch %d: loss %.5f  hit_acc %.4f  (%.0f sequences/s)" % (ep, m["train/loss"], m["train/hit_accuracy"],
                                                                            n / (time.perf_counter() - t0)))
+            # the evaluation leg (ref:train.py:219-250 -> log_eval, ref:evaluator.py:516-525) on the epochs of the save schedule:
+            # predict each enabled set on the device, per-voice metrics on the device, one 30-float copy per set
+            if ep in part or ep in full:
+                for name, (xin, gt) in eval_sets.items():
+                    sc = metrics.evaluate(model, xin, gt)
+                    rec = {"%s/%s" % (name, k): v for k, v in sc.items()}
+                    model.eval_log.append(dict(rec, epoch=ep))
+                    print("  %s: hits accuracy %.4f  velocity MSE %.5f  offset MSE %.5f" %
+                          (name, sc["Hits_Accuracy_Overall"], sc["Velocity_MSE_Overall"], sc["Offset_MSE_Overall"]))
+                    if wb:
+                        wb.log(dict(rec, epoch=ep), commit=False)
+                    if _flag(args.dump_eval):
+                        import json
+                        with open(os.path.join(save_dir, "eval_%s_Epoch_%d.json" % (name, ep)), "w") as f:
+                            json.dump(dict(sc, epoch=ep), f)
             if wb:
                 wb.log({"epoch": ep}, commit=True)
     if wb:

@@ -58,6 +58,8 @@ _SIGS = {
     "gt_voice_metrics": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     # xs, ys, idx, n_seq, batch, src_dim, x, y, stream
     "gt_gather_batch": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp]),
+    # cfg, algo, params, grads, m, v, ws, state, zero_grads, stream
+    "gt_optimizer_step_ws": (ctypes.c_int, [_cfgp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
     "gt_grad_buckets": (ctypes.c_int, [_cfgp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "gt_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_overlap": (ctypes.c_int, [ctypes.c_int]),

@@ -933,13 +933,23 @@ static void input_layer_bwd(const Ctx& x, const LayerP& first, const Tmp& t, con
 // "everything from tensor X to the end" is final early: X = the decoder input layer of an encoder-decoder model, else
 // encoder layer L/2.  split_layer: first encoder layer of the upper bucket (enc-dec: L, i.e. no encoder layer).
 struct GradSplit { int nb; int split_layer; int64_t off[2], cnt[2]; };
+static bool seq_ride(const gt_config& c);
 static GradSplit grad_split(const gt_config& c, const PLayout& P) {
   GradSplit g;
   g.nb = 1; g.split_layer = 0; g.off[0] = 0; g.cnt[0] = P.total; g.off[1] = g.cnt[1] = 0;
   int64_t cut = 0;
   if (c.n_dec_layers > 0) { cut = P.din_w; g.split_layer = c.n_enc_layers; }
   else if (c.n_enc_layers >= 2) { g.split_layer = c.n_enc_layers / 2; cut = P.enc[g.split_layer].sa.in_w; }
-  if (cut > 0 && !use_seq(c)) {
+  // sequence-resident path: one bucket -- unless the weight gradients ride in the backward phases (gt_seq_wg.h): after phase p < L
+  // everything from encoder layer L - p + 1 on is final; the cut is after phase min((L + 2) / 2, L - 1)
+  if (use_seq(c)) {
+    const int L = c.n_enc_layers;
+    int pcut = (L + 2) / 2;                       // (the LAST phase's tiles are finished by the tail launch: the cut lies before it)
+    if (pcut > L - 1) pcut = L - 1;
+    if (pcut >= 1 && seq_ride(c)) { g.split_layer = L - pcut + 1; cut = g.split_layer < L ? P.enc[g.split_layer].sa.in_w : P.encn_w; }
+    else cut = 0;
+  }
+  if (cut > 0) {
     g.nb = 2; g.off[0] = cut; g.cnt[0] = P.total - cut; g.off[1] = 0; g.cnt[1] = cut;
   }
   return g;
@@ -1004,6 +1014,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
       gt_launch(heads_bwd_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, d_hvo, hvo, ws + W.dlogits, M * GT_TGT);
     }
     // LayerNorm jobs in the order the kernel fills their partial blocks (one [2][d] row per sequence)
+    const GradSplit split_ = split;                              // (the bucket cut; `split` below is the two-workgroups-per-sequence mode)
     const bool split = seq_split(*cfg);
     const int nwg = split ? 2 * cfg->batch : cfg->batch;       // partial rows per LayerNorm instance: one per workgroup
     bool ok = ln_job(x, P.encn_w, nwg) != nullptr;
@@ -1020,33 +1031,39 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
         // rider workgroups behind the 2 x batch sequence workgroups: as many as the busiest phase has units, at most the idle CUs
         a.grd = grads; a.nseq = 2 * cfg->batch; a.wg_accumulate = (accumulate && !grads_zero) ? 1 : 0;
         const int per_layer = gt_seq_wg_tiles(d, x.F) + gt_seq_wg_tiles(x.F, d) + gt_seq_wg_tiles(d, d), win = gt_seq_wg_tiles(3 * d, d);
-        const int idle = seq_cu_count() - a.nseq, busiest = per_layer + (L > 1 ? win : 0);
+        const int lnu = (2 * d + 63) / 64;                            // LayerNorm column blocks per job
+        const int idle = seq_cu_count() - a.nseq, busiest = per_layer + (L > 1 ? win : 0) + 2 * lnu + (L == 1 ? lnu : 0);
         const int R = idle < busiest ? (idle > 0 ? idle : 1) : busiest;
         // the last phase's sequence work is short (attention backward + in-proj dgrad of layer 0): its riders take only the first
         // GT_SEQ_RIDE_LAST_PCT % of the tokens of each tile, the tail launch -- the whole chip -- adds the rest
         static const int last_pct = [] { const char* e = getenv("GT_SEQ_RIDE_LAST_PCT"); const int v = e ? atoi(e) : GT_SEQ_RIDE_LAST_PCT; return v < 0 ? 0 : v > 100 ? 100 : v; }();
         a.ride_last_k = (int)((int64_t)M * last_pct / 100) / 64 * 64;
         if (last_pct == 100) a.ride_last_k = M;
-        fl += 2.0 * M * ((L - 1) * 3.0 * d * d + L * ((double)d * d + 2.0 * d * x.F)) - 2.0 * (M - a.ride_last_k) * busiest * 2048.0;
+        fl += 2.0 * M * ((L - 1) * 3.0 * d * d + L * ((double)d * d + 2.0 * d * x.F) + 27.0 * d)
+              - 2.0 * (M - a.ride_last_k) * (per_layer + (L > 1 ? win : 0)) * 2048.0;
         gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
-        for (int p = 0; p <= L; ++p) {
+        // bucketed backward (data-parallel overlap): phase 1 = the launches up to the cut of grad_split, phase 2 = the rest + tail
+        const int pcut = L - split_.split_layer + 1;                 // last backward phase of the first half (split_.nb == 2)
+        const int p_lo = phase == 2 ? pcut + 1 : 0, p_hi = phase == 1 ? pcut : L;
+        a.ln_nwg = nwg;
+        for (int p = p_lo; p <= p_hi; ++p) {
           SeqArgs ap = a;
           ap.phase = p;
-          if (p > 0) gt_prof_tag("seq_bwd", 0.0, 0.0);
-          gt_seq_launch_bwd(ap, d, hc, true, a.nseq + (p == 0 ? 0 : R), x.s);
+          if (p > p_lo) gt_prof_tag("seq_bwd", 0.0, 0.0);
+          gt_seq_launch_bwd(ap, d, hc, true, a.nseq + (p == 0 ? gt_seq_wg_tiles(GT_TGT, d) : R), x.s);
         }
-        // the tail: the rest of the last phase's tiles, then in-proj of layer 0 + output layer + input layer (token range split in two:
-        // two partial tiles adding onto zero commute, so this stays reproducible; GT_SEQ_TAIL_KS for experiments), the LayerNorm
-        // parameter gradients, the step-counter bump
+        if (phase == 1) return launch_status("gt_backward");
+        // the tail: the rest of the last phase's tiles, then in-proj of layer 0 + input layer (token range split in two: two partial
+        // tiles adding onto zero commute, so this stays reproducible; GT_SEQ_TAIL_KS for experiments), the step-counter bump
         static const int tail_ks = [] { const char* e = getenv("GT_SEQ_TAIL_KS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 16 ? 16 : v; }();
-        const int tiles = win + gt_seq_wg_tiles(GT_TGT, d) + gt_seq_wg_tiles(d, cfg->src_dim);
+        const int tiles = win + gt_seq_wg_tiles(d, cfg->src_dim);
         int ks = (gt_deterministic() && tail_ks > 2) ? 2 : tail_ks;
         if (ks > M / 8) ks = M / 8;
-        a.phase = L + 1; a.tail_phase = L + 1; a.tail_ksplit = ks; a.ln_nwg = nwg; a.bump = bump_state;
-        const int nrest = a.ride_last_k < M ? busiest : 0;
-        gt_prof_tag("seq_tail", 2.0 * M * (3.0 * d * d + 27.0 * d + (double)d * cfg->src_dim) + 2.0 * (M - a.ride_last_k) * busiest * 2048.0,
+        a.phase = L + 1; a.tail_phase = L + 1; a.tail_ksplit = ks; a.bump = bump_state;
+        const int nrest = a.ride_last_k < M ? per_layer + (L > 1 ? win : 0) : 0;
+        gt_prof_tag("seq_tail", 2.0 * M * (3.0 * d * d + (double)d * cfg->src_dim) + 2.0 * (M - a.ride_last_k) * nrest * 2048.0,
                     4.0 * M * (4.0 * d + cfg->src_dim));
-        gt_seq_launch_tail(a, (unsigned)(nrest + tiles * ks + (2 * L + 1) * ((2 * d + 63) / 64)), x.s);
+        gt_seq_launch_tail(a, (unsigned)(nrest + tiles * ks), x.s);
         return launch_status("gt_backward");
       }
       gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
@@ -1234,6 +1251,26 @@ static int optimizer_step_impl(int algo, float* params, float* grads, float* m, 
 extern "C" int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n, gt_step_state* state,
                                  int zero_grads, gt_stream_t stream) {
   return optimizer_step_impl(algo, params, grads, m, v, n, state, zero_grads, stream, 0);
+}
+
+// gt_optimizer_step for a caller that steps with gt_train_step(skip_update = 1..3) (data-parallel: all-reduce in between): on the
+// sequence-resident path the update also writes the next step's fragment-ordered weight copies into ws, so that step may pass
+// GT_STEP_PACKS_CURRENT; elsewhere (or with zero_grads == 0) it is gt_optimizer_step.
+extern "C" int gt_optimizer_step_ws(const gt_config* cfg, int algo, float* params, float* grads, float* m, float* v, float* ws,
+                                    gt_step_state* state, int zero_grads, gt_stream_t stream) {
+  if (check_cfg(cfg)) return -1;
+  PLayout P = param_layout(*cfg);
+  if (!use_seq(*cfg) || !zero_grads || !ws) return optimizer_step_impl(algo, params, grads, m, v, P.total, state, zero_grads, stream, 0);
+  if (!params || !grads || !state) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
+  if (algo != 0 && algo != 1) return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
+  if (algo == 1 && (!m || !v)) return gt_fail("gt_optimizer_step: adam needs m and v");
+  Ctx x;
+  if (make_ctx(x, cfg, params, grads, ws, state, 1, stream)) return -1;
+  const SeqArgs a = mk_seq(x, nullptr, nullptr, nullptr);
+  gt_prof_tag("optimizer", 0, (algo ? 28.0 : 12.0) * P.total + 8.0 * cfg->n_enc_layers * x.W.pack_stride);
+  gt_seq_launch_update_pack(a, algo, params, grads, m, v, P.total, state, 0, (hipStream_t)stream);
+  gt_launch(step_inc_kernel, dim3(1), dim3(64), (hipStream_t)stream, state);
+  return launch_status("gt_optimizer_step_ws");
 }
 
 // ------------------------------------------------------------------------------------ fused train step

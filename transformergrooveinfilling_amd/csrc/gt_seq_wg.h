@@ -209,7 +209,6 @@ __device__ __forceinline__ void seq_wg_unit(const SeqWgProb& p, const int ti, co
 }
 // tiles of a problem
 __device__ __forceinline__ int seq_wg_tiles(const int rows, const int cols) { return ((rows + GT_WG_TM - 1) / GT_WG_TM) * ((cols + GT_WG_TN - 1) / GT_WG_TN); }
-template <bool TAIL>
 __device__ __forceinline__ void seq_wg_run(const SeqWgProb& p, const int tile, const int k0, const int k1, const int mode, float* lds, float* sb,
                                            const int tid) {
   const int ntj = (p.cols + GT_WG_TN - 1) / GT_WG_TN, ti = tile / ntj, tj = tile % ntj;
@@ -220,13 +219,13 @@ __device__ __forceinline__ void seq_wg_run(const SeqWgProb& p, const int tile, c
   const bool packed_a = p.rows <= GT_WG_TM && p.lda == p.rows && al_a;
   const bool packed_b = p.cols <= GT_WG_TN && p.ldb == p.cols && al_b;
   if (lines_a && lines_b) seq_wg_unit<GT_WGL_LINES, GT_WGL_LINES>(p, ti, tj, k0, k1, mode, lds, sb, tid);
-  else if (TAIL && packed_a && lines_b) seq_wg_unit<GT_WGL_PACKED, GT_WGL_LINES>(p, ti, tj, k0, k1, mode, lds, sb, tid);    // the output layer
-  else if (TAIL && lines_a && packed_b) seq_wg_unit<GT_WGL_LINES, GT_WGL_PACKED>(p, ti, tj, k0, k1, mode, lds, sb, tid);    // the input layer
+  else if (packed_a && lines_b) seq_wg_unit<GT_WGL_PACKED, GT_WGL_LINES>(p, ti, tj, k0, k1, mode, lds, sb, tid);    // the output layer
+  else if (lines_a && packed_b) seq_wg_unit<GT_WGL_LINES, GT_WGL_PACKED>(p, ti, tj, k0, k1, mode, lds, sb, tid);    // the input layer
   else seq_wg_unit<GT_WGL_SCALAR, GT_WGL_SCALAR>(p, ti, tj, k0, k1, mode, lds, sb, tid);
 }
 
 // ---- the problems of the encoder (operands: the buffers the sequence kernels save; destinations: a.grd at the parameter offsets)
-enum { GT_WGP_OUT = 0, GT_WGP_W2 = 1, GT_WGP_W1 = 2, GT_WGP_WO = 3, GT_WGP_WIN = 4, GT_WGP_IN = 5 };
+enum { GT_WGP_OUT = 0, GT_WGP_W2 = 1, GT_WGP_W1 = 2, GT_WGP_WO = 3, GT_WGP_WIN = 4, GT_WGP_IN = 5, GT_WGP_LN = 6 };
 __device__ __forceinline__ SeqWgProb seq_wg_prob(const SeqArgs& a, const int kind, const int l) {
   const int d = a.d, F = a.F;
   const float* ws = a.ws;
@@ -246,99 +245,12 @@ __device__ __forceinline__ SeqWgProb seq_wg_prob(const SeqArgs& a, const int kin
   }
   return p;
 }
-// The problems whose operands are complete when backward phase `phase` STARTS and not earlier (phase L + 1: the tail -- which also
-// takes the two edge problems, output and input layer, whose narrow operands want the packed staging form), in launch order:
-// f(kind, layer) for each until f returns true.  (No arrays: everything stays in scalar registers.)
-template <typename F>
-__device__ __forceinline__ void seq_wg_phase_list(const SeqArgs& a, const int phase, F f) {
-  const int L = a.L;
-  if (phase == 0) return;
-  if (phase >= 2) { if (f(GT_WGP_WIN, L - phase + 1)) return; }
-  if (phase <= L) {
-    const int l = L - phase;
-    if (f(GT_WGP_W2, l)) return;
-    if (f(GT_WGP_W1, l)) return;
-    f(GT_WGP_WO, l);
-  } else {
-    if (f(GT_WGP_OUT, 0)) return;
-    f(GT_WGP_IN, 0);
-  }
-}
-__device__ __forceinline__ int seq_wg_kind_tiles(const SeqArgs& a, const int kind) {
-  const int d = a.d, F = a.F;
-  switch (kind) {
-    case GT_WGP_OUT: return seq_wg_tiles(GT_TGT, d);
-    case GT_WGP_W2:  return seq_wg_tiles(d, F);
-    case GT_WGP_W1:  return seq_wg_tiles(F, d);
-    case GT_WGP_WO:  return seq_wg_tiles(d, d);
-    case GT_WGP_WIN: return seq_wg_tiles(3 * d, d);
-    default:         return seq_wg_tiles(d, a.S);
-  }
-}
-__device__ __forceinline__ int seq_wg_phase_units(const SeqArgs& a, const int phase, const int ksplit) {
-  int n = 0;
-  seq_wg_phase_list(a, phase, [&](int kind, int) { n += seq_wg_kind_tiles(a, kind) * ksplit; return false; });
-  return n;
-}
-// unit u of the phase's list over the tokens [klo, khi), split into ksplit chunks (units = tiles x chunks, chunk-major inside a tile);
-// false when u is beyond the list
-template <bool TAIL>
-__device__ __forceinline__ bool seq_wg_phase_unit(const SeqArgs& a, const int phase, int u, const int klo, const int khi, const int ksplit,
-                                                  const int mode, float* lds, float* sb, const int tid) {
-  bool done = false;
-  seq_wg_phase_list(a, phase, [&](int kind, int layer) {
-    const int nt = seq_wg_kind_tiles(a, kind) * ksplit;
-    if (u >= nt) { u -= nt; return false; }
-    const SeqWgProb p = seq_wg_prob(a, kind, layer);
-    const int tile = u / ksplit, c = u % ksplit;
-    const int per = (((khi - klo) / GT_WG_SLAB + ksplit - 1) / ksplit) * GT_WG_SLAB;        // tokens per chunk (multiple of 8)
-    const int k0 = klo + c * per < khi ? klo + c * per : khi, k1 = k0 + per < khi ? k0 + per : khi;
-    seq_wg_run<TAIL>(p, tile, k0, k1, mode, lds, sb, tid);
-    done = true;
-    return true;
-  });
-  return done;
-}
-// rider workgroup r of R in backward phase `phase`: units r, r + R, ... of the phase's list.  Every phase but the last covers all
-// tokens; the LAST phase (its sequence work is short: attention backward + in-proj dgrad of layer 0) covers [0, a.ride_last_k) and
-// leaves the rest of each tile to the tail launch, which ADDS behind it -- a split across two launches needs no atomics.
-__device__ __forceinline__ void seq_wg_riders(const SeqArgs& a, const int phase, const int r, const int R, float* lds, float* sb, const int tid) {
-  const int mode = a.wg_accumulate ? GT_WG_ADD : GT_WG_STORE;
-  const int khi = phase == a.L ? a.ride_last_k : a.B * 32;
-  for (int u = r; seq_wg_phase_unit<false>(a, phase, u, 0, khi, 1, mode, lds, sb, tid); u += R) { }
-}
-
-#ifdef GT_SEQ_TU_BWD
-// ---- the tail, in block order: (1) the rest of the last phase's tiles (tokens [a.ride_last_k, M), added behind the riders' part);
-// (2) what could not ride at all -- layer 0's in-proj, the output and the input layer -- token range split a.tail_ksplit ways (two
-// partial tiles meeting in fp32 atomics on a zeroed gradient are still order-independent; more are not: gt_set_deterministic keeps
-// it at <= 2); (3) the LayerNorm dgamma / dbeta reductions; and the step-counter bump of the fused train step.
-__global__ __launch_bounds__(GT_SEQ_NT_WG) void seq_tail_kernel(SeqArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[GT_WG_LDS];
-  __shared__ float sb[8 * 64];
-  const int tid = threadIdx.x;
-  if (a.bump != nullptr && blockIdx.x == 0 && tid == 0) { a.bump->step += 1u; a.bump->opt_step += 1u; }
-  const int M = a.B * 32, ks = a.tail_ksplit;
-  int blk = blockIdx.x;
-  if (a.tail_phase <= a.L) {       // (a debug launch names one phase's list: that list alone, over all tokens)
-    seq_wg_phase_unit<true>(a, a.tail_phase, blk, 0, M, ks, ks > 1 ? GT_WG_ATOMIC : GT_WG_ADD, lds, sb, tid);
-    return;
-  }
-  const int nrest = a.ride_last_k < M ? seq_wg_phase_units(a, a.L, 1) : 0;
-  if (blk < nrest) { seq_wg_phase_unit<true>(a, a.L, blk, a.ride_last_k, M, 1, GT_WG_ADD, lds, sb, tid); return; }
-  blk -= nrest;
-  const int nunits = seq_wg_phase_units(a, a.L + 1, ks);
-  if (blk < nunits) {
-    seq_wg_phase_unit<true>(a, a.L + 1, blk, 0, M, ks, ks > 1 ? GT_WG_ATOMIC : (a.wg_accumulate ? GT_WG_ADD : GT_WG_STORE), lds, sb, tid);
-    return;
-  }
-  blk -= nunits;
-  // LayerNorm job j (order of the kernel's partial blocks: 0 = final norm, 1 + 2 k = norm2 of layer L-1-k, 2 + 2 k = its norm1), 64
-  // columns of [dgamma | dbeta] per workgroup: thread (column, row group of 8); a group walks its partial rows 8 loads at a time
-  // (a one-load-per-trip walk is a chain of L2 round trips: 32 of them took the tail to 37 us), the groups meet in LDS, group 0 first
-  const int d = a.d, nwg = a.ln_nwg, ncol = 2 * d, ncb = (ncol + 63) / 64;
-  const int j = blk / ncb, cb = blk % ncb;
-  if (j >= 2 * a.L + 1) return;
+// LayerNorm dgamma / dbeta: job j (order of the sequence kernels' partial blocks: 0 = final norm, 1 + 2 k = norm2 of layer L-1-k,
+// 2 + 2 k = its norm1), 64 columns of [dgamma | dbeta] per workgroup (column block cb): thread (column, row group of 8); a group walks
+// its partial rows 8 loads at a time (a one-load-per-trip walk is a chain of L2 round trips: 32 of them took the first tail to 37 us),
+// the groups meet in LDS, group 0 first -- a fixed order.  Begins and ends with a workgroup barrier.
+__device__ __forceinline__ void seq_wg_ln_job(const SeqArgs& a, const int j, const int cb, float* lds, const int tid) {
+  const int d = a.d, nwg = a.ln_nwg, ncol = 2 * d;
   int64_t goff;
   if (j == 0) goff = a.encn_w;
   else { const int k = (j - 1) >> 1, l = a.L - 1 - k; goff = (int64_t)l * a.pstride + (((j - 1) & 1) ? a.p0.n1w : a.p0.n2w); }
@@ -356,8 +268,9 @@ __global__ __launch_bounds__(GT_SEQ_NT_WG) void seq_tail_kernel(SeqArgs a) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc += v[u];
   }
+  GT_BARRIER();
   lds[tid] = acc;
-  __syncthreads();
+  GT_BARRIER();
   if (grp == 0 && ok) {
     float t = lds[tid];
 #pragma unroll
@@ -365,5 +278,107 @@ __global__ __launch_bounds__(GT_SEQ_NT_WG) void seq_tail_kernel(SeqArgs a) {
     float* o = c < d ? dst + c : dst + bo + (c - d);
     if (a.wg_accumulate) *o += t; else *o = t;
   }
+}
+// The work whose operands are complete when backward phase `phase` STARTS and not earlier (phase L + 1: the tail), in launch
+// order: f(kind, layer or LayerNorm job) for each until f returns true.  (No arrays: everything stays in scalar registers.)
+//   phase 0      output layer (d loss / d logits and the final norm's output exist before the backward starts)
+//   phase p >= 1 in-proj of layer L-p+1 (p >= 2), FFN2 / FFN1 / out-proj of layer L-p, the LayerNorm jobs phase p-1 filled
+//   tail         in-proj of layer 0, input layer
+// so after phase p everything from encoder layer L-p+1 to the end of the parameter buffer is final: gradient buckets for the
+// data-parallel all-reduce (gt_grad_buckets).
+template <typename F>
+__device__ __forceinline__ void seq_wg_phase_list(const SeqArgs& a, const int phase, F f) {
+  const int L = a.L;
+  if (phase == 0) { f(GT_WGP_OUT, 0); return; }
+  if (phase >= 2) { if (f(GT_WGP_WIN, L - phase + 1)) return; }
+  if (phase <= L) {
+    const int l = L - phase;
+    if (f(GT_WGP_W2, l)) return;
+    if (f(GT_WGP_W1, l)) return;
+    if (f(GT_WGP_WO, l)) return;
+    if (phase == 1) { if (f(GT_WGP_LN, 0)) return; }
+    if (f(GT_WGP_LN, 2 * phase - 1)) return;
+    f(GT_WGP_LN, 2 * phase);
+  } else {
+    f(GT_WGP_IN, 0);
+  }
+}
+__device__ __forceinline__ int seq_wg_kind_tiles(const SeqArgs& a, const int kind) {
+  const int d = a.d, F = a.F;
+  switch (kind) {
+    case GT_WGP_OUT: return seq_wg_tiles(GT_TGT, d);
+    case GT_WGP_W2:  return seq_wg_tiles(d, F);
+    case GT_WGP_W1:  return seq_wg_tiles(F, d);
+    case GT_WGP_WO:  return seq_wg_tiles(d, d);
+    case GT_WGP_WIN: return seq_wg_tiles(3 * d, d);
+    case GT_WGP_LN:  return (2 * d + 63) / 64;
+    default:         return seq_wg_tiles(d, a.S);
+  }
+}
+// units of a phase's list: matrix tiles x ksplit token chunks (+ the LayerNorm column blocks, never split, when with_ln)
+__device__ __forceinline__ int seq_wg_phase_units(const SeqArgs& a, const int phase, const int ksplit, const bool with_ln) {
+  int n = 0;
+  seq_wg_phase_list(a, phase, [&](int kind, int) {
+    if (kind == GT_WGP_LN) { if (with_ln) n += seq_wg_kind_tiles(a, kind); }
+    else n += seq_wg_kind_tiles(a, kind) * ksplit;
+    return false;
+  });
+  return n;
+}
+// unit u of the phase's list over the tokens [klo, khi), split into ksplit chunks (units = tiles x chunks, chunk-major inside a tile);
+// false when u is beyond the list
+__device__ __forceinline__ bool seq_wg_phase_unit(const SeqArgs& a, const int phase, int u, const int klo, const int khi, const int ksplit,
+                                                  const int mode, const bool with_ln, float* lds, float* sb, const int tid) {
+  bool done = false;
+  seq_wg_phase_list(a, phase, [&](int kind, int layer) {
+    if (kind == GT_WGP_LN) {
+      if (!with_ln) return false;
+      const int ncb = seq_wg_kind_tiles(a, kind);
+      if (u >= ncb) { u -= ncb; return false; }
+      seq_wg_ln_job(a, layer, u, lds, tid);
+      done = true;
+      return true;
+    }
+    const int nt = seq_wg_kind_tiles(a, kind) * ksplit;
+    if (u >= nt) { u -= nt; return false; }
+    const SeqWgProb p = seq_wg_prob(a, kind, layer);
+    const int tile = u / ksplit, c = u % ksplit;
+    const int per = (((khi - klo) / GT_WG_SLAB + ksplit - 1) / ksplit) * GT_WG_SLAB;        // tokens per chunk (multiple of 8)
+    const int k0 = klo + c * per < khi ? klo + c * per : khi, k1 = k0 + per < khi ? k0 + per : khi;
+    seq_wg_run(p, tile, k0, k1, mode, lds, sb, tid);
+    done = true;
+    return true;
+  });
+  return done;
+}
+// rider workgroup r of R in backward phase `phase`: units r, r + R, ... of the phase's list.  Every phase but the last covers all
+// tokens; the LAST phase (its sequence work is short: attention backward + in-proj dgrad of layer 0) covers [0, a.ride_last_k) and
+// leaves the rest of each tile to the tail launch, which ADDS behind it -- a split across two launches needs no atomics.
+__device__ __forceinline__ void seq_wg_riders(const SeqArgs& a, const int phase, const int r, const int R, float* lds, float* sb, const int tid) {
+  const int mode = a.wg_accumulate ? GT_WG_ADD : GT_WG_STORE;
+  const int khi = phase == a.L ? a.ride_last_k : a.B * 32;
+  for (int u = r; seq_wg_phase_unit(a, phase, u, 0, khi, 1, mode, true, lds, sb, tid); u += R) { }
+}
+
+#ifdef GT_SEQ_TU_BWD
+// ---- the tail, in block order: (1) the rest of the last phase's tiles (tokens [a.ride_last_k, M), added behind the riders' part);
+// (2) what could not ride at all -- layer 0's in-proj and the input layer -- token range split a.tail_ksplit ways (two partial tiles
+// meeting in fp32 atomics on a zeroed gradient are still order-independent; more are not: gt_set_deterministic keeps it at <= 2);
+// and the step-counter bump of the fused train step.
+__global__ __launch_bounds__(GT_SEQ_NT_WG) void seq_tail_kernel(SeqArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[GT_WG_LDS];
+  __shared__ float sb[8 * 64];
+  const int tid = threadIdx.x;
+  if (a.bump != nullptr && blockIdx.x == 0 && tid == 0) { a.bump->step += 1u; a.bump->opt_step += 1u; }
+  const int M = a.B * 32, ks = a.tail_ksplit;
+  int blk = blockIdx.x;
+  if (a.tail_phase <= a.L) {       // (a debug launch names one phase's list: its matrix tiles alone, over all tokens)
+    seq_wg_phase_unit(a, a.tail_phase, blk, 0, M, ks, ks > 1 ? GT_WG_ATOMIC : GT_WG_ADD, false, lds, sb, tid);
+    return;
+  }
+  const int nrest = a.ride_last_k < M ? seq_wg_phase_units(a, a.L, 1, false) : 0;
+  if (blk < nrest) { seq_wg_phase_unit(a, a.L, blk, a.ride_last_k, M, 1, GT_WG_ADD, false, lds, sb, tid); return; }
+  blk -= nrest;
+  seq_wg_phase_unit(a, a.L + 1, blk, 0, M, ks, ks > 1 ? GT_WG_ATOMIC : (a.wg_accumulate ? GT_WG_ADD : GT_WG_STORE), true, lds, sb, tid);
 }
 #endif

@@ -25,6 +25,8 @@ OVERLAP_MIN_BYTES = 16 << 20
 EAGER_MAX_LAUNCHES = 24                # use_graph="auto": steps of at most this many launches are enqueued directly, not replayed
 PREDICT_CHUNK = 512                    # floor of the sequences per gt_predict call
 PREDICT_WS_BYTES = 32 << 30            # ... the chunk grows (x2) while its workspace stays under this and under half the free HBM
+PREDICT_WS_KEEP = 4 << 30              # predict() keeps a workspace between calls only up to this size (a per-epoch evaluation must not pin tens of GiB)
+MAX_SLOTS = 6                          # per-batch-size step slots kept (least recently created dropped first; the engine's own batch size stays)
 
 
 def _ptr(t):
@@ -131,6 +133,8 @@ class StepEngine:
     def slot(self, B):
         B = int(B)
         if B not in self._slots:
+            if len(self._slots) >= MAX_SLOTS:                     # evaluation remainders etc.: bounded, like the loss slots
+                self._slots.pop(next(k for k in self._slots if k != self.B))
             self._slots[B] = _Slot(self, B)
         return self._slots[B]
 
@@ -193,23 +197,35 @@ class StepEngine:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- the hot path ----------------------------------------------------------------------------
+    def _packs_current(self, s):
+        """Are the fragment-ordered weight copies in slot s's workspace those of the current parameters?  (written by the last
+        fused update on THIS slot, nothing -- the engine or torch -- has written the parameters since; never under graph replay:
+        a captured graph would replay the flag blindly)"""
+        return (self.fold_pack and not self.graph_for(s) and s.pack_epoch == self._pepoch
+                and self._pver == self.params._version)
+
     def _enqueue_step(self, s, skip_update):
-        if skip_update == 0 and self.fold_pack and not self.graph_for(s):     # (a captured graph would replay the flag blindly)
-            if s.pack_epoch == self._pepoch and self._pver == self.params._version:
-                skip_update |= 4           # GT_STEP_PACKS_CURRENT
+        flags = skip_update
+        if skip_update != 3 and self._packs_current(s):
+            flags |= 4                         # GT_STEP_PACKS_CURRENT: no packing launch at the head of the step
+        if skip_update == 0:                   # whole step: its update writes the next step's copies into this slot
             self._pepoch += 1
             s.pack_epoch, self._pver = self._pepoch, self.params._version
-        else:
-            self._pepoch += 1              # parameters change (or may) without this slot's copies following
         self.lib.call("gt_train_step", ctypes.byref(s.cfg), self.algo, _ptr(self.params), _ptr(self.grads),
                       _ptr(self.m), _ptr(self.v), _ptr(self.pe), _ptr(s.x), _ptr(s.y),
                       ctypes.c_float(self.penalty), _ptr(s.hvo), _ptr(s.stats), _ptr(s.tgt), _ptr(s.ws),
-                      _ptr(self.state), int(skip_update), self.stream)
+                      _ptr(self.state), int(flags), self.stream)
 
-    def enqueue_update(self, zero_grads=True):
+    def enqueue_update(self, zero_grads=True, slot=None):
         """Fused update over the flat buffers.  zero_grads=True also clears the consumed gradients (fused step path);
-        the torch.optim-style front keeps them until zero_grad() like torch does."""
+        the torch.optim-style front keeps them until zero_grad() like torch does.  slot: the step's slot -- its workspace then
+        receives the next step's weight copies (gt_optimizer_step_ws)."""
         self._pepoch += 1
+        if slot is not None and zero_grads and self.fold_pack:
+            slot.pack_epoch, self._pver = self._pepoch, self.params._version
+            self.lib.call("gt_optimizer_step_ws", ctypes.byref(slot.cfg), self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m),
+                          _ptr(self.v), _ptr(slot.ws), _ptr(self.state), 1, self.stream)
+            return
         self.lib.call("gt_optimizer_step", self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v),
                       ctypes.c_int64(self.total), _ptr(self.state), int(zero_grads), self.stream)
 
@@ -279,7 +295,7 @@ class StepEngine:
             else:
                 self._replay(s, ("fwdbwd", self.algo, self.penalty), lambda: self._enqueue_step(s, 1))
                 dist.all_reduce(self.grads)                  # RCCL sum over xGMI; averaged by grad_scale
-            self.enqueue_update()
+            self.enqueue_update(slot=s)
         return s.stats
 
     def train_step_indexed(self, xs, ys, idx):
@@ -388,6 +404,8 @@ class StepEngine:
             cfg, ws, tgt = self._predict_ws[m]
             self.lib.call("gt_predict", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x[i:i + m]), _ptr(out[i:i + m]),
                           ctypes.c_float(thres), int(use_thres), _ptr(tgt), _ptr(ws), self.stream)
+        for m in [k for k, (_, ws, _) in self._predict_ws.items() if 4 * ws.numel() > PREDICT_WS_KEEP]:
+            del self._predict_ws[m]               # (stream-ordered free: the caching allocator keeps the block until the launches ran)
         return out
 
     def mean_stats(self, s):
