@@ -730,7 +730,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
   a.dctx = x.W.seq_dctx; a.phase = 0;
   a.loss_y = nullptr; a.loss_penalty = 0.f; a.loss_stats = nullptr; a.loss_part = nullptr; a.loss_ticket = nullptr;
-  a.grd = nullptr; a.nseq = 0; a.wg_accumulate = 0; a.ride_last_k = x.M; a.tail_phase = 0; a.tail_ksplit = 1; a.ln_nwg = 0; a.bump = nullptr;
+  a.grd = nullptr; a.nseq = 0; a.wg_accumulate = 0; a.ride_last_k = x.M; a.out_early = 0; a.tail_phase = 0; a.tail_ksplit = 1; a.ln_nwg = 0; a.bump = nullptr;
   return a;
 }
 // the whole forward (input layer ... output heads) of every sequence: ONE launch
@@ -1039,7 +1039,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
         static const int last_pct = [] { const char* e = getenv("GT_SEQ_RIDE_LAST_PCT"); const int v = e ? atoi(e) : GT_SEQ_RIDE_LAST_PCT; return v < 0 ? 0 : v > 100 ? 100 : v; }();
         a.ride_last_k = (int)((int64_t)M * last_pct / 100) / 64 * 64;
         if (last_pct == 100) a.ride_last_k = M;
-        fl += 2.0 * M * ((L - 1) * 3.0 * d * d + L * ((double)d * d + 2.0 * d * x.F) + 27.0 * d)
+        fl += 2.0 * M * ((L - 1) * 3.0 * d * d + L * ((double)d * d + 2.0 * d * x.F))
               - 2.0 * (M - a.ride_last_k) * (per_layer + (L > 1 ? win : 0)) * 2048.0;
         gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
         // bucketed backward (data-parallel overlap): phase 1 = the launches up to the cut of grad_split, phase 2 = the rest + tail
@@ -1050,18 +1050,24 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
           SeqArgs ap = a;
           ap.phase = p;
           if (p > p_lo) gt_prof_tag("seq_bwd", 0.0, 0.0);
-          gt_seq_launch_bwd(ap, d, hc, true, a.nseq + (p == 0 ? gt_seq_wg_tiles(GT_TGT, d) : R), x.s);
+          gt_seq_launch_bwd(ap, d, hc, true, a.nseq + (p == 0 ? 0 : R), x.s);
         }
-        if (phase == 1) return launch_status("gt_backward");
+        if (phase == 1) {      // bucket 0 reaches to the END of the buffer: the output layer's gradient now, by a launch of its own
+          a.phase = 0; a.tail_phase = 0; a.tail_ksplit = 2; a.bump = nullptr;
+          gt_prof_tag("seq_tail", 2.0 * M * 27.0 * d, 4.0 * M * (27.0 + d));
+          gt_seq_launch_tail(a, (unsigned)(gt_seq_wg_tiles(GT_TGT, d) * 2), x.s);
+          return launch_status("gt_backward");
+        }
+        a.out_early = phase == 2 ? 1 : 0;
         // the tail: the rest of the last phase's tiles, then in-proj of layer 0 + input layer (token range split in two: two partial
         // tiles adding onto zero commute, so this stays reproducible; GT_SEQ_TAIL_KS for experiments), the step-counter bump
         static const int tail_ks = [] { const char* e = getenv("GT_SEQ_TAIL_KS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 16 ? 16 : v; }();
-        const int tiles = win + gt_seq_wg_tiles(d, cfg->src_dim);
+        const int tiles = win + gt_seq_wg_tiles(d, cfg->src_dim) + (a.out_early ? 0 : gt_seq_wg_tiles(GT_TGT, d));
         int ks = (gt_deterministic() && tail_ks > 2) ? 2 : tail_ks;
         if (ks > M / 8) ks = M / 8;
         a.phase = L + 1; a.tail_phase = L + 1; a.tail_ksplit = ks; a.bump = bump_state;
         const int nrest = a.ride_last_k < M ? per_layer + (L > 1 ? win : 0) : 0;
-        gt_prof_tag("seq_tail", 2.0 * M * (3.0 * d * d + (double)d * cfg->src_dim) + 2.0 * (M - a.ride_last_k) * nrest * 2048.0,
+        gt_prof_tag("seq_tail", 2.0 * M * (3.0 * d * d + (a.out_early ? 0.0 : 27.0 * d) + (double)d * cfg->src_dim) + 2.0 * (M - a.ride_last_k) * nrest * 2048.0,
                     4.0 * M * (4.0 * d + cfg->src_dim));
         gt_seq_launch_tail(a, (unsigned)(nrest + tiles * ks), x.s);
         return launch_status("gt_backward");

@@ -31,6 +31,7 @@ struct SeqArgs {
   int nseq;                                                  // sequence workgroups of the launch; blocks beyond them are riders
   int wg_accumulate;                                         // 1: add into grd (gt_backward's accumulate), 0: overwrite (grd is zero or dead)
   int ride_last_k;                                           // riders of the last phase cover the tokens [0, ride_last_k); the tail adds the rest
+  int out_early;                                             // the output layer's weight gradient was computed by a launch of its own (bucketed backward)
   int tail_phase;                                            // tail kernel: L + 1 (debug launches: another phase's list alone)
   int tail_ksplit;                                           // tail kernel: token chunks per tile (> 1: partial tiles meet in atomics)
   int ln_nwg;                                                // tail kernel: partial rows per LayerNorm instance

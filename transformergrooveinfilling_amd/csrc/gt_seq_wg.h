@@ -26,7 +26,7 @@
 #define GT_WG_TM 32                       // tile rows (columns of dY)
 #define GT_WG_TN 64                       // tile columns (columns of X)
 #ifndef GT_WG_DEPTH
-#define GT_WG_DEPTH 4                     // slabs in flight in registers per wave
+#define GT_WG_DEPTH 2                     // slabs in flight in registers per wave (2 and 4 time alike; at 4 the rider kernel hits 256 VGPRs and spills)
 #endif
 #define GT_WG_STAGE (2 * GT_WG_SLAB * (GT_WG_TM + GT_WG_TN))   // floats of staging per wave (two buffers)
 #define GT_WG_LDS (8 * GT_WG_TM * GT_WG_TN)                    // floats the unit needs: 8 partial tiles (>= 8 staging areas)
@@ -209,6 +209,7 @@ __device__ __forceinline__ void seq_wg_unit(const SeqWgProb& p, const int ti, co
 }
 // tiles of a problem
 __device__ __forceinline__ int seq_wg_tiles(const int rows, const int cols) { return ((rows + GT_WG_TM - 1) / GT_WG_TM) * ((cols + GT_WG_TN - 1) / GT_WG_TN); }
+template <bool TAIL>
 __device__ __forceinline__ void seq_wg_run(const SeqWgProb& p, const int tile, const int k0, const int k1, const int mode, float* lds, float* sb,
                                            const int tid) {
   const int ntj = (p.cols + GT_WG_TN - 1) / GT_WG_TN, ti = tile / ntj, tj = tile % ntj;
@@ -219,8 +220,8 @@ __device__ __forceinline__ void seq_wg_run(const SeqWgProb& p, const int tile, c
   const bool packed_a = p.rows <= GT_WG_TM && p.lda == p.rows && al_a;
   const bool packed_b = p.cols <= GT_WG_TN && p.ldb == p.cols && al_b;
   if (lines_a && lines_b) seq_wg_unit<GT_WGL_LINES, GT_WGL_LINES>(p, ti, tj, k0, k1, mode, lds, sb, tid);
-  else if (packed_a && lines_b) seq_wg_unit<GT_WGL_PACKED, GT_WGL_LINES>(p, ti, tj, k0, k1, mode, lds, sb, tid);    // the output layer
-  else if (lines_a && packed_b) seq_wg_unit<GT_WGL_LINES, GT_WGL_PACKED>(p, ti, tj, k0, k1, mode, lds, sb, tid);    // the input layer
+  else if (TAIL && packed_a && lines_b) seq_wg_unit<GT_WGL_PACKED, GT_WGL_LINES>(p, ti, tj, k0, k1, mode, lds, sb, tid);    // the output layer
+  else if (TAIL && lines_a && packed_b) seq_wg_unit<GT_WGL_LINES, GT_WGL_PACKED>(p, ti, tj, k0, k1, mode, lds, sb, tid);    // the input layer
   else seq_wg_unit<GT_WGL_SCALAR, GT_WGL_SCALAR>(p, ti, tj, k0, k1, mode, lds, sb, tid);
 }
 
@@ -281,9 +282,11 @@ __device__ __forceinline__ void seq_wg_ln_job(const SeqArgs& a, const int j, con
 }
 // The work whose operands are complete when backward phase `phase` STARTS and not earlier (phase L + 1: the tail), in launch
 // order: f(kind, layer or LayerNorm job) for each until f returns true.  (No arrays: everything stays in scalar registers.)
-//   phase 0      output layer (d loss / d logits and the final norm's output exist before the backward starts)
+//   phase 0      (riders: nothing) the output layer -- its operands exist before the backward starts, but its 27-wide dY wants the
+//                packed staging form, which only the tail kernel carries (in the rider kernel it cost 880 B/lane of scratch): list 0
+//                is run by a tail-kernel launch of its own, and only when the backward is cut in two for the data-parallel overlap
 //   phase p >= 1 in-proj of layer L-p+1 (p >= 2), FFN2 / FFN1 / out-proj of layer L-p, the LayerNorm jobs phase p-1 filled
-//   tail         in-proj of layer 0, input layer
+//   tail         in-proj of layer 0, output layer (unless list 0 ran), input layer
 // so after phase p everything from encoder layer L-p+1 to the end of the parameter buffer is final: gradient buckets for the
 // data-parallel all-reduce (gt_grad_buckets).
 template <typename F>
@@ -300,6 +303,7 @@ __device__ __forceinline__ void seq_wg_phase_list(const SeqArgs& a, const int ph
     if (f(GT_WGP_LN, 2 * phase - 1)) return;
     f(GT_WGP_LN, 2 * phase);
   } else {
+    if (!a.out_early) { if (f(GT_WGP_OUT, 0)) return; }
     f(GT_WGP_IN, 0);
   }
 }
@@ -327,6 +331,7 @@ __device__ __forceinline__ int seq_wg_phase_units(const SeqArgs& a, const int ph
 }
 // unit u of the phase's list over the tokens [klo, khi), split into ksplit chunks (units = tiles x chunks, chunk-major inside a tile);
 // false when u is beyond the list
+template <bool TAIL>
 __device__ __forceinline__ bool seq_wg_phase_unit(const SeqArgs& a, const int phase, int u, const int klo, const int khi, const int ksplit,
                                                   const int mode, const bool with_ln, float* lds, float* sb, const int tid) {
   bool done = false;
@@ -345,7 +350,7 @@ __device__ __forceinline__ bool seq_wg_phase_unit(const SeqArgs& a, const int ph
     const int tile = u / ksplit, c = u % ksplit;
     const int per = (((khi - klo) / GT_WG_SLAB + ksplit - 1) / ksplit) * GT_WG_SLAB;        // tokens per chunk (multiple of 8)
     const int k0 = klo + c * per < khi ? klo + c * per : khi, k1 = k0 + per < khi ? k0 + per : khi;
-    seq_wg_run(p, tile, k0, k1, mode, lds, sb, tid);
+    seq_wg_run<TAIL>(p, tile, k0, k1, mode, lds, sb, tid);
     done = true;
     return true;
   });
@@ -357,7 +362,7 @@ __device__ __forceinline__ bool seq_wg_phase_unit(const SeqArgs& a, const int ph
 __device__ __forceinline__ void seq_wg_riders(const SeqArgs& a, const int phase, const int r, const int R, float* lds, float* sb, const int tid) {
   const int mode = a.wg_accumulate ? GT_WG_ADD : GT_WG_STORE;
   const int khi = phase == a.L ? a.ride_last_k : a.B * 32;
-  for (int u = r; seq_wg_phase_unit(a, phase, u, 0, khi, 1, mode, true, lds, sb, tid); u += R) { }
+  for (int u = r; seq_wg_phase_unit<false>(a, phase, u, 0, khi, 1, mode, true, lds, sb, tid); u += R) { }
 }
 
 #ifdef GT_SEQ_TU_BWD
@@ -373,12 +378,12 @@ __global__ __launch_bounds__(GT_SEQ_NT_WG) void seq_tail_kernel(SeqArgs a) {
   const int M = a.B * 32, ks = a.tail_ksplit;
   int blk = blockIdx.x;
   if (a.tail_phase <= a.L) {       // (a debug launch names one phase's list: its matrix tiles alone, over all tokens)
-    seq_wg_phase_unit(a, a.tail_phase, blk, 0, M, ks, ks > 1 ? GT_WG_ATOMIC : GT_WG_ADD, false, lds, sb, tid);
+    seq_wg_phase_unit<true>(a, a.tail_phase, blk, 0, M, ks, ks > 1 ? GT_WG_ATOMIC : GT_WG_ADD, false, lds, sb, tid);
     return;
   }
   const int nrest = a.ride_last_k < M ? seq_wg_phase_units(a, a.L, 1, false) : 0;
-  if (blk < nrest) { seq_wg_phase_unit(a, a.L, blk, a.ride_last_k, M, 1, GT_WG_ADD, false, lds, sb, tid); return; }
+  if (blk < nrest) { seq_wg_phase_unit<true>(a, a.L, blk, a.ride_last_k, M, 1, GT_WG_ADD, false, lds, sb, tid); return; }
   blk -= nrest;
-  seq_wg_phase_unit(a, a.L + 1, blk, 0, M, ks, ks > 1 ? GT_WG_ATOMIC : (a.wg_accumulate ? GT_WG_ADD : GT_WG_STORE), true, lds, sb, tid);
+  seq_wg_phase_unit<true>(a, a.L + 1, blk, 0, M, ks, ks > 1 ? GT_WG_ATOMIC : (a.wg_accumulate ? GT_WG_ADD : GT_WG_STORE), true, lds, sb, tid);
 }
 #endif
