@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 EPI = {0: None, 1: "gemm_wgrad", 2: "gemm_fwd_input", 3: "gemm_fwd_ffn1", 4: "gemm_fwd_heads", 5: "gemm_dgrad_ffn2",
        6: "gemm_dgrad_input", 7: "gemm_fwd_res_ln", 8: "gemm_dgrad_lnbwd"}
-PLAIN = [("wgrad_group_kernel", "gemm_wgrad"), ("wgrad_reduce", "gemm_wgrad_reduce"), ("attn_fwd", "attn_fwd"), ("attn_bwd", "attn_bwd"),
+PLAIN = [("seq_tail_kernel", "seq_tail"), ("seq_update_pack_kernel", "optimizer"), ("wgrad_group_kernel", "gemm_wgrad"), ("wgrad_reduce", "gemm_wgrad_reduce"), ("attn_fwd", "attn_fwd"), ("attn_bwd", "attn_bwd"),
          ("attn_decode", "attn_decode"), ("ln_bwd", "ln_bwd"), ("ln_fwd", "ln_fwd"), ("heads_loss", "heads_loss"), ("loss_kernel", "loss"),
          ("sgd_kernel", "optimizer"), ("adam_kernel", "optimizer"), ("ln_param_reduce", "ln_param_reduce"),
          ("encoder_small", "encoder_small"), ("seq_fwd_kernel", "seq_fwd"), ("seq_bwd_kernel", "seq_bwd"),
@@ -135,17 +135,28 @@ def main():
         for row in csv.DictReader(open(stats)):
             dur[row["Name"]] = (float(row["AverageNs"]) / 1e3, int(row["Calls"]), float(row["Percentage"]))
     sq, fe, wr = counters(os.path.join(base, "pmc_sq")), counters(os.path.join(base, "pmc_fetch")), counters(os.path.join(base, "pmc_write"))
+    ctf = {}
+    cj = os.path.join(base, "class_tflops.json")          # tools/class_profile.py --json: flop rate per kernel class (live, eager pass)
+    if os.path.exists(cj):
+        ctf = json.load(open(cj))
+        shutil.copy(cj, pre + "_class_tflops.json")
     with open(pre + "_mfma_hbm.md", "w") as f:
         f.write("# %s, workload %s: per-kernel MFMA-busy %% and HBM traffic (csrc %s, rev %s)\n\n" % (tag, wl, sha, rev))
         f.write("Durations: the kernel-trace pass (steps as the engine enqueues them).  Counters: three separate --pmc passes of the same workload, eager launches.\n\n")
-        f.write("| kernel | calls | avg µs | % of GPU time | MFMA busy % | HBM GB/s | HBM MB / launch |\n|---|---|---|---|---|---|---|\n")
+        f.write("TFLOP/s: the algorithmic flops of the kernel's CLASS (2 M N K of its launches, tagged by the library) over the class's time in a live eager pass "
+                "(tools/class_profile.py); kernels of one class share the figure.\n\n")
+        f.write("| kernel | calls | avg µs | % of GPU time | class | TFLOP/s of the class | % of MFMA peak | MFMA busy % | HBM GB/s | HBM MB / launch |\n|---|---|---|---|---|---|---|---|---|---|\n")
         for name, (us, calls, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
             if pct < 0.4:
                 continue
             s = sq.get(name, {})
             busy = 100.0 * s["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (4.0 * s["SQ_BUSY_CU_CYCLES"][0]) if s.get("SQ_BUSY_CU_CYCLES", (0,))[0] else float("nan")
             kib = 2.0 * fe.get(name, {}).get("FETCH_SIZE", (float("nan"),))[0] + wr.get(name, {}).get("WRITE_SIZE", (float("nan"),))[0]
-            f.write("| `%s` | %d | %.2f | %.1f | %.1f | %.0f | %.2f |\n" % (short(name), calls, us, pct, busy, kib * 1024 / us / 1e3, kib * 1024 / 1e6))
+            kc = klass(name) or ""
+            c = ctf.get("classes", {}).get(kc, {})
+            tfs = ("%.1f" % c["tflops"]) if c.get("tflops") else "-"
+            frs = ("%.1f" % (100 * c["frac_of_mfma_peak"])) if c.get("tflops") else "-"
+            f.write("| `%s` | %d | %.2f | %.1f | %s | %s | %s | %.1f | %.0f | %.2f |\n" % (short(name), calls, us, pct, kc, tfs, frs, busy, kib * 1024 / us / 1e3, kib * 1024 / 1e6))
     classes = {}
     for kern in set(fe) | set(wr):
         k = klass(kern)

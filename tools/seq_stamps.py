@@ -50,8 +50,9 @@ print("  input-layer epilogue %d" % (st[102 + 10 * L] - prev))
 
 sub = st[200:216]
 if sub[0]:
-    print(" forward layer 1 in-proj, wave 0: issue first B loads %d; then per tile [wait + MFMAs, epilogue, gap]:" % (sub[1] - sub[0]),
-          " ".join("[%d %d %d]" % (sub[3 + 3 * i] - sub[2 + 3 * i], sub[4 + 3 * i] - sub[3 + 3 * i], (sub[5 + 3 * i] - sub[4 + 3 * i]) if i < 2 else 0) for i in range(3)))
+    print(" forward layer 1 FFN1, wave 0: issue first B loads %d; then per tile [wait + MFMAs, epilogue, gap]:" % (sub[1] - sub[0]),
+          " ".join("[%d %d %d]" % (sub[3 + 3 * i] - sub[2 + 3 * i], sub[4 + 3 * i] - sub[3 + 3 * i], (sub[5 + 3 * i] - sub[4 + 3 * i]) if i < 3 else 0) for i in range(4)),
+          " stage start -> first stamp %d" % (sub[0] - st[2 + 10 * 1 + 4]))
 
 if os.environ.get("GT_SEQ_SPLIT") == "1":
     print(" SPLIT mode (two workgroups per sequence, one launch per phase): cycles of workgroup 0")

@@ -934,7 +934,6 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     const float* pl = prm + (int64_t)l * a.pstride;
     const float* kf = ws + a.pack_f + (int64_t)l * a.kstride;
     GT_STAMP(2 + 10 * l);
-    GT_SUBSET(l == 1);
     seq_mm_tiles<NK, (3 * DP / 16 + 7) / 8, EXACT, HALF>(sX + rb * SX, SX, d, kf, 3 * d, pl + a.p0.in_b, wave, lane,
                                                           [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
       const int col = n0 + 4 * lg;
@@ -943,7 +942,6 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     });
     GT_BARRIER();
     GT_STAMP(2 + 10 * l + 1);
-    GT_SUBSET(false);
   };
   // ---- the rest of layer l: attention .. norm2 -> the next layer's input in sX (own rows); ends with a barrier
   auto layer_rest = [&](const int l, const bool save_qkv) {
@@ -1000,6 +998,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     // ---- FFN1: hact = drop(relu(x1 W1^T + b1))
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_FFN);
+      GT_SUBSET(l == 1);                                         // (diagnostic builds: sub-stage stamps of this stage, wave 0)
       seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT, HALF>(sX1 + rb * SX, SX, d, kf_w1, F, pl + a.p0.b1, wave, lane,
                                                        [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
         const int col = n0 + 4 * lg;
@@ -1018,6 +1017,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       });
     }
     GT_BARRIER();
+    GT_SUBSET(false);
     GT_STAMP(sb + 5);
     // ---- FFN2 (K = F: split over the waves) -> partial tiles; the FFN tile goes to global (saved for the backward)
     seq_tile_out(wl + a.w0.hact + r0 * F, sH, SH, F, tid, rb, NROW);
