@@ -466,6 +466,27 @@ def check_golden(backend, path):
             assert np.abs(new[k] - z["sgd/" + k]).max() < 1e-5, k
 
 
+def check_golden_bf16(backend, path):
+    """The committed stock-torch vectors (full-depth C4 / C5 models) on the bf16-operand path (precision = 1): the per-operation
+    teacher-forced check -- the parity proof of this mode -- on the golden's own parameters and inputs, and the torch fp32 outputs /
+    loss as the end-to-end sanity bound (what separates the two is the bf16 rounding of the operands, nothing else)."""
+    z = np.load(path)
+    cfg = {k: (float(v) if k == "dropout" else int(v)) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
+    cfg = dict(cfg, precision=1)
+    P = ng.init_params(cfg, seed=int(z["seed"]), perturb=0.05)
+    x, y = z["x"], z["y"]
+    tgt = shift_right(y) if cfg["num_decoder_layers"] else None
+    r = Runner(cfg, x.shape[0], backend, lr=0.094)
+    r.set_params(P)
+    hvo = r.forward(x, tgt)
+    assert np.abs(hvo - np.concatenate([z["h"], z["v"], z["o"]], -1)).max() < BF16_OUT_MAX
+    stats, _ = r.loss(y, 0.47)
+    assert abs(stats[0] - z["stats_pen0.47"][0]) < 1e-2 * max(1.0, abs(z["stats_pen0.47"][0]))
+    G = r.backward()
+    nops = check_ops_bf16(r, P, cfg, x, tgt, (1234, 99, 0), 0.0, G)
+    assert nops >= 10 * (cfg["num_encoder_layers"] + cfg["num_decoder_layers"])
+
+
 def check_demo_ckpt(backend):
     z = np.load(os.path.join(GOLD, "demo_ckpt.npz"))
     P = {k[3:]: z[k] for k in z.files if k.startswith("sd/") and not k.endswith(".pe")}

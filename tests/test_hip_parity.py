@@ -53,6 +53,11 @@ def test_golden_vectors(path):
     parity.check_golden("hip", path)
 
 
+@pytest.mark.parametrize("path", [p for p in parity.golden_files() if any(t in p for t in ("c4", "c5_sym", "encdec_c3"))])
+def test_full_depth_golden_vectors_on_the_bf16_operand_path(path):
+    parity.check_golden_bf16("hip", path)
+
+
 def test_demo_checkpoint():
     parity.check_demo_ckpt("hip")
 

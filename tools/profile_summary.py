@@ -37,13 +37,14 @@ PLAIN = [("seq_tail_kernel", "seq_tail"), ("seq_update_pack_kernel", "optimizer"
 
 def klass(name):
     """kernel name -> the class label the library's live profile (gt_profile_report) uses"""
-    m = re.match(r"void (?:gemm_kernel|gemm32_kernel|bgemm_kernel)<(.*?)>", name)
+    m = re.match(r"void (gemm_kernel|gemm32_kernel)<(.*?)>", name)
     if m:
-        a = [x.strip() for x in m.group(1).split(",")]
+        a = [x.strip() for x in m.group(2).split(",")]
         try:
-            epi, bkm = int(a[-1]), a[-2] == "true"
+            # gemm_kernel<WM, WN, TM, TN, BK, AKM, BKM, EPI, PREC>; gemm32_kernel<BKM, EPI, PREC>
+            bkm, epi = (a[6] == "true", int(a[7])) if m.group(1) == "gemm_kernel" else (a[0] == "true", int(a[1]))
             return EPI.get(epi) or ("gemm_dgrad" if bkm else "gemm_fwd_bias")
-        except ValueError:
+        except (ValueError, IndexError):
             return "gemm"
     for k, v in PLAIN:
         if k in name:

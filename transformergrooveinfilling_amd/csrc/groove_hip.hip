@@ -465,7 +465,7 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
   g.dgamma = x.grd + gamma_off; g.dbeta = x.grd + gamma_off + (x.d + 63) / 64 * 64;   // bias tensor follows the weight
   g.C2 = x.drop ? dzm : nullptr;
   g.drop = mk_drop(x, site);
-  const int bm = gemm_row_bm(x.M, x.d);
+  const int bm = gemm_row_rows(g, true);
   g.ln_part = ln_job(x, gamma_off, (x.M + bm - 1) / bm);
   return gemm_launch_row<false, true, EPI_RES_LNBWD>(g, x.s);
 }

@@ -193,6 +193,131 @@ __device__ static inline float gt_red16(float v) {
   return v;
 }
 
+// Row epilogues on a staged tile: sC (LDS, [BM][CSTR], CSTR = BN + 4) holds the raw accumulators of rows m0 .. m0 + BM - 1 (all BN
+// columns: the workgroup owns whole rows); every 16-lane group owns one row at a time, lane l16 holds columns l16 + 16 i in registers
+// and the LayerNorm statistics are 16-lane xor-shuffle sums.  Shared by gemm_body's row tiles and the ring-body row kernel
+// (gt_gemm32.h).  NT threads, NG = NT / 16 row groups, BM % NG == 0.  smem: sC itself -- the dgamma / dbeta partials reuse it.
+template <int BM, int BN, int NT, int EPI>
+__device__ __forceinline__ void gemm_row_epilogue(const GemmArgs& g, const int m0, const int by, float* smem) {
+  constexpr int CSTR = BN + 4, NG = NT / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
+  const float* const zp = gt_zero_ptr();
+  auto ldg = [zp](const float* p, size_t idx, bool ok) -> float { return *(ok ? p + idx : zp); };
+  const uint32_t dkey = gt_drop_key(g.drop);
+  float* sC = smem;
+  constexpr int CPL = BN / 16;            // columns per lane of a 16-lane row group
+  const int grp = wave * 4 + lg;
+  const float invN = 1.0f / (float)g.N;
+  float dg[EPI == EPI_RES_LNBWD ? CPL : 1], db[EPI == EPI_RES_LNBWD ? CPL : 1];
+  if (EPI == EPI_RES_LNBWD) {
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+  }
+
+  for (int rl = grp; rl < BM; rl += NG) {           // BM % NG == 0: the trip count is wave-uniform
+    const int row = m0 + rl;
+    const bool live = row < g.M;
+    const size_t rowc = live ? row : 0;               // clamped row for the unconditional loads
+    const float* zr = sC + rl * CSTR;
+    float z[CPL], e1[CPL], e2[CPL], e3[CPL];
+    if (EPI == EPI_RES_LN) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {                 // phase 1: all loads
+        const int c = l16 + 16 * i;
+        const bool okc = c < g.N;
+        z[i] = zr[c];
+        e1[i] = ldg(g.bias, c, okc);
+        e2[i] = ldg(g.res, rowc * g.ldres + c, okc);
+        e3[i] = ldg(g.gamma, c, okc);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = l16 + 16 * i;
+        z[i] = (c < g.N) ? (z[i] + e1[i]) * gt_drop_mul(g.drop, dkey, (uint32_t)(rowc * g.N + c)) + e2[i] : 0.f;
+        s += z[i];
+      }
+      const float mean = gt_red16(s) * invN;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) { const int c = l16 + 16 * i; if (c < g.N) { const float d = z[i] - mean; q += d * d; } }
+      const float rstd = 1.0f / sqrtf(gt_red16(q) * invN + GT_LN_EPS);
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) e1[i] = ldg(g.beta, l16 + 16 * i, l16 + 16 * i < g.N);
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int c = l16 + 16 * i;
+          if (c < g.N) {
+            const float xh = (z[i] - mean) * rstd;
+            g.aux[(size_t)row * g.N + c] = xh;
+            g.C[(size_t)row * g.ldc + c] = xh * e3[i] + e1[i];
+          }
+        }
+        if (l16 == 0) g.aux2[row] = rstd;
+      }
+    } else {
+      const float rs = g.rstd[rowc];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {                 // phase 1: all loads
+        const int c = l16 + 16 * i;
+        const bool okc = live && c < g.N;
+        z[i] = zr[c];
+        e1[i] = ldg(g.res, rowc * g.ldres + c, okc && g.res != nullptr);
+        e2[i] = ldg(g.xhat, rowc * g.N + c, okc);
+        e3[i] = ldg(g.gamma, c, okc);
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = l16 + 16 * i;
+        const float dy = (live && c < g.N) ? z[i] + e1[i] : 0.f;
+        z[i] = dy;
+        const float gdy = dy * e3[i];
+        s1 += gdy; s2 += gdy * e2[i];
+        dg[i] += dy * e2[i]; db[i] += dy;
+      }
+      const float m1 = gt_red16(s1) * invN, m2 = gt_red16(s2) * invN;
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int c = l16 + 16 * i;
+          if (c < g.N) {
+            const float dz = rs * (z[i] * e3[i] - m1 - e2[i] * m2);
+            g.C[(size_t)row * g.ldc + c] = dz;
+            if (g.C2) g.C2[(size_t)row * g.ldc + c] = dz * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + c));
+          }
+        }
+      }
+    }
+  }
+  if (EPI == EPI_RES_LNBWD) {
+    // dgamma/dbeta: reduce the NG row groups through LDS, then ONE atomic per column per workgroup
+    __syncthreads();
+    float* sG = smem;
+    float* sBt = smem + NG * CSTR;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = l16 + 16 * i;
+      sG[grp * CSTR + c] = dg[i];
+      sBt[grp * CSTR + c] = db[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < g.N; c += NT) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) { a += sG[q * CSTR + c]; b += sBt[q * CSTR + c]; }
+      if (g.ln_part) {       // 128+ workgroups adding into the same d addresses serialise at the atomic unit (~6 us):
+        g.ln_part[((size_t)by * 2) * g.N + c] = a;             // store partials, ln_param_reduce_kernel sums them later
+        g.ln_part[((size_t)by * 2 + 1) * g.N + c] = b;
+      } else {
+        atomicAdd(&g.dgamma[c], a);
+        atomicAdd(&g.dbeta[c], b);
+      }
+    }
+  }
+}
+
 template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI, int PREC = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, float* smem) {
   typedef GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI, PREC> Cfg;
@@ -536,117 +661,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
           make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
   __syncthreads();
 
-  constexpr int CPL = BN / 16;            // columns per lane of a 16-lane row group
-  const int grp = wave * 4 + lg;
-  const float invN = 1.0f / (float)g.N;
-  float dg[EPI == EPI_RES_LNBWD ? CPL : 1], db[EPI == EPI_RES_LNBWD ? CPL : 1];
-  if (EPI == EPI_RES_LNBWD) {
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
-  }
-
-  for (int rl = grp; rl < BM; rl += NG) {           // BM % NG == 0: the trip count is wave-uniform
-    const int row = m0 + rl;
-    const bool live = row < g.M;
-    const size_t rowc = live ? row : 0;               // clamped row for the unconditional loads
-    const float* zr = sC + rl * CSTR;
-    float z[CPL], e1[CPL], e2[CPL], e3[CPL];
-    if (EPI == EPI_RES_LN) {
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {                 // phase 1: all loads
-        const int c = l16 + 16 * i;
-        const bool okc = c < g.N;
-        z[i] = zr[c];
-        e1[i] = ldg(g.bias, c, okc);
-        e2[i] = ldg(g.res, rowc * g.ldres + c, okc);
-        e3[i] = ldg(g.gamma, c, okc);
-      }
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int c = l16 + 16 * i;
-        z[i] = (c < g.N) ? (z[i] + e1[i]) * gt_drop_mul(g.drop, dkey, (uint32_t)(rowc * g.N + c)) + e2[i] : 0.f;
-        s += z[i];
-      }
-      const float mean = gt_red16(s) * invN;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) { const int c = l16 + 16 * i; if (c < g.N) { const float d = z[i] - mean; q += d * d; } }
-      const float rstd = 1.0f / sqrtf(gt_red16(q) * invN + GT_LN_EPS);
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) e1[i] = ldg(g.beta, l16 + 16 * i, l16 + 16 * i < g.N);
-      if (live) {
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-          const int c = l16 + 16 * i;
-          if (c < g.N) {
-            const float xh = (z[i] - mean) * rstd;
-            g.aux[(size_t)row * g.N + c] = xh;
-            g.C[(size_t)row * g.ldc + c] = xh * e3[i] + e1[i];
-          }
-        }
-        if (l16 == 0) g.aux2[row] = rstd;
-      }
-    } else {
-      const float rs = g.rstd[rowc];
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {                 // phase 1: all loads
-        const int c = l16 + 16 * i;
-        const bool okc = live && c < g.N;
-        z[i] = zr[c];
-        e1[i] = ldg(g.res, rowc * g.ldres + c, okc && g.res != nullptr);
-        e2[i] = ldg(g.xhat, rowc * g.N + c, okc);
-        e3[i] = ldg(g.gamma, c, okc);
-      }
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int c = l16 + 16 * i;
-        const float dy = (live && c < g.N) ? z[i] + e1[i] : 0.f;
-        z[i] = dy;
-        const float gdy = dy * e3[i];
-        s1 += gdy; s2 += gdy * e2[i];
-        dg[i] += dy * e2[i]; db[i] += dy;
-      }
-      const float m1 = gt_red16(s1) * invN, m2 = gt_red16(s2) * invN;
-      if (live) {
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-          const int c = l16 + 16 * i;
-          if (c < g.N) {
-            const float dz = rs * (z[i] * e3[i] - m1 - e2[i] * m2);
-            g.C[(size_t)row * g.ldc + c] = dz;
-            if (g.C2) g.C2[(size_t)row * g.ldc + c] = dz * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + c));
-          }
-        }
-      }
-    }
-  }
-  if (EPI == EPI_RES_LNBWD) {
-    // dgamma/dbeta: reduce the NG row groups through LDS, then ONE atomic per column per workgroup
-    __syncthreads();
-    float* sG = smem;
-    float* sBt = smem + NG * CSTR;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      const int c = l16 + 16 * i;
-      sG[grp * CSTR + c] = dg[i];
-      sBt[grp * CSTR + c] = db[i];
-    }
-    __syncthreads();
-    for (int c = tid; c < g.N; c += NT) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int q = 0; q < NG; ++q) { a += sG[q * CSTR + c]; b += sBt[q * CSTR + c]; }
-      if (g.ln_part) {       // 128+ workgroups adding into the same d addresses serialise at the atomic unit (~6 us):
-        g.ln_part[((size_t)by * 2) * g.N + c] = a;             // store partials, ln_param_reduce_kernel sums them later
-        g.ln_part[((size_t)by * 2 + 1) * g.N + c] = b;
-      } else {
-        atomicAdd(&g.dgamma[c], a);
-        atomicAdd(&g.dbeta[c], b);
-      }
-    }
-  }
+  gemm_row_epilogue<BM, BN, NT, EPI>(g, m0, by, smem);
 }
 
 // 128x128 tiles: ask for two waves per SIMD (<= 256 registers) so that two workgroups share a CU and one's prologue, barriers
@@ -908,8 +923,20 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
 #endif
 // wide rows (d_model > 128) go on to 64-row tiles when even those fill the chip: per flop they stage half the weight bytes
 static inline int gemm_row_bm(int M, int N) { return M < GT_ROW_BM32_MIN ? 16 : (N > 128 && M >= GT_ROW_BM64_MIN) ? 64 : 32; }
+static inline bool gemm32row_ok(const GemmArgs& g, bool bkm);
+template <bool BKM, int EPI>
+static inline void gemm32row_launch(const GemmArgs& g, hipStream_t s);
+#ifndef GT_ROW32_MIN_M
+#define GT_ROW32_MIN_M 8192     /* the ring-body row tiles (gt_gemm32.h) from this many tokens: 256 / 128 workgroups of 32 / 64 rows */
+#endif
+// rows per workgroup of the row-fused launch of g (the LayerNorm-backward partials table has one row per workgroup)
+static inline int gemm_row_rows(const GemmArgs& g, bool bkm) {
+  if (g.M >= GT_ROW32_MIN_M && gemm32row_ok(g, bkm)) return (g.N == 512 || g.M / 64 >= 256) ? 64 : 32;
+  return gemm_row_bm(g.M, g.N);
+}
 template <bool AKM, bool BKM, int EPI>
 static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
+  if constexpr (!AKM) { if (g.M >= GT_ROW32_MIN_M && gemm32row_ok(g, BKM)) { gemm32row_launch<BKM, EPI>(g, s); return 0; } }
   const int bm = gemm_row_bm(g.M, g.N);
   const bool small = bm == 16;
   if (g.N <= 32) {

@@ -272,6 +272,119 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
 #undef G32_SLAB
 }
 
+// ================================================================================================================ row-owning tiles
+// Round 3: the LayerNorm-fused Linears (EPI_RES_LN / EPI_RES_LNBWD of gt_gemm.h: the workgroup owns WHOLE rows) on the ring body.
+// The one-deep 16x16x4 row tiles ran at 35 % (d_model 256) / 52-65 % (512) of the MFMA peak: 256 VGPR + 130 AGPR at one wave per
+// SIMD, no prefetch distance.  Here: v_mfma_f32_32x32x2_f32, 8 waves (2 per SIMD), BMW x (8 / BMW) waves of 32 x (32 NB) columns,
+// BK = 16 slabs double-buffered in LDS with the next-but-one slab in registers (the two-deep ring of gemm32_body), then the
+// accumulators go through LDS ([BM][BN + 4], over the operand buffers) into gemm_row_epilogue -- the same arithmetic, in the same
+// order per row, as the tiles they replace.  BN = d_model (256 or 512), interior only: M % BM == 0, K % 32 == 0, 16-byte rows.
+template <int BN, int BMW> struct Gemm32RowCfg {
+  static constexpr int BM = 32 * BMW, BK = 16, NT = 512, WN = 8 / BMW, NB = BN / (32 * WN);      // NB 32-column fragments per wave
+  template <bool KM> static constexpr int bstr() { return KM ? BN + 4 : BK + 4; }
+  template <bool KM> static constexpr int bsz() { return KM ? BK * (BN + 4) : BN * (BK + 4); }
+  static constexpr int ASTR = BK + 4, ASZ = BM * ASTR;
+  template <bool KM> static constexpr int main_sz() { return 2 * (ASZ + bsz<KM>()); }
+  // epilogue: the [BM][BN + 4] accumulator image; the LayerNorm backward re-uses it for 2 x (NT / 16) rows of dgamma / dbeta partials
+  template <int EPI> static constexpr int epi_sz() { return ((EPI == EPI_RES_LNBWD && 2 * (NT / 16) > BM) ? 2 * (NT / 16) : BM) * (BN + 4); }
+  template <bool KM, int EPI> static constexpr int smem() { return main_sz<KM>() > epi_sz<EPI>() ? main_sz<KM>() : epi_sz<EPI>(); }
+};
+template <int BN, int BMW, bool BKM, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm32row_kernel(GemmArgs g) {
+  typedef Gemm32RowCfg<BN, BMW> Cfg;
+  constexpr int BM = Cfg::BM, BK = Cfg::BK, NT = Cfg::NT, WN = Cfg::WN, NB = Cfg::NB;
+  constexpr int ASTR = Cfg::ASTR, ASZ = Cfg::ASZ, BSTR = Cfg::template bstr<BKM>(), BSZ = Cfg::template bsz<BKM>();
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::template smem<BKM, EPI>()];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int by = blockIdx.x, m0 = by * BM;
+  // staging: A = BM x 16 floats per slab (BM * 4 float4: the first BM * 4 threads take one each); B = BN x 16 floats = BN * 4 float4
+  constexpr int PB = BN * 4 / NT;                              // float4 of B per thread and slab (2 at 256, 4 at 512)
+  const bool has_a = tid < BM * 4;
+  const char* pa = reinterpret_cast<const char*>(g.A + (size_t)(m0 + (has_a ? tid >> 2 : 0)) * g.lda + (tid & 3) * 4);
+  const int sa_off = (tid >> 2) * ASTR + (tid & 3) * 4;
+  const char* pb[PB];
+  int sb_off[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int ch = tid + i * NT;
+    if (BKM) { const int kr = ch / (BN / 4), cn = (ch % (BN / 4)) * 4; pb[i] = reinterpret_cast<const char*>(g.B + (size_t)kr * g.ldb + cn); sb_off[i] = kr * BSTR + cn; }
+    else { const int r = ch >> 2, c = (ch & 3) * 4; pb[i] = reinterpret_cast<const char*>(g.B + (size_t)r * g.ldb + c); sb_off[i] = r * BSTR + c; }
+  }
+  const size_t bstep = BKM ? (size_t)g.ldb * 4 : 4;            // bytes per k
+  f32x4 va, wa, vb[PB], wb[PB];
+#define G32R_LD(XA, XB, k0)                                                                    \
+  XA = has_a ? *reinterpret_cast<const f32x4*>(pa + (size_t)(k0) * 4) : f32x4{0.f, 0.f, 0.f, 0.f}; \
+  _Pragma("unroll") for (int i = 0; i < PB; ++i) XB[i] = *reinterpret_cast<const f32x4*>(pb[i] + (size_t)(k0) * bstep);
+#define G32R_ST(XA, XB, buf)                                                                   \
+  if (has_a) *reinterpret_cast<f32x4*>(&smem[(buf) * ASZ + sa_off]) = XA;                      \
+  _Pragma("unroll") for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(&smem[2 * ASZ + (buf) * BSZ + sb_off[i]]) = XB[i];
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const int offa = (wm * 32 + r32) * ASTR + 4 * h;
+  const int offb = 2 * ASZ + (BKM ? (4 * h) * BSTR + wn * (32 * NB) + r32 : (wn * (32 * NB) + r32) * BSTR + 4 * h);
+  // one slab = two 8-k groups; fragment element j of lane half h is k = 4 h + j of the group, for A and B alike (gemm32_body)
+#define G32R_SLAB(CUR)                                                                         \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                           \
+    const f32x4 fa = *reinterpret_cast<const f32x4*>(smem + (CUR) * ASZ + offa + kk * 8);      \
+    f32x4 fb[NB];                                                                              \
+    _Pragma("unroll") for (int t = 0; t < NB; ++t) {                                           \
+      if (BKM) { _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[t][j] = smem[(CUR) * BSZ + offb + (kk * 8 + j) * BSTR + 32 * t]; } \
+      else fb[t] = *reinterpret_cast<const f32x4*>(smem + (CUR) * BSZ + offb + (32 * t) * BSTR + kk * 8); \
+    }                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+    _Pragma("unroll") for (int t = 0; t < NB; ++t) acc[t] = GT_MFMA32(fb[t][j], fa[j], acc[t]); \
+  }
+  const int nk = g.K / BK;                                     // even (K % 32 == 0)
+  G32R_LD(va, vb, 0)
+  G32R_LD(wa, wb, BK)
+  G32R_ST(va, vb, 0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    { const int k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * BK; G32R_LD(va, vb, k2) }       // slab kt + 2 (va / vb are free: slab kt is in LDS)
+    G32R_SLAB(0)
+    G32R_ST(wa, wb, 1)                                                                   // slab kt + 1 -> the other buffer
+    __syncthreads();
+    { const int k3 = (kt + 3 < nk ? kt + 3 : nk - 1) * BK; G32R_LD(wa, wb, k3) }
+    G32R_SLAB(1)
+    G32R_ST(va, vb, 0)
+    __syncthreads();
+  }
+#undef G32R_LD
+#undef G32R_ST
+#undef G32R_SLAB
+  // accumulators -> sC[BM][BN + 4] (transposed product: lane (r32, h) holds ONE row per 32x32 tile, registers 4 q .. 4 q + 3 = the
+  // four consecutive columns 8 q + 4 h + 0..3), then the shared row epilogue
+  constexpr int CSTR = BN + 4;
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      *reinterpret_cast<f32x4*>(&smem[(wm * 32 + r32) * CSTR + wn * (32 * NB) + 32 * t + 8 * q4 + 4 * h]) =
+          f32x4{acc[t][4 * q4], acc[t][4 * q4 + 1], acc[t][4 * q4 + 2], acc[t][4 * q4 + 3]};
+  __syncthreads();
+  gemm_row_epilogue<BM, BN, NT, EPI>(g, m0, by, smem);
+}
+// host side: does this row-fused Linear qualify, and which instance
+static inline bool gemm32row_ok(const GemmArgs& g, bool bkm) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (g.bf16 || (g.N != 256 && g.N != 512) || g.K % 32 || g.K < 32 || g.M % 64) return false;
+  if ((g.lda & 3) || (g.ldb & 3) || !al16(g.A) || !al16(g.B)) return false;
+  (void)bkm;
+  return true;
+}
+template <bool BKM, int EPI>
+static inline void gemm32row_launch(const GemmArgs& g, hipStream_t s) {
+  gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + 3.0 * g.M * g.N));
+  // 64-row tiles once they fill the chip (one workgroup per CU at d_model 512: 132 KB of LDS); 32-row tiles below that at 256
+  if (g.N == 512) gt_launch(gemm32row_kernel<512, 2, BKM, EPI>, dim3(g.M / 64), dim3(512), s, g);
+  else if (g.M / 64 >= 256) gt_launch(gemm32row_kernel<256, 2, BKM, EPI>, dim3(g.M / 64), dim3(512), s, g);
+  else gt_launch(gemm32row_kernel<256, 1, BKM, EPI>, dim3(g.M / 32), dim3(512), s, g);
+}
+
 template <bool BKM, int EPI, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[Gemm32Cfg::smem<false, BKM>()];
