@@ -705,7 +705,7 @@ extern "C" int gt_step_launches(const gt_config* cfg) {
   if (!use_seq(*cfg)) return 0;
   // (with GT_STEP_PACKS_CURRENT one less: no packing launch)
   if (!seq_split(*cfg)) return 7;
-  return 2 * (cfg->n_enc_layers + 1) + (seq_ride(*cfg) ? 3 : 5);   // pack, phases, [grouped weight gradients x 2,] reduce / tail, update
+  return 2 * cfg->n_enc_layers + 1 + (seq_ride(*cfg) ? 3 : 5);   // pack, L forward + L + 1 backward phases, [grouped weight gradients x 2,] reduce / tail, update
 }
 static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hvo) {
   SeqArgs a;
@@ -750,7 +750,7 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
   const int hc = x.hd < 16 ? 0 : x.hd;             // head-dim class (one instantiation each: the attention bodies' registers differ 4x)
   if (seq_split(x.c)) {
     const dim3 grid(2 * x.c.batch);
-    for (int p = 0; p <= x.c.n_enc_layers; ++p) {
+    for (int p = 0; p < x.c.n_enc_layers; ++p) {               // one launch per encoder layer (gt_seq.h, SPLIT)
       SeqArgs ap = a;
       ap.phase = p;
       if (p > 0) gt_prof_tag("seq_fwd", 0.0, 0.0);          // (flops and bytes of the whole forward are on the first phase's tag)

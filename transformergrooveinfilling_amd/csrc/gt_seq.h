@@ -34,6 +34,7 @@
 // head_dim 16 / 32 / 64 or < 16 (seq_supported in groove_hip.hip).
 #pragma once
 #include "gt_seq_api.h"
+#include <type_traits>
 
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md 7): workgroup 0, thread 0 records the shader clock at stage
 // boundaries into a buffer nothing else reads.  tools/seq_stamps.py prints the per-stage cycle counts.
@@ -898,9 +899,15 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   };
 
   // ---- input layer: a0 = x Win^T + b; x0 = drop(relu(a0) + pe)     (A tile: the own input rows, zero-padded to 32 columns)
-  auto input_layer = [&]() {
-    for (int e = tid; e < NROW * 32; e += GT_SEQ_NT) {
-      const int r = rb + (e >> 5), c = e & 31;
+  // (all_tag: std::true_type = ALL 32 rows of the sequence even in a SPLIT workgroup -- the first SPLIT phase computes the input layer and
+  //  layer 0's in-proj for the partner's rows too instead of waiting a launch for them: the weight fragments, which bound these stages,
+  //  are streamed once either way)
+  auto input_layer = [&](auto all_tag) {
+    constexpr bool HF = HALF && !decltype(all_tag)::value;    // 16 own rows, or all 32
+    constexpr int NHX = HF ? 1 : 2, NRX = HF ? 16 : 32;
+    const int rbx = HF ? rb : 0;
+    for (int e = tid; e < NRX * 32; e += GT_SEQ_NT) {
+      const int r = rbx + (e >> 5), c = e & 31;
       sC[r * SX + c] = *(c < a.S ? a.xin + (r0 + r) * a.S + c : zp);
     }
     GT_BARRIER();
@@ -908,11 +915,11 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     const uint32_t key = seq_key(dk, GT_SITE_PE_ENC);
     float* ga0 = ws + a.a0 + r0 * d;
     float* gx0 = ws + a.x0 + r0 * d;
-    seq_mm_edge<false, false, 2, HALF>(sC + rb * SX, SX, a.S, prm + a.in_w, a.S, d, prm + a.in_b, wave, lane, zp,
-                                       [&](int n0, const f32x4& c0, const f32x4& c1, const float (&bi)[4]) {
+    seq_mm_edge<false, false, 2, HF>(sC + rbx * SX, SX, a.S, prm + a.in_w, a.S, d, prm + a.in_b, wave, lane, zp,
+                                     [&](int n0, const f32x4& c0, const f32x4& c1, const float (&bi)[4]) {
 #pragma unroll
-      for (int h2 = 0; h2 < NH; ++h2) {
-        const int row = rb + 16 * h2 + l16, col = n0 + 4 * lg;
+      for (int h2 = 0; h2 < NHX; ++h2) {
+        const int row = rbx + 16 * h2 + l16, col = n0 + 4 * lg;
         const f32x4& c = h2 ? c1 : c0;
         const float4 pe = *reinterpret_cast<const float4*>(a.pe + row * d + col);
         const unsigned o = (unsigned)(row * d + col);
@@ -922,23 +929,27 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         v.y = (fmaxf(pre.y, 0.f) + pe.y) * seq_dmul(dk, key, idxd + o + 1);
         v.z = (fmaxf(pre.z, 0.f) + pe.z) * seq_dmul(dk, key, idxd + o + 2);
         v.w = (fmaxf(pre.w, 0.f) + pe.w) * seq_dmul(dk, key, idxd + o + 3);
-        *reinterpret_cast<float4*>(ga0 + o) = pre;
-        *reinterpret_cast<float4*>(gx0 + o) = v;
+        if (!HALF || HF || (row >= rb && row < rb + 16)) {     // saved for the backward: every row once (its owner)
+          *reinterpret_cast<float4*>(ga0 + o) = pre;
+          *reinterpret_cast<float4*>(gx0 + o) = v;
+        }
         *reinterpret_cast<float4*>(&sX[row * SX + col]) = v;
       }
     });
     GT_BARRIER();
   };
   // ---- in-proj of layer l: qkv = x Win^T + b -> the LDS qkv tile (own rows); ends with a barrier
-  auto in_proj = [&](const int l) {
+  auto in_proj = [&](const int l, auto all_tag) {
+    constexpr bool HF = HALF && !decltype(all_tag)::value;
+    const int rbx = HF ? rb : 0;
     const float* pl = prm + (int64_t)l * a.pstride;
     const float* kf = ws + a.pack_f + (int64_t)l * a.kstride;
     GT_STAMP(2 + 10 * l);
-    seq_mm_tiles<NK, (3 * DP / 16 + 7) / 8, EXACT, HALF>(sX + rb * SX, SX, d, kf, 3 * d, pl + a.p0.in_b, wave, lane,
-                                                          [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
+    seq_mm_tiles<NK, (3 * DP / 16 + 7) / 8, EXACT, HF>(sX + rbx * SX, SX, d, kf, 3 * d, pl + a.p0.in_b, wave, lane,
+                                                        [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
       const int col = n0 + 4 * lg;
-      *reinterpret_cast<float4*>(&sQ[(rb + l16) * SQ + col]) = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
-      if (!HALF) *reinterpret_cast<float4*>(&sQ[(16 + l16) * SQ + col]) = make_float4(c1[0] + bi.x, c1[1] + bi.y, c1[2] + bi.z, c1[3] + bi.w);
+      *reinterpret_cast<float4*>(&sQ[(rbx + l16) * SQ + col]) = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
+      if (!HF) *reinterpret_cast<float4*>(&sQ[(16 + l16) * SQ + col]) = make_float4(c1[0] + bi.x, c1[1] + bi.y, c1[2] + bi.z, c1[3] + bi.w);
     });
     GT_BARRIER();
     GT_STAMP(2 + 10 * l + 1);
@@ -1115,33 +1126,37 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   GT_SUBSET(false);
   GT_BARRIER();
 #endif
+  typedef std::true_type AllRows;
+  typedef std::false_type OwnRows;
   if (!SPLIT) {
     GT_STAMP(0);
-    input_layer();
-    for (int l = 0; l < a.L; ++l) { in_proj(l); layer_rest(l, true); }
+    input_layer(OwnRows{});
+    for (int l = 0; l < a.L; ++l) { in_proj(l, OwnRows{}); layer_rest(l, true); }
     output_layer();
     GT_STAMP(2 + 10 * a.L);
-  } else if (a.phase == 0) {
-    GT_STAMP(60);
-    input_layer();
-    in_proj(0);
-    seq_tile_out(ws + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
-    GT_STAMP(61);
   } else {
-    const int l = a.phase - 1;
-    GT_STAMP(60 + 2 * a.phase);
-    load_rows(sX, SX, (l == 0 ? ws + a.x0 : ws + (int64_t)(l - 1) * a.wstride + a.w0.xout) + r0 * d, d, rb, NROW);   // own rows of the layer input
-    load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                          // q / k / v of the whole sequence
-    GT_BARRIER();
+    // SPLIT phase l (one launch per encoder layer): [phase 0: input layer + in-proj(0) for ALL rows | else: the layer input's own rows and
+    // the whole sequence's q / k / v from the workspace], attention .. norm2 of layer l on the own rows, then in-proj(l + 1) of the own
+    // rows (saved: the next launch's operands) or the output layer + loss
+    const int l = a.phase;
+    GT_STAMP(60 + 2 * (l + 1));
+    if (l == 0) {
+      input_layer(AllRows{});
+      in_proj(0, AllRows{});
+    } else {
+      load_rows(sX, SX, ws + (int64_t)(l - 1) * a.wstride + a.w0.xout + r0 * d, d, rb, NROW);                      // own rows of the layer input
+      load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                          // q / k / v of the whole sequence
+      GT_BARRIER();
+    }
     GT_STAMP(2 + 10 * l + 1);
-    layer_rest(l, false);
+    layer_rest(l, l == 0);
     if (l + 1 < a.L) {
-      in_proj(l + 1);
+      in_proj(l + 1, OwnRows{});
       seq_tile_out(ws + (int64_t)(l + 1) * a.wstride + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
     } else {
       output_layer();
     }
-    GT_STAMP(61 + 2 * a.phase);
+    GT_STAMP(61 + 2 * (l + 1));
   }
 }
 
