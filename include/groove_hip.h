@@ -215,7 +215,8 @@ int gt_debug_seq_wg_phase(const gt_config* cfg, const float* params, float* grad
  * step is reproducible already (fixed-order reductions).  Off by default: the small shapes lose their token parallelism
  * (env GT_DETERMINISTIC=1 does the same). */
 int gt_set_deterministic(int on);
-/* Kernel launches of one gt_train_step for this configuration when it runs on the sequence-resident path (7 ... 2 L + 7), 0 when
+/* Kernel launches of one gt_train_step for this configuration when it runs on the sequence-resident path (7 whole-sequence; SPLIT: 2 L + 4 with rider weight gradients, 2 L + 6
+ * without; one less with GT_STEP_PACKS_CURRENT), 0 when
  * it runs one kernel per operation (dozens to hundreds).  A host that replays the step as a captured hipGraph can use it to
  * decide: measured on MI355X / ROCm 7.2 a 12-launch step is 2 % FASTER enqueued directly (0.241 vs 0.246 ms) -- the graph costs
  * ~0.4 us per node, and at this count the host stays ahead of the GPU by itself. */

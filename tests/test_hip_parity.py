@@ -225,6 +225,24 @@ def test_random_odd_shapes():
     assert fuzz_parity.run(20, seed=11, verbose=False) == 0
 
 
+@pytest.mark.parametrize("B,S", [(64, 16), (17, 27), (80, 16)])
+def test_rider_path_repeats_bit_for_bit_by_default(B, S):
+    """SPLIT phases with rider weight gradients (gt_seq_wg.h): one owner per gradient tile (two partial tiles commuting onto zero in the tail)
+    -> a run of train steps repeats bit for bit WITHOUT gt_set_deterministic; the packs folded into the update (GT_STEP_PACKS_CURRENT) too."""
+    cfgp = dict(C2, dropout=0.24, embedding_size_src=S)
+    P = ng.init_params(cfgp, seed=2)
+    x, y = ng.synthetic_batch(B, S, seed=77)
+    runs = []
+    for _ in range(3):
+        r = Runner(cfgp, B, "hip", rng=(9, 4, 0), lr=0.05, seq="split")
+        assert len(r.lib.grad_buckets(r.c)) == 2                       # (riders on: the backward has two gradient buckets)
+        r.set_params(P)
+        for step in range(5):
+            r.train_step(x, y, 0.4, skip_update=4 if step else 0)
+        runs.append(r.params.numpy().copy())
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+
+
 @pytest.mark.parametrize("cfg,B,p,seq", [(C2, 64, 0.24, True), (C2, 64, 0.24, False), (cfg_dict(256, 2, 512, 2), 32, 0.3, True),
                                          (ENCDEC, 16, 0.2, True)])
 def test_deterministic_weight_gradients_repeat_bit_for_bit(cfg, B, p, seq):

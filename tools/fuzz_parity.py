@@ -39,7 +39,9 @@ def run(n, seed, backend="hip", verbose=True):
             parity.check_predict(backend, cfg, min(B, 4), True)
             # the sequence-resident kernels (csrc/gt_seq.h) run the whole backward in one launch: a single gradient bucket
             seq = Ld == 0 and d % 16 == 0 and d <= 128 and F % 16 == 0 and F <= 512 and S <= 32 and (hd < 16 or hd in (16, 32, 64))
-            parity.check_bucketed_backward(backend, cfg, min(B, 8), p, 2 if (Ld or L >= 2) and not seq else 1, exact=False)
+            nbk = len(parity.Runner(cfg, min(B, 8), backend).lib.grad_buckets(parity.Runner(cfg, min(B, 8), backend).c))   # (riders: 2 at d_model 128)
+            assert nbk == (2 if (Ld or L >= 2) and not seq else 1) or (seq and d == 128)
+            parity.check_bucketed_backward(backend, cfg, min(B, 8), p, nbk, exact=False)
             if verbose:
                 print("ok   %-40s %.1fs" % (tag, time.time() - t0), flush=True)
         except Exception as e:  # noqa: BLE001
@@ -48,12 +50,43 @@ def run(n, seed, backend="hip", verbose=True):
     return fails
 
 
+def run_riders(n, seed, backend="hip", verbose=True):
+    """d_model-128 shapes through the SPLIT phases with rider weight gradients (gt_seq_wg.h): odd batches (odd slab counts per wave),
+    dim_feedforward with partial column tiles, 27- / 5-wide inputs (packed / scalar staging in the tail), 1-4 layers (bucket cut)."""
+    rnd = random.Random(1000 + seed)
+    fails = 0
+    for k in range(n):
+        H = rnd.choice([2, 4, 8, 16, 32])
+        F = rnd.choice([16, 48, 64, 112, 128, 320, 512])
+        L = rnd.choice([1, 2, 3, 4])
+        B = rnd.choice([1, 2, 3, 5, 9, 17, 33, 64, 80])
+        S = rnd.choice([16, 27, 5])
+        p = rnd.choice([0.0, 0.1, 0.3])
+        mode = rnd.choice(["split", "split", "split-noride", True])
+        cfg = cfg_dict(128, H, F, L, 0, embedding_size_src=S)
+        tag = "riders d128 H%d F%d L%d B%d S%d p%.1f %s" % (H, F, L, B, S, p, mode)
+        t0 = time.time()
+        try:
+            r, _, _, _ = parity.check_step(backend, cfg, B, p, seed=k, seq=mode)
+            nb = len(r.lib.grad_buckets(r.c))
+            parity.check_train_step(backend, cfg, min(B, 16), p, seq=mode)
+            parity.check_bucketed_backward(backend, cfg, min(B, 16), p, nb if B <= 16 else len(parity.Runner(cfg, min(B, 16), backend, seq=mode).lib.grad_buckets(
+                parity.Runner(cfg, min(B, 16), backend, seq=mode).c)), exact=False, seq=mode)
+            if verbose:
+                print("ok   %-50s %d buckets %.1fs" % (tag, nb, time.time() - t0), flush=True)
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print("FAIL %-50s %s: %s" % (tag, type(e).__name__, str(e)[:200]), flush=True)
+    return fails
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=24)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--riders", action="store_true", help="d_model-128 SPLIT / rider shapes only")
     args = ap.parse_args()
-    fails = run(args.n, args.seed)
+    fails = run_riders(args.n, args.seed) if args.riders else run(args.n, args.seed)
     print("failures:", fails)
     sys.exit(1 if fails else 0)
 

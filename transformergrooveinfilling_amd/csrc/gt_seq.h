@@ -28,7 +28,9 @@
 // d_model 128, dim_feedforward 512) a sequence's layer is ~13 MFLOP: the matmul stages are bound by the fp32 MFMA rate of the
 // ONE CU the workgroup runs on (256 FLOP/clk), the whole step is 7 launches instead of 49.  While twice the batch fits the CUs the
 // SPLIT instantiations take over there: two workgroups per sequence, 16 token rows each, one launch per phase (see seq_fwd_kernel) --
-// 12 launches, twice the CUs.  In gt_train_step the launch that runs the output layer also computes the loss (fused tail).
+// twice the CUs; round 3: the weight gradients ride in the backward phases' launches on the CUs that are still idle (gt_seq_wg.h) and
+// the update writes the next step's weight packs: 9 launches per step.  In gt_train_step the launch that runs the output layer also
+// computes the loss (fused tail).
 //
 // Supported: encoder-only, fp32 operands, d_model % 16 == 0 and <= 128, dim_feedforward % 16 == 0 and <= 512, src_dim <= 32,
 // head_dim 16 / 32 / 64 or < 16 (seq_supported in groove_hip.hip).
@@ -868,6 +870,7 @@ template <int DP> struct SeqGeo {
 // launch picks its state up from the saved-activation buffers the backward needs anyway.  phase 0: input layer + in-proj(0);
 // phase l + 1: attention(l) .. norm2(l), then in-proj(l + 1) or the output layer.  2 x batch workgroups fill twice the CUs: the
 // path for small batches of the d_model-128 class, where a sequence's matmuls are bound by the MFMA rate of one CU.
+// (Round 3: phase 0 and phase 1 are ONE launch -- the first phase computes input layer + in-proj(0) for all 32 rows; a.phase = layer.)
 template <int DP, int HDC, bool EXACT, bool SPLIT>
 __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   using G = SeqGeo<DP>;

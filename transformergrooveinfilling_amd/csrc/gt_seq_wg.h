@@ -11,14 +11,16 @@
 // Unit of work: one 32 x 64 tile of dW = dY^T X over a token range, by ONE workgroup:
 //   * the 8 waves split the tokens (wave w takes the 8-token slabs w, w + 8, ...), each with its own accumulators and its own
 //     double-buffered LDS staging area: no workgroup barrier inside the contraction;
-//   * staging: 16-byte line-shaped global loads (a slab row of dY / X is 128 / 256 contiguous bytes), three slabs in flight in
+//   * staging: 16-byte line-shaped global loads (a slab row of dY / X is 128 / 256 contiguous bytes), GT_WG_DEPTH slabs in flight in
 //     registers; fragments for v_mfma_f32_32x32x2_f32 are conflict-free ds_read_b32 rows (lanes 0-31: token k, lanes 32-63: k + 1);
 //   * the 8 partial tiles meet in LDS and are summed in a fixed order: with one owner per tile over ALL tokens the gradient needs no
 //     atomics and is bitwise reproducible -- the default now, not an opt-in mode;
 //   * bias gradients are the column sums of the dY fragments the MFMAs consume anyway (units of the first column tile).
-// What cannot ride (the in-proj of layer 0 and the input layer: their operands appear in the last phase) runs in seq_tail_kernel on
-// the whole chip, together with the LayerNorm dgamma / dbeta reduction and the step-counter bump -- there the token range is split
-// over workgroups and the partial tiles meet in fp32 atomics (one owner per tile under gt_set_deterministic).
+// The LayerNorm dgamma / dbeta reductions ride as units too (one phase after the partials were written).  What cannot ride -- the
+// in-proj of layer 0 and the input layer (their operands appear in the last phase), the 27-wide output layer (packed staging form) --
+// runs in seq_tail_kernel on the whole chip, together with the second half of the last phase's tiles and the step-counter bump;
+// there a tile's token range is cut in two and the two partial tiles meet in fp32 atomics on the zeroed gradient (order-independent).
+// After backward phase p < L everything from encoder layer L - p + 1 to the end of the parameter buffer is final: gradient buckets.
 #pragma once
 #include "gt_seq_api.h"
 
