@@ -163,6 +163,11 @@ int gt_train_step(const gt_config* cfg, int algo, float* params, float* grads, f
 int gt_predict(const gt_config* cfg, const float* params, const float* pe, const float* x,
                float* hvo_out, float thres, int use_thres, float* tgt_scratch, float* ws,
                gt_stream_t stream);
+/* model.predict(src, use_pd=True): as gt_predict, but the hits are SAMPLED from the predicted probabilities: h = 1 iff p > u with
+ * u = (fmix32((idx * 0x9E3779B1) ^ seed) >> 8) * 2^-24, idx = (row * 27 + voice column) of hvo_out (the hash of the dropout masks,
+ * shared with oracle/numpy_groove.py).  The encoder-decoder's greedy decode feeds the sampled hits back. */
+int gt_predict_pd(const gt_config* cfg, const float* params, const float* pe, const float* x, float* hvo_out, uint32_t seed,
+                  float* tgt_scratch, float* ws, gt_stream_t stream);
 
 /* Replaces, for the device side, what the reference's evaluator computes from model.predict's output per epoch
  * (ref:evaluator.py:522-525: get_hits_accuracies / get_velocity_errors / get_micro_timing_errors over the 9 voices of

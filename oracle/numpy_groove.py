@@ -441,16 +441,28 @@ def adam_step(P, G, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     return out, m2, v2
 
 
-def predict(P, cfg, x, use_thres=True, thres=0.5, dtype=np.float32):
+def pd_uniforms(seed, B):
+    """use_pd sampling: u[b, t, j] = (fmix32((idx * 0x9E3779B1) ^ seed) >> 8) * 2^-24, idx = (b * 32 + t) * 27 + j -- the counter hash of
+    the dropout masks (include/groove_hip.h, gt_predict_pd)."""
+    m = np.uint64(0xFFFFFFFF)
+    idx = (np.arange(B * T, dtype=np.uint64)[:, None] * np.uint64(27) + np.arange(NV, dtype=np.uint64)[None, :]) & m
+    h = _fmix32(((idx * np.uint64(0x9E3779B1)) & m) ^ np.uint64(seed & 0xFFFFFFFF))
+    return ((h >> np.uint64(8)).astype(np.float64) / 16777216.0).reshape(B, T, NV)
+
+
+def predict(P, cfg, x, use_thres=True, thres=0.5, dtype=np.float32, pd_seed=None):
     """eval-mode forward + threshold (ref:evaluator.py:173).  Encoder-decoder: greedy decode with
     tgt row 0 = zeros and row t+1 = the step-t prediction.  Returns (h,v,o) and the per-element
-    decision margin |sigmoid(logit) - thres| (for "bit-exact where the margin allows" tests)."""
+    decision margin |sigmoid(logit) - thres| (for "bit-exact where the margin allows" tests).
+    pd_seed: the hits are sampled instead (use_pd): 1 iff p > pd_uniforms(pd_seed)."""
     Ld = cfg.get("num_decoder_layers", 0)
     B = x.shape[0]
+    U = pd_uniforms(pd_seed, B) if pd_seed is not None else None
 
-    def thr(hl):
+    def thr(hl, t=None):
         pr = 1.0 / (1.0 + np.exp(-hl.astype(np.float64)))
-        return (np.where(pr > thres, 1.0, 0.0) if use_thres else pr).astype(dtype), np.abs(pr - thres)
+        cut = thres if U is None else (U if t is None else U[:, t])
+        return (np.where(pr > cut, 1.0, 0.0) if (use_thres or U is not None) else pr).astype(dtype), np.abs(pr - cut)
 
     if not Ld:
         (h, v, o), _ = forward(P, cfg, x, dtype=dtype)
@@ -461,7 +473,7 @@ def predict(P, cfg, x, use_thres=True, thres=0.5, dtype=np.float32):
     margin = np.zeros((B, T, NV))
     for t in range(T):
         (h, v, o), _ = forward(P, cfg, x, tgt=tgt, dtype=dtype)
-        hh, mg = thr(h[:, t])
+        hh, mg = thr(h[:, t], t)
         margin[:, t] = mg
         out[:, t] = np.concatenate([hh, v[:, t], o[:, t]], -1)
         if t + 1 < T:

@@ -149,8 +149,12 @@ class Runner:
                       int(skip_update), self.stream)
         return self.stats.numpy().copy()
 
-    def predict(self, x, thres=0.5, use_thres=True):
+    def predict(self, x, thres=0.5, use_thres=True, pd_seed=None):
         self.x = self.Buf(np.asarray(x, np.float32).reshape(self.M, -1))
+        if pd_seed is not None:
+            self.lib.call("gt_predict_pd", ctypes.byref(self.c), self.params.ptr, self.pe.ptr, self.x.ptr, self.hvo.ptr,
+                          ctypes.c_uint32(pd_seed), self.tgt.ptr, self.ws.ptr, self.stream)
+            return self.hvo.numpy().reshape(self.B, 32, 27).copy()
         self.lib.call("gt_predict", ctypes.byref(self.c), self.params.ptr, self.pe.ptr, self.x.ptr, self.hvo.ptr,
                       ctypes.c_float(thres), int(use_thres), self.tgt.ptr, self.ws.ptr, self.stream)
         return self.hvo.numpy().reshape(self.B, 32, 27).copy()

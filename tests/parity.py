@@ -400,7 +400,7 @@ def check_train_step(backend, cfg, B, p, algo=0, seq=True):
     assert r.step_state().step == (3 if folded else 2)
 
 
-def check_predict(backend, cfg, B, use_thres=True, thres=0.5, out_tol=OUT_TOL, margin_tol=1e-4):
+def check_predict(backend, cfg, B, use_thres=True, thres=0.5, out_tol=OUT_TOL, margin_tol=1e-4, pd_seed=None):
     """out_tol / margin_tol: the fp32 bars by default; the bf16 operand path passes its own (hits compared where the decision
     margin exceeds what a bf16 rounding flip can move a probability by)."""
     cfg = dict(cfg, dropout=0.3)      # predict is eval mode: dropout must be ignored
@@ -408,9 +408,12 @@ def check_predict(backend, cfg, B, use_thres=True, thres=0.5, out_tol=OUT_TOL, m
     x, _ = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=8)
     r = Runner(cfg, B, backend)
     r.set_params(P)
-    hvo = r.predict(x, thres=thres, use_thres=use_thres)
-    (h, v, o), margin = ng.predict(P, cfg, x, use_thres=use_thres, thres=thres, dtype=np.float64)
-    if use_thres:
+    hvo = r.predict(x, thres=thres, use_thres=use_thres, pd_seed=pd_seed)         # pd_seed: the reference's use_pd (sampled hits)
+    (h, v, o), margin = ng.predict(P, cfg, x, use_thres=use_thres, thres=thres, dtype=np.float64, pd_seed=pd_seed)
+    if pd_seed is not None:
+        frac = float(hvo[..., :9].mean())
+        assert 0.02 < frac < 0.98, frac                                            # really sampled: neither all hits nor none
+    if use_thres or pd_seed is not None:
         sure = margin > margin_tol
         if cfg.get("num_decoder_layers", 0):
             # greedy decoding: a flipped low-margin hit changes every LATER step of that sequence, so each sequence is

@@ -172,6 +172,8 @@ def test_sequence_resident_train_step_and_predict():
     parity.check_bucketed_backward("emu", cfg_dict(128, 4, 64, 2), 1, 0.0, 2, exact=True, seq="split")
     parity.check_bucketed_backward("emu", cfg_dict(128, 4, 64, 2), 2, 0.1, 1, exact=False, seq="split-noride")
     parity.check_predict("emu", cfg_dict(32, 4, 16, 2), 2, True)
+    parity.check_predict("emu", cfg_dict(32, 4, 16, 2), 3, pd_seed=12345)                 # use_pd: hits sampled on the device
+    parity.check_predict("emu", cfg_dict(32, 4, 16, 1, 1), 2, pd_seed=777)                # ... fed back through the greedy decode
 
 
 @pytest.mark.parametrize("cfg,B,p", [(ENC, 3, 0.25), (SYM, 1, 0.0), (cfg_dict(64, 4, 64, 1), 1, 0.1)])

@@ -270,6 +270,22 @@ def test_indexed_train_step_and_voice_metrics():
     assert metrics.evaluate(model, xs, ys) == m                                             # bitwise reproducible
 
 
+def test_model_predict_use_pd_on_both_model_kinds():
+    """model.predict(src, use_pd=True) (the reference's sampling mode): reproducible for a seed, different across seeds, hits in {0,1};
+    no NotImplementedError for the encoder-decoder any more"""
+    from BaseGrooveTransformers import initialize_model
+    for enc_only in (True, False):
+        model, _, _ = initialize_model(_params(enc_only=enc_only, d=32, H=4, F=16, L=2))
+        x, _ = ng.synthetic_batch(6, 16, seed=3)
+        xt = torch.from_numpy(x).cuda()
+        h1, v1, o1 = model.predict(xt, use_pd=True, pd_seed=11)
+        h2, _, _ = model.predict(xt, use_pd=True, pd_seed=11)
+        h3, _, _ = model.predict(xt, use_pd=True, pd_seed=12)
+        assert torch.equal(h1, h2) and not torch.equal(h1, h3)
+        assert set(h1.unique().tolist()) <= {0.0, 1.0} and h1.shape == (6, 32, 9) and v1.shape == o1.shape == (6, 32, 9)
+        model.predict(xt, use_pd=True)                                           # seed drawn from torch's generator
+
+
 def test_predict_walks_large_sets_in_chunks():
     """engine.predict (ref:evaluator.py:173 hands over the whole evaluation set): any chunking gives the same HVO tensor, and the
     default chunk grows with the set while the workspace fits (greedy decoding is launch-bound per call)."""

@@ -78,6 +78,13 @@ def test_predict(cfg, B, use_thres):
     parity.check_predict("hip", cfg, B, use_thres)
 
 
+@pytest.mark.parametrize("cfg,B", [(ENC, 8), (C2, 32), (ENCDEC, 5), (C3, 4)])
+def test_predict_use_pd_samples_on_the_device(cfg, B):
+    """model.predict(use_pd=True): hits sampled from the probabilities by a counter hash of the seed (gt_predict_pd), bit-exact against
+    the oracle's restatement of the hash outside the decision margin; the encoder-decoder feeds the sampled hits back"""
+    parity.check_predict("hip", cfg, B, pd_seed=987654321)
+
+
 # ---- properties at full size (BASELINE configs[1]: d128/H4/F512/L3, bs 64, dropout 0.24) ---------------
 FULL_SIZES = [(C2, 64, 0.24, 0.07),                                                      # BASELINE configs[1]
               (cfg_dict(256, 2, 512, 6, 6), 256, 0.3, 0.02),                              # configs[2]: full encoder-decoder, bs 256

@@ -1365,8 +1365,20 @@ extern "C" int gt_gather_batch(const float* xs, const float* ys, const int64_t* 
 }
 
 // ------------------------------------------------------------------------------------ predict
+static int predict_impl(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, float thres,
+                        int use_thres, uint32_t seed, float* tgt_scratch, float* ws, gt_stream_t stream);
 extern "C" int gt_predict(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, float thres,
                           int use_thres, float* tgt_scratch, float* ws, gt_stream_t stream) {
+  return predict_impl(cfg, params, pe, xin, hvo_out, thres, use_thres != 0, 0u, tgt_scratch, ws, stream);
+}
+// model.predict(src, use_pd=True): hits sampled from the predicted probabilities (see predict_head_kernel); the encoder-decoder's
+// greedy decode feeds the SAMPLED hits back, step by step
+extern "C" int gt_predict_pd(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, uint32_t seed,
+                             float* tgt_scratch, float* ws, gt_stream_t stream) {
+  return predict_impl(cfg, params, pe, xin, hvo_out, 0.5f, 2, seed, tgt_scratch, ws, stream);
+}
+static int predict_impl(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, float thres,
+                        int use_thres, uint32_t seed, float* tgt_scratch, float* ws, gt_stream_t stream) {
   Ctx x;
   if (make_ctx(x, cfg, params, nullptr, ws, nullptr, 0, stream)) return -1;
   if (!pe || !xin || !hvo_out) return gt_fail("gt_predict: pe / x / hvo_out must not be NULL");
@@ -1375,7 +1387,7 @@ extern "C" int gt_predict(const gt_config* cfg, const float* params, const float
   if (cfg->n_dec_layers == 0) {
     output_layer_fwd(x, hvo_out);
     gt_launch(predict_head_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, (const float*)hvo_out, hvo_out, (float*)nullptr,
-              thres, use_thres, -1, B);
+              thres, use_thres, -1, B, seed);
     return launch_status("gt_predict");
   }
   if (!tgt_scratch) return gt_fail("gt_predict: encoder-decoder model needs tgt_scratch");
@@ -1402,7 +1414,7 @@ extern "C" int gt_predict(const gt_config* cfg, const float* params, const float
       decoder_step(x, pe, tgt_scratch, t, tmp);
     }
     gt_launch(predict_head_kernel, dim3((B * GT_TGT + 255) / 256), dim3(256), x.s, (const float*)tmp, hvo_out, tgt_scratch, thres,
-              use_thres, t, B);
+              use_thres, t, B, seed);
   }
   return launch_status("gt_predict");
 }

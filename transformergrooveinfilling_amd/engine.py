@@ -381,7 +381,7 @@ class StepEngine:
             chunk *= 2
         return chunk
 
-    def predict(self, x, use_thres=True, thres=0.5, chunk=None):
+    def predict(self, x, use_thres=True, thres=0.5, chunk=None, pd_seed=None):
         """model.predict for ANY batch size (ref:evaluator.py:173 passes the whole evaluation set at once):
         returns a (N,32,27) HVO tensor on the device ([h | v | o], one D2H for the evaluator).  The set is walked in chunks
         of `chunk` sequences (default: predict_chunk) over one cached workspace (sized for a chunk, not for N)."""
@@ -402,6 +402,10 @@ class StepEngine:
                 tgt = torch.empty(m, 32, 27, dtype=torch.float32, device=self.device) if not self.encoder_only else None
                 self._predict_ws[m] = (cfg, ws, tgt)
             cfg, ws, tgt = self._predict_ws[m]
+            if pd_seed is not None:         # use_pd: hits sampled from the probabilities; the chunk offset keeps the streams of the chunks apart
+                self.lib.call("gt_predict_pd", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x[i:i + m]), _ptr(out[i:i + m]),
+                              ctypes.c_uint32((int(pd_seed) + 0x9E3779B9 * (i // chunk)) & 0xFFFFFFFF), _ptr(tgt), _ptr(ws), self.stream)
+                continue
             self.lib.call("gt_predict", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x[i:i + m]), _ptr(out[i:i + m]),
                           ctypes.c_float(thres), int(use_thres), _ptr(tgt), _ptr(ws), self.stream)
         for m in [k for k, (_, ws, _) in self._predict_ws.items() if 4 * ws.numel() > PREDICT_WS_KEEP]:

@@ -162,17 +162,18 @@ class _GrooveBase(nn.Module):
         n = self.embedding_size_tgt // 3
         return hvo[..., :n], hvo[..., n:2 * n], hvo[..., 2 * n:]
 
-    def predict(self, src, use_thres=True, thres=0.5, use_pd=False):
-        """eval-mode, no-grad inference (ref:evaluator.py:173): h thresholded to {0,1} (or probabilities)."""
+    def predict(self, src, use_thres=True, thres=0.5, use_pd=False, pd_seed=None):
+        """eval-mode, no-grad inference (ref:evaluator.py:173): h thresholded to {0,1} (or probabilities).
+        use_pd: hits SAMPLED from the predicted probabilities on the device (gt_predict_pd: h = 1 iff p > u, one u per (sequence, step,
+        voice) from a counter hash of pd_seed -- drawn from torch's generator when not given); the encoder-decoder feeds the sampled
+        hits back through its greedy decode."""
         self.eval()
         n = self.embedding_size_tgt // 3
         if use_pd:
-            # hits sampled from the predicted probability: h = 1 iff p > U[0,1) drawn per (step, voice)
-            if self.num_decoder_layers:
-                raise NotImplementedError("use_pd with the encoder-decoder's greedy decode is not part of the HIP path")
+            if pd_seed is None:
+                pd_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
             with torch.no_grad():
-                hvo = self.engine.predict(src, use_thres=False)
-                hvo[..., :n] = (hvo[..., :n] > torch.rand_like(hvo[..., :n])).float()
+                hvo = self.engine.predict(src, pd_seed=pd_seed)
             return hvo[..., :n], hvo[..., n:2 * n], hvo[..., 2 * n:]
         with torch.no_grad():
             hvo = self.engine.predict(src, use_thres=use_thres, thres=thres)
