@@ -478,6 +478,14 @@ static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float*
   const int nblk = (x.M + rows_per_block - 1) / rows_per_block;
   float* part = ln_job(x, gamma_off, nblk);
   gt_prof_tag("ln_bwd", 0, (res ? 16.0 : 12.0) * x.M * x.d);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (part != nullptr && (x.d == 256 || x.d == 512) && al16(dy) && al16(xhat) && al16(dz) && (!res || al16(res)) && (!x.drop || al16(dzm))) {
+    if (x.d == 512) gt_launch(ln_bwd_v4_kernel<2>, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd, x.prm + gamma_off, dz,
+                              x.drop ? dzm : (float*)nullptr, mk_drop(x, site), part, x.M, rpw);
+    else gt_launch(ln_bwd_v4_kernel<1>, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd, x.prm + gamma_off, dz,
+                   x.drop ? dzm : (float*)nullptr, mk_drop(x, site), part, x.M, rpw);
+    return;
+  }
   gt_launch(ln_bwd_kernel, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd,
             x.prm + gamma_off, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
             x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d, rpw);
