@@ -1049,7 +1049,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
         if (last_pct == 100) a.ride_last_k = M;
         fl += 2.0 * M * ((L - 1) * 3.0 * d * d + L * ((double)d * d + 2.0 * d * x.F))
               - 2.0 * (M - a.ride_last_k) * (per_layer + (L > 1 ? win : 0)) * 2048.0;
-        gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0));
+        gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0) + 4.0 * M * L * (8.0 * d + 2.0 * x.F));   // + the riders' operands, once
         // bucketed backward (data-parallel overlap): phase 1 = the launches up to the cut of grad_split, phase 2 = the rest + tail
         const int pcut = L - split_.split_layer + 1;                 // last backward phase of the first half (split_.nb == 2)
         const int p_lo = phase == 2 ? pcut + 1 : 0, p_hi = phase == 1 ? pcut : L;
