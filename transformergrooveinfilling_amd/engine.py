@@ -26,6 +26,7 @@ EAGER_MAX_LAUNCHES = 24                # use_graph="auto": steps of at most this
 PREDICT_CHUNK = 512                    # floor of the sequences per gt_predict call
 PREDICT_WS_BYTES = 32 << 30            # ... the chunk grows (x2) while its workspace stays under this and under half the free HBM
 PREDICT_WS_KEEP = 4 << 30              # predict() keeps a workspace between calls only up to this size (a per-epoch evaluation must not pin tens of GiB)
+MAX_GRAPHS = 4                         # captured step graphs kept per slot (least recently used dropped first)
 MAX_SLOTS = 6                          # per-batch-size step slots kept (least recently created dropped first; the engine's own batch size stays)
 
 
@@ -50,6 +51,7 @@ class _Slot:
         self.stats = torch.zeros(8, **f32)
         self.idx = torch.zeros(B, dtype=torch.int64, device=eng.device)     # static batch indices of the indexed step
         self.graphs = {}               # step recipe -> captured hipGraph
+        self.keep = {}                 # step recipe -> tensors whose raw pointers its graph holds
         self.use_graph = None          # StepEngine.graph_for's decision for this slot (use_graph="auto")
         self.fwd_id = 0                # bumped by every call that overwrites the saved activations (see StepEngine.forward)
         self.pack_epoch = -1           # StepEngine._pepoch at which this workspace's fragment-ordered weight copies were written
@@ -245,8 +247,8 @@ class StepEngine:
             fn()
             return
         if key not in s.graphs:
-            if not aux:
-                s.graphs.clear()                  # a new step recipe (optimizer / penalty changed): drop the old graphs
+            if not aux and len(s.graphs) >= MAX_GRAPHS:      # a small LRU instead of dropping everything: alternating recipes (train_step /
+                s.graphs.pop(next(iter(s.graphs)))          # train_step_indexed, a second resident dataset) must not re-capture every call
             # one launch outside capture (code-object load), every buffer it touched restored, then capture once
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -264,7 +266,9 @@ class StepEngine:
             with torch.cuda.graph(g):
                 fn()
             s.graphs[key] = g
-        s.graphs[key].replay()
+        g = s.graphs.pop(key)
+        s.graphs[key] = g                         # (most recently used last)
+        g.replay()
 
     def train_step(self, x=None, y=None, B=None):
         """One optimisation step on (x, y) (device or host tensors; None = reuse the static buffers).
@@ -312,7 +316,12 @@ class StepEngine:
                           int(self.dims["embedding_size_src"]), _ptr(s.x), _ptr(s.y), self.stream)
 
         if self.world_size == 1 and not self.force_dp:
-            self._replay(s, ("fused_idx", self.algo, self.penalty) + key, lambda: (gather(), self._enqueue_step(s, 0)))
+            gkey = ("fused_idx", self.algo, self.penalty) + key
+            self._replay(s, gkey, lambda: (gather(), self._enqueue_step(s, 0)))
+            if gkey in s.graphs:
+                s.keep[gkey] = (xs, ys)           # the captured graph holds their raw pointers: keep the tensors alive with it
+                for k in [k for k in s.keep if k not in s.graphs]:
+                    del s.keep[k]
             return s.stats
         gather()
         return self.train_step(B=s.B)
