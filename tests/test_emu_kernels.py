@@ -76,6 +76,7 @@ def test_predict_bf16_operands():
 # ---- big-tile fp32 kernel (gt_gemm32.h: 32x32x2 MFMA, two-deep prefetch ring) -------------------------------------------------
 # It serves problems of >= 192 tiles of 128x128 -- far beyond what the emulator can run -- so this test builds a variant of the
 # emulator library whose tile rule sends EVERY eligible problem (interior tiles, K % 64 == 0) to that kernel, in a subprocess
+# -- and every head_dim-64 attention backward to the LDS-staged kernel (attn_bwd_lds_kernel: batch x heads >= 1024 otherwise) --
 # (the harness's library handle is process-wide).
 def test_big_tile_kernel_variant():
     import os
@@ -83,7 +84,7 @@ def test_big_tile_kernel_variant():
     import sys
     from harness import ROOT
     so = os.path.join(ROOT, "tests", "emu", "libgroove_emu_big.so")
-    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh"), "-DGT_T128_BIG_MIN=1", "-DGT_WGRAD_T128_MIN=1", "-DGT_ROW32_MIN_M=64", "-DGT_ROW_FUSE_MIN_M=64"],
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh"), "-DGT_T128_BIG_MIN=1", "-DGT_WGRAD_T128_MIN=1", "-DGT_ROW32_MIN_M=64", "-DGT_ROW_FUSE_MIN_M=64", "-DGT_ATTN_BWD_LDS_MIN=1"],
                           env=dict(os.environ, GT_EMU_OUT=so),
                           stdout=subprocess.DEVNULL)
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -92,7 +93,7 @@ def test_big_tile_kernel_variant():
             "parity.check_step('emu', cfg_dict(128, 2, 256, 1, 1), 4, 0.0)\n"        # encoder-decoder: accumulate epilogue (cross-attention dmem)
             "parity.check_step_bf16('emu', cfg_dict(128, 4, 128, 2), 4, 0.2)\n"     # the same kernels with bf16 fragments (32x32x16 MFMA)
             "parity.check_step('emu', cfg_dict(256, 2, 64, 2), 2, 0.2)\n"           # ring-body row tiles (gemm32row_kernel): 32-row tiles at d_model 256, NT + NN, K 256 / 64 / 768
-            "parity.check_step('emu', cfg_dict(256, 4, 32, 1, 1), 2, 0.0)\n"        # ... encoder-decoder (three norms per decoder layer)
+            "parity.check_step('emu', cfg_dict(256, 4, 32, 1, 1), 2, 0.0)\n"        # ... encoder-decoder (three norms per decoder layer; head_dim 64: self, causal and cross attention backward from LDS)
             "parity.check_step('emu', cfg_dict(512, 8, 32, 1), 2, 0.1)\n"           # ... 64-row tiles at d_model 512
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GT_EMU_LIB_PATH=so), capture_output=True, text=True, timeout=1500)

@@ -566,6 +566,9 @@ static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k,
     default:  gt_launch(attn_fwd_kernel, grid, dim3(256), x.s, a);
   }
 }
+#ifndef GT_ATTN_BWD_LDS_MIN
+#define GT_ATTN_BWD_LDS_MIN 1024       // (sequence, head) pairs from which attention backward stages its operands in LDS
+#endif
 static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* P,
                           const float* dctx, float* dq, int lddq, float* dk, float* dv, int lddkv, int site) {
   AttnArgs a;
@@ -575,6 +578,14 @@ static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k,
   a.dctx = dctx; a.lddc = x.d; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddkv; a.lddv = lddkv;
   gt_prof_tag("attn_bwd", 10.0 * x.M * 32 * x.d, 4.0 * (7.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   const dim3 grid(x.c.batch * x.H);
+  // head_dim 64 with the chip full: the LDS-staged form (every operand byte requested once, 16 bytes at a time)
+  static const int lds_min = [] { const char* e = getenv("GT_ATTN_BWD_LDS_MIN"); return e ? atoi(e) : GT_ATTN_BWD_LDS_MIN; }();
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (attn_mfma_hd(x) == 64 && (int)grid.x >= lds_min && ((ldq | ldkv | lddq | lddkv | x.d) & 3) == 0 && al16(q) && al16(k) && al16(v) &&
+      al16(dctx) && al16(dq) && al16(dk) && al16(dv)) {
+    gt_launch(attn_bwd_lds_kernel<64>, grid, dim3(128), x.s, a);
+    return;
+  }
   switch (attn_mfma_hd(x)) {
     case 16:  gt_launch(attn_bwd_mfma_kernel<16, false>, grid, dim3(128), x.s, a); break;
     case 32:  gt_launch(attn_bwd_mfma_kernel<32, false>, grid, dim3(128), x.s, a); break;

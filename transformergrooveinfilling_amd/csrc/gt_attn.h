@@ -296,39 +296,43 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
 //   role 2 (key tile w, S layout: lane holds X[i = 16 ti + 4g + r][j = l16]): dPd = dO V^T, P reloaded in this layout,
 //           (P*mask) and dS are then the A operands (A[m = j][k = i]) of  dv = (P*mask)^T dO  and  dk = dS^T q.
 // (two bodies with a workgroup barrier between them -- srd, 32 floats of LDS per (sequence, head), carries the row sums)
+// operands of one (sequence, head): row 0 / first column of the head, in global memory or staged in LDS (attn_bwd_lds_kernel)
+struct AttnOps { const float* q; const float* k; const float* v; const float* dctx; int ldq, ldk, ldv, lddc; };
+__device__ __forceinline__ AttnOps attn_ops_global(const AttnArgs& a, const int bh, const int hdr) {
+  const size_t row0 = (size_t)(bh / a.H) * 32;
+  const int hc = (bh % a.H) * hdr;
+  return AttnOps{a.q + row0 * a.ldq + hc, a.k + row0 * a.ldk + hc, a.v + row0 * a.ldv + hc, a.dctx + row0 * a.lddc + hc, a.ldq, a.ldk, a.ldv, a.lddc};
+}
 template <int HD, bool PAD>
-__device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const int bh, const int w, const int lane, float* srd,
+__device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const AttnOps& op, const int bh, const int w, const int lane, float* srd,
                                                     f32x4 (&dq_out)[HD / 16]) {
   constexpr int NQ = HD / 16;
   const int hdr = PAD ? a.hd : HD;
   const float* const zp = gt_zero_ptr();
   const int l16 = lane & 15, g = lane >> 4;
-  const int b = bh / a.H, h = bh % a.H;
   const uint32_t dkey = gt_drop_key(a.drop);
-  const size_t row0 = (size_t)b * 32;
-  const int hc = h * hdr;
 
   // ---------------------------------------------------------------- role 1: query tile w
   {
     const int i = 16 * w + l16;
-    const float* dorow = a.dctx + (row0 + i) * a.lddc + hc + 4 * g;
-    const float* vrow = a.v + (row0 + l16) * a.ldv + hc + 4 * g;
+    const float* dorow = op.dctx + (size_t)i * op.lddc + 4 * g;
+    const float* vrow = op.v + (size_t)l16 * op.ldv + 4 * g;
     f32x4 dt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // dPd^T tiles [tj]
     float4 df[NQ], v0[NQ], v1[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {                       // all loads of this role first (see the forward kernel)
       df[q] = attn_ld4<PAD>(dorow + 16 * q, 16 * q + 4 * g, hdr, zp);
       v0[q] = attn_ld4<PAD>(vrow + 16 * q, 16 * q + 4 * g, hdr, zp);
-      v1[q] = attn_ld4<PAD>(vrow + (size_t)16 * a.ldv + 16 * q, 16 * q + 4 * g, hdr, zp);
+      v1[q] = attn_ld4<PAD>(vrow + (size_t)16 * op.ldv + 16 * q, 16 * q + 4 * g, hdr, zp);
     }
-    const float* __restrict__ kcol = a.k + (row0 + 4 * g) * a.ldk + hc + l16;
+    const float* __restrict__ kcol = op.k + (size_t)(4 * g) * op.ldk + l16;
     float kb[NQ][2][4];
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) kb[ct][tj][c] = attn_ld1<PAD>(kcol + (size_t)(16 * tj + c) * a.ldk + 16 * ct, 16 * ct + l16, hdr, zp);
+        for (int c = 0; c < 4; ++c) kb[ct][tj][c] = attn_ld1<PAD>(kcol + (size_t)(16 * tj + c) * op.ldk + 16 * ct, 16 * ct + l16, hdr, zp);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       dt[0] = GT_MFMA16(v0[q].x, df[q].x, dt[0]); dt[1] = GT_MFMA16(v1[q].x, df[q].x, dt[1]);
@@ -370,32 +374,30 @@ __device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const int
     for (int ct = 0; ct < NQ; ++ct) dq_out[ct] = o[ct];
   }
 }
+// (dv / dk of key tile w are returned in registers: the caller stores them -- and role 1's dq -- see attn_bwd_store_direct)
 template <int HD, bool PAD>
-__device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const int bh, const int w, const int lane, const float* srd,
-                                                    const f32x4 (&dq_out)[HD / 16]) {
+__device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const AttnOps& op, const int bh, const int w, const int lane, const float* srd,
+                                                    f32x4 (&ov)[HD / 16], f32x4 (&ok)[HD / 16]) {
   constexpr int NQ = HD / 16;
   const int hdr = PAD ? a.hd : HD;
   const float* const zp = gt_zero_ptr();
   const int l16 = lane & 15, g = lane >> 4;
-  const int b = bh / a.H, h = bh % a.H;
   const uint32_t dkey = gt_drop_key(a.drop);
-  const size_t row0 = (size_t)b * 32;
-  const int hc = h * hdr;
   // ---------------------------------------------------------------- role 2: key tile w
   {
     const int j = 16 * w + l16;
-    const float* dorow = a.dctx + (row0 + l16) * a.lddc + hc + 4 * g;               // query tile 0; tile 1 = + 16 rows
-    const float* vrow = a.v + (row0 + j) * a.ldv + hc + 4 * g;
+    const float* dorow = op.dctx + (size_t)l16 * op.lddc + 4 * g;               // query tile 0; tile 1 = + 16 rows
+    const float* vrow = op.v + (size_t)j * op.ldv + 4 * g;
     f32x4 dd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // dPd tiles [ti]
     float4 vf[NQ], d0[NQ], d1[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       vf[q] = attn_ld4<PAD>(vrow + 16 * q, 16 * q + 4 * g, hdr, zp);
       d0[q] = attn_ld4<PAD>(dorow + 16 * q, 16 * q + 4 * g, hdr, zp);
-      d1[q] = attn_ld4<PAD>(dorow + (size_t)16 * a.lddc + 16 * q, 16 * q + 4 * g, hdr, zp);
+      d1[q] = attn_ld4<PAD>(dorow + (size_t)16 * op.lddc + 16 * q, 16 * q + 4 * g, hdr, zp);
     }
-    const float* __restrict__ docol = a.dctx + (row0 + 4 * g) * a.lddc + hc + l16;
-    const float* __restrict__ qcol = a.q + (row0 + 4 * g) * a.ldq + hc + l16;
+    const float* __restrict__ docol = op.dctx + (size_t)(4 * g) * op.lddc + l16;
+    const float* __restrict__ qcol = op.q + (size_t)(4 * g) * op.ldq + l16;
     float db[NQ][2][4], qb[NQ][2][4];
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct)
@@ -403,8 +405,8 @@ __device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const int
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          db[ct][ti][c] = attn_ld1<PAD>(docol + (size_t)(16 * ti + c) * a.lddc + 16 * ct, 16 * ct + l16, hdr, zp);
-          qb[ct][ti][c] = attn_ld1<PAD>(qcol + (size_t)(16 * ti + c) * a.ldq + 16 * ct, 16 * ct + l16, hdr, zp);
+          db[ct][ti][c] = attn_ld1<PAD>(docol + (size_t)(16 * ti + c) * op.lddc + 16 * ct, 16 * ct + l16, hdr, zp);
+          qb[ct][ti][c] = attn_ld1<PAD>(qcol + (size_t)(16 * ti + c) * op.ldq + 16 * ct, 16 * ct + l16, hdr, zp);
         }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -425,7 +427,6 @@ __device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const int
         pdm[ti][r] = pv * mk;
         ds[ti][r] = pv * (dd[ti][r] * mk - srd[i]) * a.scale;
       }
-    f32x4 ov[NQ], ok[NQ];
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct) {
       ov[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -437,28 +438,100 @@ __device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const int
           ok[ct] = GT_MFMA16(ds[ti][c], qb[ct][ti][c], ok[ct]);
         }
     }
-    float* __restrict__ dqrow = a.dq + (row0 + 16 * w + 4 * g) * a.lddq + hc + l16;
-    float* __restrict__ dvrow = a.dv + (row0 + 16 * w + 4 * g) * a.lddv + hc + l16;
-    float* __restrict__ dkrow = a.dk + (row0 + 16 * w + 4 * g) * a.lddk + hc + l16;
-#pragma unroll
-    for (int ct = 0; ct < NQ; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (PAD && 16 * ct + l16 >= hdr) continue;
-        dqrow[(size_t)r * a.lddq + 16 * ct] = dq_out[ct][r];
-        dvrow[(size_t)r * a.lddv + 16 * ct] = ov[ct][r];
-        dkrow[(size_t)r * a.lddk + 16 * ct] = ok[ct][r];
-      }
   }
+}
+// rows 16 w + 4 g + r, columns 16 ct + l16 of the head, straight from the accumulator registers (64-byte segments)
+template <int HD, bool PAD>
+__device__ __forceinline__ void attn_bwd_store_direct(const AttnArgs& a, const int bh, const int w, const int lane, const f32x4 (&dq_out)[HD / 16],
+                                                      const f32x4 (&ov)[HD / 16], const f32x4 (&ok)[HD / 16]) {
+  constexpr int NQ = HD / 16;
+  const int hdr = PAD ? a.hd : HD;
+  const int l16 = lane & 15, g = lane >> 4;
+  const size_t row0 = (size_t)(bh / a.H) * 32;
+  const int hc = (bh % a.H) * hdr;
+  float* __restrict__ dqrow = a.dq + (row0 + 16 * w + 4 * g) * a.lddq + hc + l16;
+  float* __restrict__ dvrow = a.dv + (row0 + 16 * w + 4 * g) * a.lddv + hc + l16;
+  float* __restrict__ dkrow = a.dk + (row0 + 16 * w + 4 * g) * a.lddk + hc + l16;
+#pragma unroll
+  for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (PAD && 16 * ct + l16 >= hdr) continue;
+      dqrow[(size_t)r * a.lddq + 16 * ct] = dq_out[ct][r];
+      dvrow[(size_t)r * a.lddv + 16 * ct] = ov[ct][r];
+      dkrow[(size_t)r * a.lddk + 16 * ct] = ok[ct][r];
+    }
 }
 template <int HD, bool PAD>
 __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
   __shared__ float srd[32];
-  f32x4 dq_out[HD / 16];
+  f32x4 dq_out[HD / 16], ov[HD / 16], ok[HD / 16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  attn_bwd_mfma_role1<HD, PAD>(a, blockIdx.x, w, lane, srd, dq_out);
+  const AttnOps op = attn_ops_global(a, blockIdx.x, PAD ? a.hd : HD);
+  attn_bwd_mfma_role1<HD, PAD>(a, op, blockIdx.x, w, lane, srd, dq_out);
   __syncthreads();
-  attn_bwd_mfma_role2<HD, PAD>(a, blockIdx.x, w, lane, srd, dq_out);
+  attn_bwd_mfma_role2<HD, PAD>(a, op, blockIdx.x, w, lane, srd, ov, ok);
+  attn_bwd_store_direct<HD, PAD>(a, blockIdx.x, w, lane, dq_out, ov, ok);
+}
+
+// The same backward with the four operand tiles of the (sequence, head) -- q, k, v, dctx: 32 x HD each -- staged in LDS first: every
+// global byte is requested ONCE, by 16-byte loads that are all in flight together (the register form above reads each tile two or three
+// times, the column-major fragments 4 bytes at a time: L2 absorbs that, but at d_model 512 it held the kernel to 3.2 TB/s), the
+// fragments then come from LDS (row stride HD + 4: the 16 rows of a fragment read fall in different banks), and dq / dk / dv leave
+// through the same LDS tiles as full 256-byte row segments.
+template <int HD>
+__global__ __launch_bounds__(128) void attn_bwd_lds_kernel(AttnArgs a) {
+  constexpr int LD = HD + 4, Q4 = HD / 4, PER = 32 * Q4 / 128;
+  __shared__ __attribute__((aligned(16))) float sm[4 * 32 * LD];
+  __shared__ float srd[32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, bh = blockIdx.x;
+  const AttnOps og = attn_ops_global(a, bh, HD);
+  float4 rq[PER], rk[PER], rv[PER], rd[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = tid + 128 * u, r = e / Q4, c = (e % Q4) * 4;
+    rq[u] = *reinterpret_cast<const float4*>(og.q + (size_t)r * og.ldq + c);
+    rk[u] = *reinterpret_cast<const float4*>(og.k + (size_t)r * og.ldk + c);
+    rv[u] = *reinterpret_cast<const float4*>(og.v + (size_t)r * og.ldv + c);
+    rd[u] = *reinterpret_cast<const float4*>(og.dctx + (size_t)r * og.lddc + c);
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = tid + 128 * u, o = (e / Q4) * LD + (e % Q4) * 4;
+    *reinterpret_cast<float4*>(sm + o) = rq[u];
+    *reinterpret_cast<float4*>(sm + 32 * LD + o) = rk[u];
+    *reinterpret_cast<float4*>(sm + 64 * LD + o) = rv[u];
+    *reinterpret_cast<float4*>(sm + 96 * LD + o) = rd[u];
+  }
+  __syncthreads();
+  const AttnOps op{sm, sm + 32 * LD, sm + 64 * LD, sm + 96 * LD, LD, LD, LD, LD};
+  f32x4 dq_out[HD / 16], ov[HD / 16], ok[HD / 16];
+  attn_bwd_mfma_role1<HD, false>(a, op, bh, w, lane, srd, dq_out);
+  __syncthreads();
+  attn_bwd_mfma_role2<HD, false>(a, op, bh, w, lane, srd, ov, ok);
+  __syncthreads();                                               // every fragment read of q / k / v is done: the tiles take dq / dk / dv
+  {
+    const int l16 = lane & 15, g = lane >> 4;
+    float* o = sm + (16 * w + 4 * g) * LD + l16;
+#pragma unroll
+    for (int ct = 0; ct < HD / 16; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r * LD + 16 * ct] = dq_out[ct][r];
+        o[32 * LD + r * LD + 16 * ct] = ok[ct][r];
+        o[64 * LD + r * LD + 16 * ct] = ov[ct][r];
+      }
+  }
+  __syncthreads();
+  const size_t row0 = (size_t)(bh / a.H) * 32;
+  const int hc = (bh % a.H) * HD;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = tid + 128 * u, r = e / Q4, c = (e % Q4) * 4, o = r * LD + c;
+    *reinterpret_cast<float4*>(a.dq + (row0 + r) * a.lddq + hc + c) = *reinterpret_cast<const float4*>(sm + o);
+    *reinterpret_cast<float4*>(a.dk + (row0 + r) * a.lddk + hc + c) = *reinterpret_cast<const float4*>(sm + 32 * LD + o);
+    *reinterpret_cast<float4*>(a.dv + (row0 + r) * a.lddv + hc + c) = *reinterpret_cast<const float4*>(sm + 64 * LD + o);
+  }
 }
 
 
