@@ -320,38 +320,16 @@ __device__ __forceinline__ void seq_b_mma(f32x4& acc0, f32x4& acc1, const SeqB<N
 // of the wave's next tile is requested before the MFMAs of the current one.  epi(n0, acc0, acc1, bias float4).
 template <int NK, int MAXT, bool FULL, bool HALF, typename Epi>
 __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
-                                                  const float* __restrict__ bias, const int wave, const int lane, Epi& epi) {
+                                                  const float* __restrict__ bias, const int wave, const int lane, Epi& epi,
+                                                  const bool have_pre = false, const SeqB<NK> pre = SeqB<NK>()) {
   const int l16 = lane & 15, lg = lane >> 4, ntile = N >> 4, nk = K >> 4;
   if (wave >= ntile) return;                             // wave-uniform
   const float* ap = sA + l16 * lda + 4 * lg;
-#ifdef GT_SEQ_PFALL
-  // experiment: the B fragments of ALL the wave's tiles requested up front (tile indices clamped: no branch around a load), so the
-  // stage has one memory round trip in front and exact vmcnt counts after it
-  if constexpr (FULL && HALF) {
-    SeqB<NK> ball[MAXT];
-    float4 biall[MAXT];
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int t = wave + i * GT_SEQ_WAVES, tc = t < ntile ? t : ntile - 1;
-      seq_b_load<NK, true>(ball[i], Wp, nk, tc, 0, nk, lane);
-      biall[i] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * tc + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int t = wave + i * GT_SEQ_WAVES;
-      if (t < ntile) {
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        seq_b_mma<NK, true, true>(acc0, acc1, ball[i], ap, lda, nk);
-        epi(16 * t, acc0, acc1, biall[i]);
-      }
-    }
-    return;
-  }
-#endif
   SeqB<NK> b[2];
   float4 bi[2];
   GT_SUBSTAMP(0);
-  seq_b_load<NK, FULL>(b[0], Wp, nk, wave, 0, nk, lane);
+  if (have_pre) b[0] = pre;                               // (workgroup-uniform: the wave's first fragment was requested a stage ahead)
+  else seq_b_load<NK, FULL>(b[0], Wp, nk, wave, 0, nk, lane);
   bi[0] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * wave + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
   GT_SUBSTAMP(1);
 #pragma unroll
@@ -378,8 +356,16 @@ __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda
 // merged back into the branchy one by the compiler.
 template <int NK, int MAXT, bool FULL, bool HALF, typename Epi>
 __device__ __forceinline__ void seq_mm_tiles(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
-                                             const float* __restrict__ bias, const int wave, const int lane, Epi epi) {
-  seq_mm_tiles_impl<NK, MAXT, FULL, HALF>(sA, lda, K, Wp, N, bias, wave, lane, epi);
+                                             const float* __restrict__ bias, const int wave, const int lane, Epi epi,
+                                             const bool have_pre = false, const SeqB<NK> pre = SeqB<NK>()) {
+  seq_mm_tiles_impl<NK, MAXT, FULL, HALF>(sA, lda, K, Wp, N, bias, wave, lane, epi, have_pre, pre);
+}
+// the wave's first B fragment of a seq_mm_tiles stage (tile `wave`, all k-steps), for a caller that requests it a stage ahead
+template <int NK>
+__device__ __forceinline__ SeqB<NK> seq_tiles_first(const float* __restrict__ Wp, const int K, const int N, const int wave, const int lane) {
+  SeqB<NK> b;
+  seq_b_load<NK, true>(b, Wp, K >> 4, wave < (N >> 4) ? wave : 0, 0, K >> 4, lane);
+  return b;
 }
 __device__ __forceinline__ void seq_mma4(f32x4& acc, const float4& b, const float4& a) {
   acc = GT_MFMA16(b.x, a.x, acc); acc = GT_MFMA16(b.y, a.y, acc); acc = GT_MFMA16(b.z, a.z, acc); acc = GT_MFMA16(b.w, a.w, acc);
@@ -405,9 +391,23 @@ __device__ __forceinline__ void seq_mm_square(const float* sA, const int lda, co
 // partial tiles in sR[part][32][srs]; the pass that reads them (seq_parts_sum, inside the following LayerNorm pass) sums the
 // parts in a fixed order, part 0 first.  B moves in chunks of 8 k-steps, the next chunk requested before the current one's MFMAs.
 __device__ __forceinline__ int seq_splitk_parts(const int N) { return GT_SEQ_WAVES / (N >> 4); }
+// The wave's FIRST B chunk of a seq_mm_splitk stage, requested by the caller before the barrier that opens the stage (the weights do not
+// depend on the stage before: when that one is a matmul too -- FFN1 -> FFN2, FFN2 dgrad -> FFN1 dgrad -- nothing but its epilogue and the
+// barrier lies between, and the 1.8 k cycles to the first fragment disappear behind them).  Whole-chunk shapes only (seq_splitk_pre_ok).
+__device__ __forceinline__ bool seq_splitk_pre_ok(const int K, const int N) {
+  const int NT = N >> 4, KS = NT > 0 && NT <= GT_SEQ_WAVES ? GT_SEQ_WAVES / NT : 0, nks = K >> 4;
+  return KS > 0 && nks % (8 * KS) == 0;                 // every part a whole number of 8-k-step chunks
+}
+__device__ __forceinline__ SeqB<8> seq_splitk_first(const float* __restrict__ Wp, const int K, const int N, const int wave, const int lane) {
+  const int NT = N >> 4, KS = GT_SEQ_WAVES / NT, t = wave % NT, part = wave / NT, nks = K >> 4, per = nks / KS;
+  SeqB<8> b;
+  seq_b_load<8, true>(b, Wp, nks, t, (part < KS ? part : 0) * per, 8, lane);
+  return b;
+}
 template <bool HALF>
 __device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
-                                              float* sR, const int srs, const int wave, const int lane) {
+                                              float* sR, const int srs, const int wave, const int lane, const bool have_pre = false,
+                                              const SeqB<8> pre = SeqB<8>()) {
   const int l16 = lane & 15, lg = lane >> 4;
   const int NT = N >> 4, KS = GT_SEQ_WAVES / NT;
   const int t = wave % NT, part = wave / NT;
@@ -417,18 +417,9 @@ __device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, co
   const float* ap = sA + l16 * lda + 4 * lg;
   f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
   SeqB<8> b[2];
-#ifdef GT_SEQ_PFALL
-  if (HALF && (ks1 - ks0 == 32 || ks1 - ks0 == 24)) {             // experiment: every chunk of the wave requested up front
-    SeqB<8> ball[4];
-    const int nch = (ks1 - ks0) >> 3;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) seq_b_load<8, true>(ball[c], Wp, nks, t, ks0 + 8 * (c < nch ? c : nch - 1), 8, lane);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { if (c < nch) seq_b_mma<8, true, HALF>(acc0, acc1, ball[c], ap + 16 * (ks0 + 8 * c), lda, 8); }
-  } else
-#endif
   if (ks1 > ks0 && ((ks1 - ks0) & 7) == 0) {                       // whole chunks only (F and 3 d multiples of 128 per part): branch-free bodies
-    seq_b_load<8, true>(b[0], Wp, nks, t, ks0, 8, lane);
+    if (have_pre) b[0] = pre;                                     // (workgroup-uniform)
+    else seq_b_load<8, true>(b[0], Wp, nks, t, ks0, 8, lane);
     for (int c0 = ks0; c0 < ks1; c0 += 16) {                       // two chunks per trip: the buffer index stays compile-time
       if (c0 + 8 < ks1) seq_b_load<8, true>(b[1], Wp, nks, t, c0 + 8, 8, lane);
       seq_b_mma<8, true, HALF>(acc0, acc1, b[0], ap + 16 * c0, lda, 8);
@@ -969,6 +960,14 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     // pair's two waves the two query tiles; SPLIT: wave w takes head h8 + w, query tile = the own half.  The qkv tile goes to global
     // here (saved for the backward) -- line-shaped, see seq_tile_out.
     if (save_qkv) seq_tile_out(wl + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
+#ifndef GT_SEQ_NO_PRE2
+    const bool preo = SPLIT && EXACT && DP > 64;              // the out-proj's fragment: in flight under the attention (which loads nothing)
+    SeqB<NK> bopre = SeqB<NK>();
+    if (preo) bopre = seq_tiles_first<NK>(kf_out, d, d, wave, lane);
+#else
+    const bool preo = false;
+    const SeqB<NK> bopre = SeqB<NK>();
+#endif
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
       constexpr int HPR = HALF ? GT_SEQ_WAVES : GT_SEQ_WAVES / 2;              // heads per round
@@ -992,7 +991,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kf_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
           *reinterpret_cast<float4*>(&sR[(rb + l16) * SRS + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
           if (!HALF) *reinterpret_cast<float4*>(&sR[(16 + l16) * SRS + n0 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
-        });
+        }, preo, bopre);
     }
     GT_BARRIER();
     GT_STAMP(sb + 3);
@@ -1030,12 +1029,20 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         }
       });
     }
+#ifndef GT_SEQ_NO_PRE
+    const bool pre2 = SPLIT && seq_splitk_pre_ok(F, d);
+    SeqB<8> b2pre = SeqB<8>();
+    if (pre2) b2pre = seq_splitk_first(kf_w2, F, d, wave, lane);     // FFN2's first chunk: in flight across the barrier and the tile store
+#else
+    const bool pre2 = false;
+    const SeqB<8> b2pre = SeqB<8>();
+#endif
     GT_BARRIER();
     GT_SUBSET(false);
     GT_STAMP(sb + 5);
     // ---- FFN2 (K = F: split over the waves) -> partial tiles; the FFN tile goes to global (saved for the backward)
     seq_tile_out(wl + a.w0.hact + r0 * F, sH, SH, F, tid, rb, NROW);
-    seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kf_w2, d, sR + rb * SRS, SRS, wave, lane);
+    seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kf_w2, d, sR + rb * SRS, SRS, wave, lane, pre2, b2pre);
     GT_BARRIER();
     GT_STAMP(sb + 6);
     // ---- z2 = drop(sum of the parts + b2) + x1;  norm2 -> the next layer's input
@@ -1306,11 +1313,19 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
                                                      ha.z != 0.f ? c[2] * mscale : 0.f, ha.w != 0.f ? c[3] * mscale : 0.f);
       }
     });
+#ifndef GT_SEQ_NO_PRE
+    const bool pre1 = SPLIT && seq_splitk_pre_ok(F, d);
+    SeqB<8> b1pre = SeqB<8>();
+    if (pre1) b1pre = seq_splitk_first(kb_w1, F, d, wave, lane);     // FFN1 dgrad's first chunk: in flight across the barrier and the tile store
+#else
+    const bool pre1 = false;
+    const SeqB<8> b1pre = SeqB<8>();
+#endif
     GT_BARRIER();
     GT_STAMP(sb + 1);
     // ---- FFN1 dgrad (K = F: split over the waves) -> partial tiles; dhid goes to global (operand of both FFN weight gradients)
     seq_tile_out(tl + a.t0.dhid + r0 * F, sH, SH, F, tid, rb, NROW);
-    seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kb_w1, d, sR + rb * SRS, SRS, wave, lane);
+    seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kb_w1, d, sR + rb * SRS, SRS, wave, lane, pre1, b1pre);
     GT_BARRIER();
     GT_STAMP(sb + 2);
     // ---- norm1 backward: g1 = parts + dz2 -> dz1 -> sDZ, dz1 * mask(dropout1) -> sC.  Whole: the saved qkv tile of this layer is
