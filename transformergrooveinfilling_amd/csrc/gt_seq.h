@@ -1364,6 +1364,12 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     float* wl = ws + (int64_t)l * a.wstride;
     float* tl = ws + (int64_t)l * a.tstride;
     const int sb = 102 + 10 * (a.L - 1 - l);
+#ifndef GT_SEQ_NO_PRE4
+    const bool preq = SPLIT && seq_splitk_pre_ok(3 * d, d);
+#else
+    const bool preq = false;
+#endif
+    SeqB<8> bqpre = SeqB<8>();
     {
       const uint32_t key = seq_key(dk, GT_SITE_LAYER0 + 8 * l + GT_SITE_ATTN);
       for (int h4 = 0; h4 < a.H; h4 += GT_SEQ_WAVES / 2) {
@@ -1376,6 +1382,10 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
         if (active) seq_attn_bwd1<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dq_out);
         GT_BARRIER();
         if (active) seq_attn_bwd2<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dk_out, dv_out);
+#ifndef GT_SEQ_NO_PRE4
+        // the in-proj dgrad's first chunk: in flight across the two barriers, the dq / dk / dv store and the dqkv tile's way to global
+        if (preq && h4 + GT_SEQ_WAVES / 2 >= a.H) bqpre = seq_splitk_first(kb, 3 * d, d, wave, lane);
+#endif
         GT_BARRIER();
         if (active) seq_attn_bwd_store<HD, PAD>(sQ + h * a.hd, SQ, d, a.hd, wave & 1, lane, dq_out, dk_out, dv_out);
       }
@@ -1384,7 +1394,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     GT_STAMP(sb + 5);
     seq_tile_out(tl + a.t0.dqkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
     if (!SPLIT && !ALIAS && l > 0) load_rows(sH, SH, ws + (int64_t)(l - 1) * a.wstride + a.w0.hact + r0 * F, F, 0, 32);   // the next layer's FFN tile
-    seq_mm_splitk<HALF>(sQ + rb * SQ, SQ, 3 * d, kb, d, sR + rb * SRS, SRS, wave, lane);
+    seq_mm_splitk<HALF>(sQ + rb * SQ, SQ, 3 * d, kb, d, sR + rb * SRS, SRS, wave, lane, preq, bqpre);
     GT_BARRIER();
     GT_STAMP(sb + 6);
   };
