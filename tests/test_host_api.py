@@ -103,6 +103,32 @@ def test_find_checkpoint_latest_epoch(tmp_path):
         training.find_checkpoint(dict(lm, epoch=7))
 
 
+def test_find_checkpoint_wandb_location(tmp_path, monkeypatch):
+    """load_model.location == "wandb" (ref:tutorial.py:98-104: dir = the run path, file = file_pattern.format(run, epoch)): the file is
+    fetched with wandb.restore; without the package the request fails loudly instead of looking in a local directory."""
+    lm = {"location": "wandb", "dir": "mmil_infilling/InfillingClosedHH/y16izsyy", "file_pattern": "transformer_run_{}_Epoch_{}.Model",
+          "epoch": 50, "run": "y16izsyy"}
+    monkeypatch.setattr(training, "wandb", None)
+    with pytest.raises(RuntimeError, match="wandb"):
+        training.find_checkpoint(lm)
+    calls = []
+
+    class _Restored:
+        name = str(tmp_path / "transformer_run_y16izsyy_Epoch_50.Model")
+
+    class _Wandb:
+        run = None
+
+        @staticmethod
+        def restore(name, run_path=None):
+            calls.append((name, run_path))
+            return _Restored()
+
+    monkeypatch.setattr(training, "wandb", _Wandb)
+    assert training.find_checkpoint(lm) == _Restored.name
+    assert calls == [("transformer_run_y16izsyy_Epoch_50.Model", "mmil_infilling/InfillingClosedHH/y16izsyy")]
+
+
 def test_sharded_sampler_partitions_every_epoch():
     n, bs, world = 1000, 16, 4
     seen = []
