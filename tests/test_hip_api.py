@@ -89,16 +89,20 @@ def test_train_loop_fast_path_checkpoint_and_resume(tmp_path):
         def __getitem__(self, i):
             return self.tensors[0][i], self.tensors[1][i], i
 
-    dl = DataLoader(Triples(x, y), batch_size=32, shuffle=True)
+    # (the shuffle is seeded and the criterion is the mean of an epoch's logged minibatch losses: the loss of ONE minibatch -- what
+    #  train_loop returns -- moves by more between two batches than three epochs of SGD gain; 1 run in ~25 used to fail on that)
+    dl = DataLoader(Triples(x, y), batch_size=32, shuffle=True, generator=torch.Generator().manual_seed(0))
     bce, mse = torch.nn.BCEWithLogitsLoss(reduction="none"), torch.nn.MSELoss(reduction="none")
     logs = []
-    first = None
+    per_epoch = []
     for ep in range(3):
+        n0 = len(logs)
         m = train_loop(dataloader=dl, groove_transformer=model, encoder_only=1, opt=opt, epoch=ep, loss_fn=calculate_loss, bce_fn=bce,
                        mse_fn=mse, device="cuda", test_inputs=x[:16], test_gt=y[:16], hit_loss_penalty=0.38, save=(ep == 2),
-                       save_dir=str(tmp_path), run_id="abc", log_every=4, on_log=logs.append)
-        first = first or m["train/loss"]
-    assert m["train/loss"] < first, (first, m, [r.get("train/loss") for r in logs if "train/loss" in r])
+                       save_dir=str(tmp_path), run_id="abc", log_every=2, on_log=logs.append)
+        ls = [r["train/loss"] for r in logs[n0:] if "train/loss" in r]
+        per_epoch.append(sum(ls) / len(ls))
+    assert per_epoch[2] < per_epoch[0], (per_epoch, m, [r.get("train/loss") for r in logs if "train/loss" in r])
     assert any("test/loss" in r for r in logs) and any("train/loss" in r for r in logs)
     assert model.engine.state_struct().step == 3 * 8                                 # one fused update per batch
     ck = tmp_path / "transformer_run_abc_Epoch_2.Model"
