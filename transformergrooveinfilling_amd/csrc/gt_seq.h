@@ -848,6 +848,151 @@ __device__ __forceinline__ void seq_attn_bwd_store(float* dq, const int ldq, con
     }
 }
 
+// ---- head_dim 2 (the reference's ClosedHH YAML: d_model 32, 16 heads) on the vector ALU.  Zero-padded to a 16-wide MFMA contraction such a head does
+// 2 .. 8 useful multiplications per 16 and the stage is one latency chain per round of heads (ClosedHH YAML: 17 k cycles forward, 31 k
+// backward per layer, more than every matmul of the layer together).  Here ONE THREAD owns a (query row, head) pair: 32 scores, the
+// softmax and the head's ctx columns in registers, operands straight from the LDS qkv tile as 8- / 16-byte reads (a wave's lanes differ
+// in the head: consecutive addresses; in the row: broadcast).  rows x H <= the workgroup's threads.  Same P / dropout index layout as the
+// MFMA form (P[head][query][key], index = head base + 32 query + key).  (Written for head_dim 2 / 4 / 8; only 2 is instantiated: at 8 the compiler keeps 256 registers live and spills, and the
+// testing YAML's head_dim-8 attention stays on the zero-padded MFMA form with every other head_dim below 16.)
+template <int HD> struct SeqHv { float v[HD]; };
+template <int HD>
+__device__ __forceinline__ SeqHv<HD> seq_hv_ld(const float* p) {
+  SeqHv<HD> r;
+  if (HD == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+  else {
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) { const float4 t = *reinterpret_cast<const float4*>(p + c); r.v[c] = t.x; r.v[c + 1] = t.y; r.v[c + 2] = t.z; r.v[c + 3] = t.w; }
+  }
+  return r;
+}
+template <int HD>
+__device__ __forceinline__ float seq_hv_dot(const SeqHv<HD>& a, const SeqHv<HD>& b) {
+  float t = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) t += a.v[c] * b.v[c];
+  return t;
+}
+template <int HD>
+__device__ __forceinline__ void seq_attn_fwd_small(const float* sQ, const int ldq, const int d, const int H, const float scale, float* Pseq,
+                                                   const uint32_t pidx_seq, float* sCtx, const int ldc, const SeqDropK& dk, const uint32_t key,
+                                                   const int row0, const int nrow, const int tid) {
+  if (tid >= nrow * H) return;
+  const int h = tid % H, i = row0 + tid / H;
+  const float* kp = sQ + d + h * HD;
+  const float* vp = sQ + 2 * d + h * HD;
+  const SeqHv<HD> q = seq_hv_ld<HD>(sQ + i * ldq + h * HD);
+  float sc[32], mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    sc[j] = seq_hv_dot<HD>(q, seq_hv_ld<HD>(kp + j * ldq)) * scale; mx = fmaxf(mx, sc[j]);
+    if ((j & 3) == 3) { GT_SCHED_FENCE() }                     // (four keys' reads in flight; all 32 hoisted ahead would be 256 registers)
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    sc[j] = expf(sc[j] - mx); sum += sc[j];
+    if ((j & 3) == 3) { GT_SCHED_FENCE() }                     // (32 interleaved exp expansions are 150 registers of temporaries)
+  }
+  const float inv = 1.0f / sum;
+  float* Prow = Pseq + (size_t)h * 1024 + i * 32;
+  const uint32_t pidx = pidx_seq + (uint32_t)(h * 1024 + i * 32);
+  SeqHv<HD> o;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) o.v[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; j += 4) {
+    float4 pv;
+    pv.x = sc[j] * inv; pv.y = sc[j + 1] * inv; pv.z = sc[j + 2] * inv; pv.w = sc[j + 3] * inv;
+    *reinterpret_cast<float4*>(Prow + j) = pv;
+    const float m0 = pv.x * seq_dmul(dk, key, pidx + j), m1 = pv.y * seq_dmul(dk, key, pidx + j + 1);
+    const float m2 = pv.z * seq_dmul(dk, key, pidx + j + 2), m3 = pv.w * seq_dmul(dk, key, pidx + j + 3);
+    const SeqHv<HD> v0 = seq_hv_ld<HD>(vp + j * ldq), v1 = seq_hv_ld<HD>(vp + (j + 1) * ldq);
+    const SeqHv<HD> v2 = seq_hv_ld<HD>(vp + (j + 2) * ldq), v3 = seq_hv_ld<HD>(vp + (j + 3) * ldq);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o.v[c] += m0 * v0.v[c] + m1 * v1.v[c] + m2 * v2.v[c] + m3 * v3.v[c];
+    GT_SCHED_FENCE()
+  }
+#pragma unroll
+  for (int c = 0; c < HD; ++c) sCtx[i * ldc + h * HD + c] = o.v[c];
+}
+// Backward, the same ownership in two passes with a workgroup barrier between them (and one after: the results replace q / k / v in
+// place).  Pass A, thread = (query row i of all 32, head): dP, the row sum rd -> srd[head][i], dS, dq_i.  Pass B, thread = (key row j of
+// the rows [krow0, krow0 + nkrow), head), j fastest so that the P column reads of a wave are 64 / 128 contiguous bytes: dv_j, dk_j over
+// all 32 queries.  32 x H and nkrow x H <= the workgroup's threads; srd: H x 32 floats of LDS.
+template <int HD>
+__device__ __forceinline__ void seq_attn_bwd_small(float* sQ, const int ldq, const int d, const int H, const float scale, const float* Pseq,
+                                                   const uint32_t pidx_seq, const float* sDO, const int lddo, const SeqDropK& dk,
+                                                   const uint32_t key, float* srd, const int krow0, const int nkrow, const int tid) {
+  SeqHv<HD> dq, dkk, dvv;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) { dq.v[c] = 0.f; dkk.v[c] = 0.f; dvv.v[c] = 0.f; }
+  const bool ta = tid < 32 * H, tb = tid < nkrow * H;
+  const int ha = tid % H, ia = tid / H;                        // pass A: (query row, head), head fastest
+  const int jb = krow0 + tid % nkrow, hb = tid / nkrow;        // pass B: (key row, head), key row fastest
+  if (ta) {
+    const float* kp = sQ + d + ha * HD;
+    const float* vp = sQ + 2 * d + ha * HD;
+    const float* Prow = Pseq + (size_t)ha * 1024 + ia * 32;
+    const uint32_t pidx = pidx_seq + (uint32_t)(ha * 1024 + ia * 32);
+    const SeqHv<HD> dO = seq_hv_ld<HD>(sDO + ia * lddo + ha * HD);
+    float p[32], ds[32];
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) {
+      const float4 pv = *reinterpret_cast<const float4*>(Prow + j);
+      p[j] = pv.x; p[j + 1] = pv.y; p[j + 2] = pv.z; p[j + 3] = pv.w;
+    }
+    float rd = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      ds[j] = seq_hv_dot<HD>(dO, seq_hv_ld<HD>(vp + j * ldq)) * seq_dmul(dk, key, pidx + j);      // dP (under the probabilities' dropout mask)
+      rd += ds[j] * p[j];
+      if ((j & 3) == 3) { GT_SCHED_FENCE() }
+    }
+    srd[ha * 32 + ia] = rd;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float g = p[j] * (ds[j] - rd) * scale;
+      const SeqHv<HD> kj = seq_hv_ld<HD>(kp + j * ldq);
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dq.v[c] += g * kj.v[c];
+      if ((j & 3) == 3) { GT_SCHED_FENCE() }
+    }
+  }
+  GT_BARRIER();
+  if (tb) {
+    const float* qp = sQ + hb * HD;
+    const float* dop = sDO + hb * HD;
+    const float* Pcol = Pseq + (size_t)hb * 1024 + jb;
+    const uint32_t pidx = pidx_seq + (uint32_t)(hb * 1024 + jb);
+    const SeqHv<HD> v = seq_hv_ld<HD>(sQ + jb * ldq + 2 * d + hb * HD);
+    float p[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) p[i] = Pcol[i * 32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float mk = seq_dmul(dk, key, pidx + (uint32_t)(i * 32));
+      const SeqHv<HD> dO = seq_hv_ld<HD>(dop + i * lddo), qi = seq_hv_ld<HD>(qp + i * ldq);
+      const float pm = p[i] * mk, g = p[i] * (seq_hv_dot<HD>(dO, v) * mk - srd[hb * 32 + i]) * scale;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) { dvv.v[c] += pm * dO.v[c]; dkk.v[c] += g * qi.v[c]; }
+      if ((i & 1) == 1) { GT_SCHED_FENCE() }
+    }
+  }
+  GT_BARRIER();                                                 // every read of q / k / v is done: dq / dk / dv go over them
+  if (ta) {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) sQ[ia * ldq + ha * HD + c] = dq.v[c];
+  }
+  if (tb) {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { sQ[jb * ldq + d + hb * HD + c] = dkk.v[c]; sQ[jb * ldq + 2 * d + hb * HD + c] = dvv.v[c]; }
+  }
+}
+#ifndef GT_SEQ_VATTN
+#define GT_SEQ_VATTN 1          /* 0: head_dim < 16 stays on the zero-padded MFMA form */
+#endif
+
 // ================================================================================================================ forward
 // LDS geometry of a d_model class.  RP: most split-K parts a [32][d] result can come in (d = 16 -> 8 parts ... d > 64 -> 1).
 template <int DP> struct SeqGeo {
@@ -968,7 +1113,17 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     const bool preo = false;
     const SeqB<NK> bopre = SeqB<NK>();
 #endif
-    {
+    bool vattn = false;
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
+      vattn = a.hd == 2 && 32 * a.H <= GT_SEQ_NT;              // (the backward's bound too: both directions take the same form)
+      if (vattn) {
+        const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
+        float* Pseq = wl + a.w0.P + (size_t)(b * a.H) * 1024;
+        const uint32_t pseq = (uint32_t)(b * a.H * 1024);
+        seq_attn_fwd_small<2>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sC, SX, dk, key, rb, NROW, tid);
+      }
+    }
+    if (!vattn) {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
       constexpr int HPR = HALF ? GT_SEQ_WAVES : GT_SEQ_WAVES / 2;              // heads per round
       for (int h4 = 0; h4 < a.H; h4 += HPR) {
@@ -1370,7 +1525,20 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     const bool preq = false;
 #endif
     SeqB<8> bqpre = SeqB<8>();
-    {
+    bool vattn = false;
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
+      vattn = a.hd == 2 && 32 * a.H <= GT_SEQ_NT;
+      if (vattn) {                                              // (sR is free here: H x 32 row sums)
+        const uint32_t key = seq_key(dk, GT_SITE_LAYER0 + 8 * l + GT_SITE_ATTN);
+        const float* Pseq = wl + a.w0.P + (size_t)(b * a.H) * 1024;
+        const uint32_t pseq = (uint32_t)(b * a.H * 1024);
+        seq_attn_bwd_small<2>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sZ, SX, dk, key, sR, rb, NROW, tid);
+#ifndef GT_SEQ_NO_PRE4
+        if (preq) bqpre = seq_splitk_first(kb, 3 * d, d, wave, lane);
+#endif
+      }
+    }
+    if (!vattn) {
       const uint32_t key = seq_key(dk, GT_SITE_LAYER0 + 8 * l + GT_SITE_ATTN);
       for (int h4 = 0; h4 < a.H; h4 += GT_SEQ_WAVES / 2) {
         const int h = h4 + (wave >> 1);
