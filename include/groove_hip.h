@@ -168,6 +168,11 @@ int gt_predict(const gt_config* cfg, const float* params, const float* pe, const
  * shared with oracle/numpy_groove.py).  The encoder-decoder's greedy decode feeds the sampled hits back. */
 int gt_predict_pd(const gt_config* cfg, const float* params, const float* pe, const float* x, float* hvo_out, uint32_t seed,
                   float* tgt_scratch, float* ws, gt_stream_t stream);
+/* The same for a CHUNK of a larger evaluation set (ref:evaluator.py:173 hands the whole set over at once; the host walks it in
+ * workspace-sized chunks): first_seq = index of x's first sequence inside the set; idx above counts from the start of the SET, so the
+ * samples do not depend on the chunk size.  gt_predict_pd == gt_predict_pd_at(first_seq = 0). */
+int gt_predict_pd_at(const gt_config* cfg, const float* params, const float* pe, const float* x, float* hvo_out, uint32_t seed,
+                     int64_t first_seq, float* tgt_scratch, float* ws, gt_stream_t stream);
 
 /* Replaces, for the device side, what the reference's evaluator computes from model.predict's output per epoch
  * (ref:evaluator.py:522-525: get_hits_accuracies / get_velocity_errors / get_micro_timing_errors over the 9 voices of

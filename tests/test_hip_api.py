@@ -288,6 +288,10 @@ def test_model_predict_use_pd_on_both_model_kinds():
         assert torch.equal(h1, h2) and not torch.equal(h1, h3)
         assert set(h1.unique().tolist()) <= {0.0, 1.0} and h1.shape == (6, 32, 9) and v1.shape == o1.shape == (6, 32, 9)
         model.predict(xt, use_pd=True)                                           # seed drawn from torch's generator
+        # the samples are hashed from the element's index in the whole set: any chunking draws the same ones (gt_predict_pd_at)
+        whole = model.engine.predict(xt, pd_seed=11, chunk=6)
+        for chunk in (1, 4):
+            assert torch.equal(model.engine.predict(xt, pd_seed=11, chunk=chunk), whole)
 
 
 def test_predict_walks_large_sets_in_chunks():

@@ -55,6 +55,7 @@ _SIGS = {
     "gt_predict": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),
     # cfg, params, pe, x, hvo_out, seed, tgt_scratch, ws, stream
     "gt_predict_pd": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp]),
+    "gt_predict_pd_at": (ctypes.c_int, [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_uint32, ctypes.c_int64, _vp, _vp, _vp]),
     "gt_voice_metrics_scratch_floats": (ctypes.c_int64, [ctypes.c_int64]),
     # hvo_pred, hvo_gt, n_rows, out30, scratch, stream
     "gt_voice_metrics": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),

@@ -1385,7 +1385,7 @@ extern "C" int gt_gather_batch(const float* xs, const float* ys, const int64_t* 
 
 // ------------------------------------------------------------------------------------ predict
 static int predict_impl(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, float thres,
-                        int use_thres, uint32_t seed, float* tgt_scratch, float* ws, gt_stream_t stream);
+                        int use_thres, uint32_t seed, float* tgt_scratch, float* ws, gt_stream_t stream, uint32_t idx0 = 0u);
 extern "C" int gt_predict(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, float thres,
                           int use_thres, float* tgt_scratch, float* ws, gt_stream_t stream) {
   return predict_impl(cfg, params, pe, xin, hvo_out, thres, use_thres != 0, 0u, tgt_scratch, ws, stream);
@@ -1396,8 +1396,15 @@ extern "C" int gt_predict_pd(const gt_config* cfg, const float* params, const fl
                              float* tgt_scratch, float* ws, gt_stream_t stream) {
   return predict_impl(cfg, params, pe, xin, hvo_out, 0.5f, 2, seed, tgt_scratch, ws, stream);
 }
+// ... for a chunk of a larger set: first_seq = index of the chunk's first sequence inside the set.  The uniform of element (row, column)
+// is hashed from its index in the WHOLE set, so the samples do not depend on how the set is cut into calls.
+extern "C" int gt_predict_pd_at(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, uint32_t seed,
+                                int64_t first_seq, float* tgt_scratch, float* ws, gt_stream_t stream) {
+  if (first_seq < 0) return gt_fail("gt_predict_pd_at: first_seq must be >= 0");
+  return predict_impl(cfg, params, pe, xin, hvo_out, 0.5f, 2, seed, tgt_scratch, ws, stream, (uint32_t)((uint64_t)first_seq * 32u * GT_TGT));
+}
 static int predict_impl(const gt_config* cfg, const float* params, const float* pe, const float* xin, float* hvo_out, float thres,
-                        int use_thres, uint32_t seed, float* tgt_scratch, float* ws, gt_stream_t stream) {
+                        int use_thres, uint32_t seed, float* tgt_scratch, float* ws, gt_stream_t stream, uint32_t idx0) {
   Ctx x;
   if (make_ctx(x, cfg, params, nullptr, ws, nullptr, 0, stream)) return -1;
   if (!pe || !xin || !hvo_out) return gt_fail("gt_predict: pe / x / hvo_out must not be NULL");
@@ -1406,7 +1413,7 @@ static int predict_impl(const gt_config* cfg, const float* params, const float* 
   if (cfg->n_dec_layers == 0) {
     output_layer_fwd(x, hvo_out);
     gt_launch(predict_head_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), x.s, (const float*)hvo_out, hvo_out, (float*)nullptr,
-              thres, use_thres, -1, B, seed);
+              thres, use_thres, -1, B, seed, idx0);
     return launch_status("gt_predict");
   }
   if (!tgt_scratch) return gt_fail("gt_predict: encoder-decoder model needs tgt_scratch");
@@ -1433,7 +1440,7 @@ static int predict_impl(const gt_config* cfg, const float* params, const float* 
       decoder_step(x, pe, tgt_scratch, t, tmp);
     }
     gt_launch(predict_head_kernel, dim3((B * GT_TGT + 255) / 256), dim3(256), x.s, (const float*)tmp, hvo_out, tgt_scratch, thres,
-              use_thres, t, B, seed);
+              use_thres, t, B, seed, idx0);
   }
   return launch_status("gt_predict");
 }

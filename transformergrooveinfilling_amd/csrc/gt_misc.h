@@ -525,9 +525,11 @@ __global__ __launch_bounds__(256) void shift_right_kernel(const float* __restric
 // predict: h = sigmoid(logit) > thres ? 1 : 0 (use_thres 1), the probability (0), or a SAMPLE of it (2: the reference's use_pd --
 // h = 1 iff p > u, u = (fmix32((idx * 0x9E3779B1) ^ seed) >> 8) * 2^-24 with idx = the element's flat index m * 27 + c, the hash of
 // the dropout masks).  t < 0: all rows (encoder-only); t >= 0: only row t of every sequence, and the step's hits are fed to tgt row
-// t+1 (greedy decode).
+// t+1 (greedy decode).  idx0: flat index of this call's first element inside the whole set (gt_predict_pd_at: a set walked in chunks
+// draws the same samples whatever the chunk size).
 __global__ __launch_bounds__(256) void predict_head_kernel(const float* __restrict__ hvo_in, float* __restrict__ hvo_out,
-                                                           float* __restrict__ tgt, float thres, int use_thres, int t, int B, uint32_t seed) {
+                                                           float* __restrict__ tgt, float thres, int use_thres, int t, int B, uint32_t seed,
+                                                           uint32_t idx0) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int rows = (t < 0) ? B * 32 : B;
   if (e >= rows * GT_TGT) return;
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(256) void predict_head_kernel(const float* __restri
   float a = hvo_in[(size_t)m * GT_TGT + c];
   if (c < GT_VOICES) {
     const float pr = gt_sigmoid(a);
-    const float cut = use_thres == 2 ? (float)(gt_fmix32(((uint32_t)(m * GT_TGT + c) * 0x9E3779B1u) ^ seed) >> 8) * (1.0f / 16777216.0f) : thres;
+    const float cut = use_thres == 2 ? (float)(gt_fmix32(((idx0 + (uint32_t)(m * GT_TGT + c)) * 0x9E3779B1u) ^ seed) >> 8) * (1.0f / 16777216.0f) : thres;
     a = use_thres ? ((pr > cut) ? 1.0f : 0.0f) : pr;
   }
   hvo_out[(size_t)m * GT_TGT + c] = a;

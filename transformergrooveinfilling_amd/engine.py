@@ -126,6 +126,7 @@ class StepEngine:
         self._pepoch, self._pver = 0, -1
         self.fold_pack = os.environ.get("GT_PACK_FOLD", "1") != "0"
         self._loss_slots = {}
+        self._train_B = None           # batch size of the most recent train step (its slot is never evicted)
         self._predict_ws = {}          # chunk size -> (cfg, workspace, tgt scratch) of predict()
         self.B = int(batch_size) if batch_size else None
         if self.B:
@@ -136,8 +137,13 @@ class StepEngine:
         B = int(B)
         if B not in self._slots:
             if len(self._slots) >= MAX_SLOTS:                     # evaluation remainders etc.: bounded, like the loss slots
-                self._slots.pop(next(k for k in self._slots if k != self.B))
+                # least recently USED first; never the engine's own batch size nor the slot the last train step ran on
+                # (its captured graphs, kept tensors and weight packs would be re-made every epoch)
+                keep = {self.B, self._train_B}
+                self._slots.pop(next((k for k in self._slots if k not in keep), next(iter(self._slots))))
             self._slots[B] = _Slot(self, B)
+        else:
+            self._slots[B] = self._slots.pop(B)                   # (most recently used last)
         return self._slots[B]
 
     def loss_slot(self, B):
@@ -206,13 +212,20 @@ class StepEngine:
         return (self.fold_pack and not self.graph_for(s) and s.pack_epoch == self._pepoch
                 and self._pver == self.params._version)
 
+    def _note_fused_step(self, s):
+        """A fused whole step is about to update the parameters and write the NEXT step's weight copies into slot s's workspace:
+        every other slot's copies go stale.  Called for every such step however it is issued -- also before a graph REPLAY, which
+        runs none of _enqueue_step's Python (an eager slot would otherwise keep passing GT_STEP_PACKS_CURRENT over weights that
+        a graphed slot's replay has updated)."""
+        self._pepoch += 1
+        s.pack_epoch, self._pver = self._pepoch, self.params._version
+
     def _enqueue_step(self, s, skip_update):
         flags = skip_update
         if skip_update != 3 and self._packs_current(s):
             flags |= 4                         # GT_STEP_PACKS_CURRENT: no packing launch at the head of the step
         if skip_update == 0:                   # whole step: its update writes the next step's copies into this slot
-            self._pepoch += 1
-            s.pack_epoch, self._pver = self._pepoch, self.params._version
+            self._note_fused_step(s)
         self.lib.call("gt_train_step", ctypes.byref(s.cfg), self.algo, _ptr(self.params), _ptr(self.grads),
                       _ptr(self.m), _ptr(self.v), _ptr(self.pe), _ptr(s.x), _ptr(s.y),
                       ctypes.c_float(self.penalty), _ptr(s.hvo), _ptr(s.stats), _ptr(s.tgt), _ptr(s.ws),
@@ -274,12 +287,15 @@ class StepEngine:
         """One optimisation step on (x, y) (device or host tensors; None = reuse the static buffers).
         Returns the device stats tensor [loss, hit_acc, -, bce, mse_v, mse_o, -, -] without syncing."""
         s = self.slot(x.shape[0] if x is not None else (B or self.B))
+        self._train_B = s.B
         s.fwd_id += 1
         if x is not None:
             s.x.copy_(x, non_blocking=True)
         if y is not None:
             s.y.copy_(y, non_blocking=True)
         if self.world_size == 1 and not self.force_dp:
+            if self.graph_for(s):
+                self._note_fused_step(s)          # (a replay updates the parameters without running _enqueue_step)
             self._replay(s, ("fused", self.algo, self.penalty), lambda: self._enqueue_step(s, 0))
         else:
             import torch.distributed as dist
@@ -307,6 +323,7 @@ class StepEngine:
         the gather into the static step inputs is the first launch of the step's hipGraph (gt_gather_batch), nothing is
         copied on the host side but the B indices into their static buffer.  Data-parallel: as train_step."""
         s = self.slot(idx.shape[0])
+        self._train_B = s.B
         s.fwd_id += 1
         s.idx.copy_(idx, non_blocking=True)
         key = (xs.data_ptr(), ys.data_ptr(), xs.shape[0])
@@ -317,6 +334,8 @@ class StepEngine:
 
         if self.world_size == 1 and not self.force_dp:
             gkey = ("fused_idx", self.algo, self.penalty) + key
+            if self.graph_for(s):
+                self._note_fused_step(s)
             self._replay(s, gkey, lambda: (gather(), self._enqueue_step(s, 0)))
             if gkey in s.graphs:
                 s.keep[gkey] = (xs, ys)           # the captured graph holds their raw pointers: keep the tensors alive with it
@@ -411,9 +430,9 @@ class StepEngine:
                 tgt = torch.empty(m, 32, 27, dtype=torch.float32, device=self.device) if not self.encoder_only else None
                 self._predict_ws[m] = (cfg, ws, tgt)
             cfg, ws, tgt = self._predict_ws[m]
-            if pd_seed is not None:         # use_pd: hits sampled from the probabilities; the chunk offset keeps the streams of the chunks apart
-                self.lib.call("gt_predict_pd", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x[i:i + m]), _ptr(out[i:i + m]),
-                              ctypes.c_uint32((int(pd_seed) + 0x9E3779B9 * (i // chunk)) & 0xFFFFFFFF), _ptr(tgt), _ptr(ws), self.stream)
+            if pd_seed is not None:         # use_pd: hits sampled from the probabilities, hashed from the element's index in the WHOLE set
+                self.lib.call("gt_predict_pd_at", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x[i:i + m]), _ptr(out[i:i + m]),
+                              ctypes.c_uint32(int(pd_seed) & 0xFFFFFFFF), ctypes.c_int64(i), _ptr(tgt), _ptr(ws), self.stream)
                 continue
             self.lib.call("gt_predict", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x[i:i + m]), _ptr(out[i:i + m]),
                           ctypes.c_float(thres), int(use_thres), _ptr(tgt), _ptr(ws), self.stream)
