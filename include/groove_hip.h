@@ -92,6 +92,10 @@ int gt_param_layout(const gt_config* cfg, int64_t* offsets, int64_t* sizes, int3
 
 /* Bytes of scratch the forward/backward of this config needs (saved activations + temporaries). */
 size_t gt_workspace_bytes(const gt_config* cfg);
+/* Call ONCE on a freshly allocated workspace, before its first use (stream-ordered; the library itself never allocates): zeroes the
+ * pair-exchange region of the four-workgroups-per-sequence forward (gt_set_seq_quad), whose granules are zero between launches by
+ * protocol.  A no-op for configs without such a region.  No counterpart in the reference (torch owns its activations there). */
+int gt_workspace_init(const gt_config* cfg, float* ws, gt_stream_t stream);
 /* Test/debug: locate a named saved activation inside the workspace (offset & count in floats).
  * names: "x0","a0","qkv","P","ctx","xhat1","rstd1","x1","hact","xhat2","rstd2","x2","memory",
  * "enc_xhat","dlogits" ... ; layer = global layer index (decoder layers follow the encoder's). */
@@ -209,6 +213,13 @@ int gt_set_seq(int on);
  * d_model 128 or 32: -1 = default (when 2 x batch workgroups fit the CUs once; d_model 32 only with dim_feedforward >= 256), 0 = off,
  * 1 = on (env GT_SEQ_SPLIT=0/1 does the same).  Same results bit for bit: the split is over token rows. */
 int gt_set_seq_split(int on);
+/* FOUR workgroups per sequence in the forward of the SPLIT mode at d_model 128 (csrc/gt_seq.h, QUAD): the two workgroups of a 16-row
+ * half are column partners that each compute half of dim_feedforward and swap their partial FFN2 results through one in-launch pair
+ * exchange per layer (8-byte tagged granules, agent-scope stores / loads) -- the forward then fills 4 x batch CUs instead of 2 x batch.
+ * -1 = default (whenever 4 x batch workgroups fit the CUs at once and dim_feedforward % 32 == 0), 0 = off, 1 = on under the same
+ * condition (env GT_SEQ_QUAD=0/1).  Results agree with the SPLIT mode to fp32 rounding (the FFN2 contraction is summed as two halves);
+ * bitwise repeatable run to run.  Needs gt_workspace_init on the workspace. */
+int gt_set_seq_quad(int on);
 /* Weight gradients as RIDER workgroups (csrc/gt_seq_wg.h): in the SPLIT mode at d_model 128 the backward phases' launches carry, on
  * the CUs their 2 x batch sequence workgroups leave idle, the weight gradients whose operands the earlier phases completed; one
  * workgroup owns a 32 x 64 gradient tile over ALL tokens (no atomics: bitwise reproducible), and a tail launch does what cannot ride

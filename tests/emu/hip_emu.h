@@ -52,6 +52,12 @@ extern dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 extern unsigned char* dyn_smem_;
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 void block_sync();
+// A workgroup that waits for data ANOTHER workgroup of the same launch publishes (the pair exchange of gt_seq.h's QUAD forward): the
+// hardware runs both at once and the waiter spins; the emulator runs workgroups one after the other, so the waiter gives up here --
+// every thread of the block calls this at the same program point, none returns -- and launch() runs the block again from the start
+// after the others (its writes so far are repeated with the same values).  launch_serial: a per-launch number for the exchange tags.
+[[noreturn]] void block_retry();
+extern unsigned launch_serial;
 void wave_rendezvous();     // all live lanes of the calling wave (hardware: lanes run in lock-step; the emulator: fibers do not)
 float wave_shfl(float v, int src_lane);
 f32x4 mfma16(float a, float b, f32x4 c);
@@ -186,6 +192,14 @@ void wave_sync() { fibers[cur].state = WAIT_WAVE; yield_to_sched(); }
 }  // namespace
 
 void wave_rendezvous() { wave_sync(); }
+static bool retry_ = false;
+unsigned launch_serial = 0;
+void block_retry() {
+  retry_ = true;
+  fibers[cur].state = DONE;
+  swapcontext(&fibers[cur].ctx, &sched_ctx);
+  abort();                                        // (never resumed)
+}
 void block_sync() { fibers[cur].state = WAIT_BLOCK; ++fibers[cur].nbar; yield_to_sched(); }
 
 float wave_shfl(float v, int src_lane) {
@@ -291,12 +305,22 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
   blockDim_ = block;
   gridDim_ = grid;
   body_ = &body;
+  ++launch_serial;
+  std::vector<dim3> pending, again;
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
-      for (unsigned x = 0; x < grid.x; ++x) {
-        blockIdx_ = dim3(x, y, z);
-        run_block();
-      }
+      for (unsigned x = 0; x < grid.x; ++x) pending.push_back(dim3(x, y, z));
+  while (!pending.empty()) {
+    again.clear();
+    for (const dim3& blk : pending) {
+      blockIdx_ = blk;
+      retry_ = false;
+      run_block();
+      if (retry_) again.push_back(blk);           // waited for a workgroup that has not run yet: once more after the others
+    }
+    if (again.size() == pending.size()) { fprintf(stderr, "hip_emu: every remaining workgroup waits for another one (%zu blocks)\n", again.size()); abort(); }
+    pending.swap(again);
+  }
   dyn_smem_ = nullptr;
 }
 }  // namespace emu

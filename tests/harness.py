@@ -64,7 +64,10 @@ class Runner:
         self.lib = emu_lib() if backend == "emu" else _lib.get_lib()
         self.lib.cdll.gt_set_seq(int(bool(seq)))  # process-global switch: sequence-resident kernels (default where supported)
         # seq = "split" / "whole": force / forbid their two-workgroups-per-sequence mode (d_model 128); True: the library's choice
-        self.lib.cdll.gt_set_seq_split(1 if seq in ("split", "split-noride") else 0 if seq == "whole" else -1)
+        self.lib.cdll.gt_set_seq_split(1 if seq in ("split", "split-noride", "split-noquad") else 0 if seq == "whole" else -1)
+        # the SPLIT forward with four workgroups per sequence (column partners + pair exchange) is the library's choice wherever
+        # 4 x batch workgroups fit the chip; "split-noquad": two workgroups per sequence in the forward too
+        self.lib.cdll.gt_set_seq_quad(0 if seq == "split-noquad" else -1)
         # "split": weight gradients as rider workgroups of the backward phases where the library chooses to (idle CUs); "split-noride":
         # the grouped dispatch at the end of backward
         self.lib.cdll.gt_set_seq_ride(0 if seq == "split-noride" else -1)
@@ -79,7 +82,8 @@ class Runner:
         for (n, shp), (off, size, rows, cols) in zip(self.names, self.entries):
             assert int(np.prod(shp)) == size and shp[0] == rows, (n, shp, size, rows, cols)
         self.M = B * 32
-        self.ws = self.Buf(np.zeros(self.lib.workspace_floats(self.c), np.float32))
+        self.ws = self.Buf(np.full(self.lib.workspace_floats(self.c), 7.25, np.float32))     # (garbage: gt_workspace_init zeroes what must be zero)
+        self.lib.call("gt_workspace_init", ctypes.byref(self.c), self.ws.ptr, ctypes.c_void_p(0))
         self.pe = self.Buf(layout.positional_encoding(cfg["d_model"]))
         self.hvo = self.Buf(np.zeros((self.M, 27), np.float32))
         self.grads = self.Buf(np.zeros(self.total, np.float32))

@@ -62,7 +62,12 @@ if os.environ.get("GT_SEQ_SPLIT") == "1":
             b = 2 + 10 * (ph - 1)
             print("   load state %d  attention %d  out-proj %d  norm1 %d  FFN1 %d  FFN2 %d  norm2 %d  then %d" %
                   (st[b + 1] - st[60 + 2 * ph], st[b + 2] - st[b + 1], st[b + 3] - st[b + 2], st[b + 4] - st[b + 3], st[b + 5] - st[b + 4],
-                   st[b + 6] - st[b + 5], st[b + 7] - st[b + 6], st[61 + 2 * ph] - st[b + 7]))
+                   st[b + 6] - st[b + 5], st[b + 7] - st[b + 6], st[61 + 2 * ph] - st[b + 7]), end="")
+            q = 300 + 4 * (ph - 1)
+            if st[q] > st[b + 5]:      # QUAD forward: the FFN2 stage = half-K product, send, wait for the partner's partial tile
+                print("   [FFN2: product %d  send %d  wait + receive %d]" % (st[q] - st[b + 5], st[q + 1] - st[q], st[q + 2] - st[q + 1]))
+            else:
+                print()
         else:
             print()
     for ph in range(L + 1):
@@ -81,3 +86,13 @@ if os.environ.get("GT_SEQ_SPLIT") == "1":
             c = 102
             print("   prologue %d  norm2 bwd %d  FFN2 dgrad %d  FFN1 dgrad %d  norm1 bwd %d  out-proj dgrad %d" %
                   (st[101] - st[160], st[c] - st[101], st[c + 1] - st[c], st[c + 2] - st[c + 1], st[c + 3] - st[c + 2], st[c + 4] - st[c + 3]))
+
+if os.environ.get("GT_SEQ_SPLIT") == "1" and len(st) >= 1024 + 4 * 512:
+    w = st[1024:1024 + 4 * 512].reshape(512, 4)
+    w = w[w[:, 0] != 0]
+    if len(w):
+        cyc, rt = w[:, 2] - w[:, 0], (w[:, 3] - w[:, 1]) * 10.0          # shader cycles; ns (100 MHz clock)
+        t0 = w[:, 1].min()
+        print(" forward phase 1, all %d workgroups: cycles min %d / median %d / max %d;  ns min %d / median %d / max %d;  clock %.2f GHz (median);"
+              "  first start -> last end %d ns; start spread %d ns" % (len(w), cyc.min(), np.median(cyc), cyc.max(), rt.min(), np.median(rt), rt.max(),
+                                                                      np.median(cyc / rt), (w[:, 3].max() - t0) * 10, (w[:, 1].max() - t0) * 10))

@@ -186,6 +186,7 @@ struct WLayout {
   int64_t hvo_tmp, dlogits, loss_part, dctx, dmem, da0_dec, ln_part, ln_part_stride, total, stamps = 0;
   int64_t pack_f = -1, pack_b = -1, pack_stride = 0;   // fragment-ordered weight copies of the sequence-resident kernels (gt_seq.h)
   int64_t seq_dctx = -1;                               // hand-over buffer of their two-workgroups-per-sequence (SPLIT) backward phases
+  int64_t seq_xchg = -1, seq_xchg_n = 0;               // pair-exchange region of their four-workgroups-per-sequence (QUAD) forward
   struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; };
   std::vector<TmpSet> set;                           // 2 alternating sets, or one per layer (wgrad_deferred)
 };
@@ -247,9 +248,10 @@ static WLayout ws_layout(const gt_config& c) {
     W.pack_stride = (int64_t)4 * d * d + (int64_t)2 * d * F;
     W.pack_f = add(W.pack_stride * c.n_enc_layers); W.pack_b = add(W.pack_stride * c.n_enc_layers);
     W.seq_dctx = add(2 * M * d);
+    if (d == 128) { W.seq_xchg_n = gt_seq_xchg_floats(c.batch); W.seq_xchg = add(W.seq_xchg_n); }
   }
 #ifdef GT_SEQ_STAMPS
-  W.stamps = add(2048);
+  W.stamps = add(2048 + 2 * 4 * 512);
 #endif
   W.total = cur;
   return W;
@@ -257,6 +259,17 @@ static WLayout ws_layout(const gt_config& c) {
 extern "C" size_t gt_workspace_bytes(const gt_config* cfg) {
   if (check_cfg(cfg)) return 0;
   return (size_t)ws_layout(*cfg).total * sizeof(float);
+}
+// One-off preparation of a fresh workspace: zeroes the region whose protocol relies on it (the QUAD forward's pair exchange: every
+// granule is zero between launches, the consumer re-zeroes what it has read).  Stream-ordered, capturable; a no-op for shapes without
+// such a region.
+static int launch_status(const char* what);
+extern "C" int gt_workspace_init(const gt_config* cfg, float* ws, gt_stream_t stream) {
+  if (check_cfg(cfg)) return -1;
+  if (!ws) return gt_fail("gt_workspace_init: ws must not be NULL");
+  const WLayout W = ws_layout(*cfg);
+  if (W.seq_xchg >= 0) (void)hipMemsetAsync(ws + W.seq_xchg, 0, (size_t)W.seq_xchg_n * sizeof(float), (hipStream_t)stream);
+  return launch_status("gt_workspace_init");
 }
 extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int64_t* offset, int64_t* count) {
   if (check_cfg(cfg)) return -1;
@@ -271,8 +284,9 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   else if (n == "memory") set(W.memory, M * d); else if (n == "y0") set(W.y0, M * d); else if (n == "b0") set(W.b0, M * d);
   else if (n == "dec_final") set(W.dec_final, M * d); else if (n == "dlogits") set(W.dlogits, M * GT_TGT);
   else if (n == "dmem") set(W.dmem, M * d); else if (n == "dctx") set(W.dctx, M * d);
+  else if (n == "seq_xchg") set(W.seq_xchg, W.seq_xchg_n);
 #ifdef GT_SEQ_STAMPS
-  else if (n == "stamps") set(W.stamps, 2048);
+  else if (n == "stamps") set(W.stamps, 2048 + 2 * 4 * 512);
 #endif
   else if (n == "dzA" || n == "dzAm" || n == "dzB" || n == "dzBm" || n == "dzC" || n == "dzCm" || n == "dhid" || n == "dqkv" || n == "dqkvx") {
     // backward temporaries of one layer (kept per layer while the weight gradients are deferred to the end of backward)
@@ -701,6 +715,16 @@ static bool seq_ride(const gt_config& c) {
   if (g_seq_ride >= 0) return g_seq_ride != 0 && idle >= 1;
   return idle >= GT_SEQ_RIDE_MIN_IDLE;
 }
+// QUAD forward (gt_seq.h): four workgroups per sequence -- row halves x column partners that share the FFN through one pair exchange per
+// layer -- while ALL of them fit the chip at once (one workgroup per CU: the partners spin on each other).  -1 = by shape, 0 / 1 forced
+// (GT_SEQ_QUAD, gt_set_seq_quad; forcing it on still requires the grid to fit).
+static int g_seq_quad = -1;
+extern "C" int gt_set_seq_quad(int on) { g_seq_quad = on < 0 ? -1 : on != 0; return 0; }
+static bool seq_quad(const gt_config& c) {
+  if (c.d_model != 128 || c.dim_ff % 32 != 0 || !seq_split(c) || 4 * c.batch > seq_cu_count()) return false;
+  if (g_seq_quad < 0) { const char* e = getenv("GT_SEQ_QUAD"); if (e) g_seq_quad = e[0] != '0'; }
+  return g_seq_quad != 0;
+}
 static bool seq_supported(const gt_config& c) {
   const int hd = c.d_model / c.n_heads;
   return c.n_dec_layers == 0 && c.precision == 0 && c.d_model % 16 == 0 && c.d_model <= 128 && c.dim_ff % 16 == 0 &&
@@ -747,7 +771,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.dlogits = x.W.dlogits; a.da0 = x.W.dctx; a.ln_part = x.W.ln_part; a.ln_part_stride = x.W.ln_part_stride;
   a.stamps = x.W.stamps;
   a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
-  a.dctx = x.W.seq_dctx; a.phase = 0;
+  a.dctx = x.W.seq_dctx; a.xchg = x.W.seq_xchg; a.phase = 0;
   a.loss_y = nullptr; a.loss_penalty = 0.f; a.loss_stats = nullptr; a.loss_part = nullptr; a.loss_ticket = nullptr;
   a.grd = nullptr; a.nseq = 0; a.wg_accumulate = 0; a.ride_last_k = x.M; a.out_early = 0; a.tail_phase = 0; a.tail_ksplit = 1; a.ln_nwg = 0; a.bump = nullptr;
   return a;
@@ -768,12 +792,16 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
   gt_prof_tag("seq_fwd", fl, 4.0 * x.M * (x.c.src_dim + x.c.n_enc_layers * (9.0 * x.d + x.F) + 27.0));
   const int hc = x.hd < 16 ? 0 : x.hd;             // head-dim class (one instantiation each: the attention bodies' registers differ 4x)
   if (seq_split(x.c)) {
-    const dim3 grid(2 * x.c.batch);
-    for (int p = 0; p < x.c.n_enc_layers; ++p) {               // one launch per encoder layer (gt_seq.h, SPLIT)
+    const bool quad = seq_quad(x.c);                           // four workgroups per sequence: column partners share the FFN
+    // GT_SEQ_QUAD_PRO=1: input layer + in-proj(0) as a prologue launch of their own instead of four times over inside phase 0 --
+    // measured neutral at the headline shape (0.2076 vs 0.2073 ms: one more launch for 17 k fewer cycles of phase 0), so off
+    static const int quad_pro = [] { const char* e = getenv("GT_SEQ_QUAD_PRO"); return (e && e[0] == '1') ? 1 : 0; }();
+    a.quad_pro = quad ? quad_pro : 0;
+    for (int p = a.quad_pro ? -1 : 0; p < x.c.n_enc_layers; ++p) {   // one launch per encoder layer (gt_seq.h, SPLIT) [+ QUAD's prologue]
       SeqArgs ap = a;
       ap.phase = p;
-      if (p > 0) gt_prof_tag("seq_fwd", 0.0, 0.0);          // (flops and bytes of the whole forward are on the first phase's tag)
-      gt_seq_launch_fwd(ap, x.d, hc, true, 2 * x.c.batch, x.s);
+      if (p > (a.quad_pro ? -1 : 0)) gt_prof_tag("seq_fwd", 0.0, 0.0);          // (flops and bytes of the whole forward are on the first phase's tag)
+      gt_seq_launch_fwd(ap, x.d, hc, true, (quad ? 4 : 2) * x.c.batch, x.s, quad);
     }
     return 0;
   }

@@ -25,8 +25,15 @@
   else if ((dm) <= 64) GT_SEQ_LAUNCH_DP(K, 64, dm, hc, grid, block, s, a)      \
   else GT_SEQ_LAUNCH_DP(K, 128, dm, hc, grid, block, s, a)
 void gt_seq_launch_pack(const SeqArgs& a, unsigned nblocks, hipStream_t s) { gt_launch(seq_pack_kernel, dim3(nblocks), dim3(256), s, a); }
-void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s) {
+void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s, bool quad) {
   const dim3 grid(nblocks), block(GT_SEQ_NT);
+  if (quad) {                                  // four workgroups per sequence (d_model 128 exactly): nblocks = 4 x batch
+    if (hc == 0) gt_launch(seq_fwd_kernel<128, 0, true, true, true>, grid, block, s, a);
+    else if (hc == 16) gt_launch(seq_fwd_kernel<128, 16, true, true, true>, grid, block, s, a);
+    else if (hc == 32) gt_launch(seq_fwd_kernel<128, 32, true, true, true>, grid, block, s, a);
+    else gt_launch(seq_fwd_kernel<128, 64, true, true, true>, grid, block, s, a);
+    return;
+  }
   if (split) { GT_SEQ_LAUNCH_SPLIT(seq_fwd_kernel, d_model, hc, grid, block, s, a) }
   else { GT_SEQ_DISPATCH(seq_fwd_kernel, d_model, hc, grid, block, s, a) }
 }

@@ -46,7 +46,11 @@ __shared__ long long* gt_sub_ptr;      // sub-stage stamps of ONE matmul stage (
 #define GT_SUBSTAMP(i) do { if (threadIdx.x == 0 && gt_sub_ptr) gt_sub_ptr[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define GT_SUBWAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #define GT_SUBSET(on) do { if (threadIdx.x == 0) gt_sub_ptr = ((on) && blockIdx.x == 0) ? reinterpret_cast<long long*>(a.ws + a.stamps) + 200 : nullptr; } while (0)
+// every workgroup of forward phase 1: [shader clock, 100 MHz real-time clock] at its start and end -> int64 slots 1024 + 4 * blockIdx.x ..
+#define GT_WGSTAMP(k) do { if (threadIdx.x == 0 && a.phase == 1 && blockIdx.x < 512) { long long* q_ = reinterpret_cast<long long*>(a.ws + a.stamps) + 1024 + 4 * blockIdx.x + 2 * (k); \
+    q_[0] = (long long)__builtin_amdgcn_s_memtime(); q_[1] = (long long)__builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
+#define GT_WGSTAMP(k) do { } while (0)
 #define GT_STAMP(i) do { } while (0)
 #define GT_SUBSTAMP(i) do { } while (0)
 #define GT_SUBWAIT() do { } while (0)
@@ -92,6 +96,88 @@ __device__ __forceinline__ float seq_row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
 #endif
   return v;
+}
+
+// ---- pair exchange between the two COLUMN PARTNERS of a QUAD forward (see seq_fwd_kernel): each of the two workgroups holds a partial
+// [16][128] result (its half of a contraction) as one 16 x 16 accumulator tile per wave and needs the other's.  A value travels as an
+// 8-byte granule {value bits, tag} written by ONE agent-scope store (sc1: write-through, never torn) and read by agent-scope loads that
+// poll the granule itself -- no separate flag, no fence, no barrier: one fabric round trip (MI355X_MICROARCH.md, handoff-1to1 / Guideline
+// 16 R2).  Slot layout per workgroup: [4 accumulator registers][512 threads] granules, so a wave-instruction moves 512 contiguous bytes;
+// the partner's lane (wave, lane) reads exactly the granules its own (wave, lane) counterpart wrote.  The CONSUMER zeroes what it has
+// read: every slot is written once and consumed once per launch, so the region is all zero between launches (gt_workspace_init zeroes
+// it once) and a stale tag can never match.  The spin is bounded: a partner that never arrives (it would mean the two were not
+// co-resident) raises the region's error word instead of hanging the GPU.
+#define GT_XTAG 0x5EC0DE01u
+#define GT_XCHG_WG_GRANULES (4 * GT_SEQ_NT)          /* 8-byte granules per workgroup slot (16 KB) */
+#ifndef GT_XCHG_SPIN_MAX
+#define GT_XCHG_SPIN_MAX (1 << 22)
+#endif
+#ifdef GT_EMU
+static inline uint32_t gt_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float gt_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+#define GT_XTAG_NOW (GT_XTAG + emu::launch_serial)     /* (the emulator re-runs a waiting workgroup: a per-launch tag instead of the reset) */
+#else
+__device__ __forceinline__ uint32_t gt_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float gt_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+#define GT_XTAG_NOW GT_XTAG
+#endif
+// one value / one arrival counter shared between workgroups of a launch without fences: write-through store, drained; returning add
+__device__ __forceinline__ void seq_pub_store(float* p, const float v) {
+#ifdef GT_EMU
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ float seq_pub_load(const float* p) {
+#ifdef GT_EMU
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ unsigned seq_pub_ticket(unsigned* counter) {       // (after this lane's seq_pub_store calls)
+#ifdef GT_EMU
+  return atomicAdd(counter, 1u);
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void seq_xchg_put(unsigned long long* slot, const f32x4& v, const int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned long long w = ((unsigned long long)GT_XTAG_NOW << 32) | (unsigned long long)gt_f2u(v[j]);
+#ifdef GT_EMU
+    slot[j * GT_SEQ_NT + tid] = w;
+#else
+    __hip_atomic_store(slot + j * GT_SEQ_NT + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  }
+}
+__device__ __forceinline__ f32x4 seq_xchg_get(unsigned long long* slot, const int tid, unsigned* err) {
+  unsigned long long w[4];
+#ifdef GT_EMU
+  bool ok = true;
+  for (int j = 0; j < 4; ++j) { w[j] = slot[j * GT_SEQ_NT + tid]; ok = ok && (uint32_t)(w[j] >> 32) == GT_XTAG_NOW; }
+  if (!ok) emu::block_retry();                               // the partner has not run yet: this workgroup is run again after it
+#else
+  int spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[j] = __hip_atomic_load(slot + j * GT_SEQ_NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = ok && (uint32_t)(w[j] >> 32) == GT_XTAG;
+    }
+    if (__all(ok)) break;                                      // (wave-uniform exit: the lanes of a wave leave together)
+    if (++spins > GT_XCHG_SPIN_MAX) { if ((tid & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) __hip_atomic_store(slot + j * GT_SEQ_NT + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  return f32x4{gt_u2f((uint32_t)w[0]), gt_u2f((uint32_t)w[1]), gt_u2f((uint32_t)w[2]), gt_u2f((uint32_t)w[3])};
 }
 
 // ================================================================================================================ matmul primitives
@@ -404,6 +490,35 @@ __device__ __forceinline__ SeqB<8> seq_splitk_first(const float* __restrict__ Wp
   seq_b_load<8, true>(b, Wp, nks, t, (part < KS ? part : 0) * per, 8, lane);
   return b;
 }
+// acc0 / acc1 += A[:, 16 ks0 .. 16 ks1) * B for column tile t of a product whose WHOLE contraction has nkt k-steps (the pack's stride):
+// B in chunks of 8 k-steps, the next chunk requested before the current one's MFMAs; pre: the first chunk, requested by the caller
+template <bool HALF>
+__device__ __forceinline__ void seq_mm_krange(f32x4& acc0, f32x4& acc1, const float* ap, const int lda, const float* __restrict__ Wp, const int nkt,
+                                              const int t, const int ks0, const int ks1, const int lane, const bool have_pre, const SeqB<8> pre) {
+  SeqB<8> b[2];
+  if (ks1 > ks0 && ((ks1 - ks0) & 7) == 0) {                       // whole chunks only (F and 3 d multiples of 128 per part): branch-free bodies
+    if (have_pre) b[0] = pre;                                     // (workgroup-uniform)
+    else seq_b_load<8, true>(b[0], Wp, nkt, t, ks0, 8, lane);
+    for (int c0 = ks0; c0 < ks1; c0 += 16) {                       // two chunks per trip: the buffer index stays compile-time
+      if (c0 + 8 < ks1) seq_b_load<8, true>(b[1], Wp, nkt, t, c0 + 8, 8, lane);
+      seq_b_mma<8, true, HALF>(acc0, acc1, b[0], ap + 16 * c0, lda, 8);
+      if (c0 + 8 < ks1) {
+        if (c0 + 16 < ks1) seq_b_load<8, true>(b[0], Wp, nkt, t, c0 + 16, 8, lane);
+        seq_b_mma<8, true, HALF>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, 8);
+      }
+    }
+  } else {
+    if (ks0 < ks1) seq_b_load<8>(b[0], Wp, nkt, t, ks0, ks1 - ks0, lane);
+    for (int c0 = ks0; c0 < ks1; c0 += 16) {
+      if (c0 + 8 < ks1) seq_b_load<8>(b[1], Wp, nkt, t, c0 + 8, ks1 - c0 - 8, lane);
+      seq_b_mma<8, false, HALF>(acc0, acc1, b[0], ap + 16 * c0, lda, ks1 - c0);
+      if (c0 + 8 < ks1) {
+        if (c0 + 16 < ks1) seq_b_load<8>(b[0], Wp, nkt, t, c0 + 16, ks1 - c0 - 16, lane);
+        seq_b_mma<8, false, HALF>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, ks1 - c0 - 8);
+      }
+    }
+  }
+}
 template <bool HALF>
 __device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
                                               float* sR, const int srs, const int wave, const int lane, const bool have_pre = false,
@@ -416,29 +531,7 @@ __device__ __forceinline__ void seq_mm_splitk(const float* sA, const int lda, co
   const int n0 = t * 16;
   const float* ap = sA + l16 * lda + 4 * lg;
   f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  SeqB<8> b[2];
-  if (ks1 > ks0 && ((ks1 - ks0) & 7) == 0) {                       // whole chunks only (F and 3 d multiples of 128 per part): branch-free bodies
-    if (have_pre) b[0] = pre;                                     // (workgroup-uniform)
-    else seq_b_load<8, true>(b[0], Wp, nks, t, ks0, 8, lane);
-    for (int c0 = ks0; c0 < ks1; c0 += 16) {                       // two chunks per trip: the buffer index stays compile-time
-      if (c0 + 8 < ks1) seq_b_load<8, true>(b[1], Wp, nks, t, c0 + 8, 8, lane);
-      seq_b_mma<8, true, HALF>(acc0, acc1, b[0], ap + 16 * c0, lda, 8);
-      if (c0 + 8 < ks1) {
-        if (c0 + 16 < ks1) seq_b_load<8, true>(b[0], Wp, nks, t, c0 + 16, 8, lane);
-        seq_b_mma<8, true, HALF>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, 8);
-      }
-    }
-  } else {
-    if (ks0 < ks1) seq_b_load<8>(b[0], Wp, nks, t, ks0, ks1 - ks0, lane);
-    for (int c0 = ks0; c0 < ks1; c0 += 16) {
-      if (c0 + 8 < ks1) seq_b_load<8>(b[1], Wp, nks, t, c0 + 8, ks1 - c0 - 8, lane);
-      seq_b_mma<8, false, HALF>(acc0, acc1, b[0], ap + 16 * c0, lda, ks1 - c0);
-      if (c0 + 8 < ks1) {
-        if (c0 + 16 < ks1) seq_b_load<8>(b[0], Wp, nks, t, c0 + 16, ks1 - c0 - 16, lane);
-        seq_b_mma<8, false, HALF>(acc0, acc1, b[1], ap + 16 * (c0 + 8), lda, ks1 - c0 - 8);
-      }
-    }
-  }
+  seq_mm_krange<HALF>(acc0, acc1, ap, lda, Wp, nks, t, ks0, ks1, lane, have_pre, pre);
   float* r = sR + part * 32 * srs + n0 + 4 * lg;
   *reinterpret_cast<float4*>(r + l16 * srs) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
   if (!HALF) *reinterpret_cast<float4*>(r + (16 + l16) * srs) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
@@ -491,6 +584,16 @@ __device__ __forceinline__ void seq_tile_out(float* __restrict__ dst, const floa
   }
 }
 
+// columns [c0, c0 + ncol) of rows rb .. rb + nrows - 1 of the tile -> the same columns of the sequence's rows (row stride ldd floats)
+__device__ __forceinline__ void seq_tile_out_cols(float* __restrict__ dst, const int ldd, const float* sT, const int str, const int c0, const int ncol,
+                                                  const int tid, const int rb, const int nrows) {
+  const int q4 = ncol >> 2;
+  for (int e = tid; e < nrows * q4; e += GT_SEQ_NT) {
+    const int r = rb + e / q4, c = c0 + (e % q4) * 4;
+    *reinterpret_cast<float4*>(dst + (unsigned)(r * ldd + c)) = *reinterpret_cast<const float4*>(sT + r * str + c);
+  }
+}
+
 // LayerNorm forward: z (this thread's CW values, from zfun(row, c0, z)) -> y = LN(z) gamma + beta -> the LDS tile sY and the
 // global y / xhat / rstd rows of this sequence (gy, gxhat, grstd: wave-uniform bases of the sequence's first row)
 template <int DP, bool HALF, typename ZFun>
@@ -520,10 +623,12 @@ __device__ __forceinline__ void seq_ln_fwd(ZFun zfun, float* sY, const int str, 
     for (int e = 0; e < CW; ++e) { xh[e] = (z[e] - mean) * rs; y[e] = xh[e] * ga[e] + be[e]; }
     const unsigned o = (unsigned)(row * d + c0);
     SeqVec<CW>::st(sY + row * str + c0, y);
-    SeqVec<CW>::st(gy + o, y);
-    SeqVec<CW>::st(gxhat + o, xh);
+    if (gy != nullptr) {                                      // (wave-uniform; nullptr: another workgroup saves these rows -- QUAD)
+      SeqVec<CW>::st(gy + o, y);
+      SeqVec<CW>::st(gxhat + o, xh);
+    }
   }
-  if (seg == 0) grstd[row] = rs;
+  if (seg == 0 && gy != nullptr) grstd[row] = rs;
 }
 
 // LayerNorm backward: g (from gfun) -> dz = LNbwd(g) -> sDz (LDS, unmasked: the residual gradient), dz * dropout mask -> sDzm
@@ -675,7 +780,7 @@ __device__ __forceinline__ void seq_attn_fwd(const SeqAttn& a, float* ctx, const
     const unsigned o = (unsigned)(i * 32 + 16 * tj + 4 * g);
     float4 pv;
     pv.x = sv[tj][0] * inv; pv.y = sv[tj][1] * inv; pv.z = sv[tj][2] * inv; pv.w = sv[tj][3] * inv;
-    *reinterpret_cast<float4*>(a.P + o) = pv;
+    if (a.P != nullptr) *reinterpret_cast<float4*>(a.P + o) = pv;      // (nullptr: the column partner saves the probabilities -- QUAD)
     pd[tj][0] = pv.x * seq_dmul(dk, key, a.pidx + o);
     pd[tj][1] = pv.y * seq_dmul(dk, key, a.pidx + o + 1);
     pd[tj][2] = pv.z * seq_dmul(dk, key, a.pidx + o + 2);
@@ -993,6 +1098,20 @@ __device__ __forceinline__ void seq_attn_bwd_small(float* sQ, const int ldq, con
 #define GT_SEQ_VATTN 1          /* 0: head_dim < 16 stays on the zero-padded MFMA form */
 #endif
 
+// SPLIT / QUAD kernels: which (sequence, part) a block is.  Blocks are dealt round-robin over the 8 XCDs (observed, speed only), so with
+// the plain order the 2 / 4 workgroups of one sequence -- which all load the same q / k / v tile at the start of a phase, and in QUAD
+// swap partial tiles -- sit on different L2s.  GT_SEQ_XCD_MAP: block x -> XCD x % 8, slot x / 8; the sequence's workgroups take
+// consecutive slots of one XCD (its state crosses the fabric once per launch, not 2 / 4 times).  Any batch: nper x 8 x ceil(B / 8) is
+// not the grid size, so the map applies when B % 8 == 0 and the plain order otherwise.  Returns sequence * nper + part.
+#ifndef GT_SEQ_XCD_MAP
+#define GT_SEQ_XCD_MAP 1
+#endif
+__device__ __forceinline__ int seq_vblock(const int bid, const int nper, const int B) {
+  if (!GT_SEQ_XCD_MAP || (B & 7) != 0 || bid >= nper * B) return bid;
+  const int xcd = bid & 7, slot = bid >> 3;
+  return ((slot / nper) * 8 + xcd) * nper + slot % nper;
+}
+
 // ================================================================================================================ forward
 // LDS geometry of a d_model class.  RP: most split-K parts a [32][d] result can come in (d = 16 -> 8 parts ... d > 64 -> 1).
 template <int DP> struct SeqGeo {
@@ -1007,8 +1126,18 @@ template <int DP> struct SeqGeo {
 // phase l + 1: attention(l) .. norm2(l), then in-proj(l + 1) or the output layer.  2 x batch workgroups fill twice the CUs: the
 // path for small batches of the d_model-128 class, where a sequence's matmuls are bound by the MFMA rate of one CU.
 // (Round 3: phase 0 and phase 1 are ONE launch -- the first phase computes input layer + in-proj(0) for all 32 rows; a.phase = layer.)
-template <int DP, int HDC, bool EXACT, bool SPLIT>
+// QUAD (round 4; SPLIT, d_model 128, while 4 x batch workgroups fit the CUs): FOUR workgroups per sequence -- the two 16-row halves x two
+// COLUMN PARTNERS (blockIdx.x & 1).  At batch 64 the SPLIT forward left 128 of the 256 CUs dark; the partners of a row half share its
+// FFN, two thirds of a layer's matmul time: each computes HALF of dim_feedforward -- its 256 columns of FFN1, the partial FFN2 product
+// over them -- and the two [16][128] partial results meet through ONE pair exchange per layer (seq_xchg_*: tagged 8-byte granules, one
+// fabric round trip); both then run the (cheap) norm2 on identical sums.  The in-proj that closes the phase is split by columns too (its
+// result goes to global memory for the next launch anyway: no exchange).  Attention, out-proj and norm1 -- a sixth of the phase -- are
+// computed by both; saved activations are written by one of the two.  The last phase's output layer + loss run on partner 0 only.
+// Both partners must be resident at once to meet: they are adjacent blocks of a grid that fits the chip (one workgroup per CU by LDS);
+// the spin is bounded (seq_xchg_get).
+template <int DP, int HDC, bool EXACT, bool SPLIT, bool QUAD = false>
 __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
+  static_assert(!QUAD || (SPLIT && EXACT && DP == 128), "QUAD: the SPLIT kernels of d_model 128");
   using G = SeqGeo<DP>;
   constexpr int SX = G::SX, SH = G::SH, SQ = G::SQ, SRS = G::SRS, CW = G::CW, NK = G::NK;
   constexpr int HD = SeqHd<HDC>::HD;
@@ -1019,7 +1148,14 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   float* const sQ = sU;                                      // qkv tile: in-proj -> attention
   float* const sH = sU;                                      // FFN tile: FFN1 -> FFN2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
-  const int b = SPLIT ? blockIdx.x >> 1 : blockIdx.x, rb = SPLIT ? 16 * (blockIdx.x & 1) : 0;
+  // (sequence, part) of this block.  Measured at the headline shape: the map takes the SPLIT backward phases from 103.7 to 101.5 us per step;
+  // the QUAD forward LOSES 3 us with its four workgroups on one XCD (78.1 -> 81.1 us: they read the same lines of one L2 at the same
+  // moments, and a write-through granule leaves the L2 it was written through), so QUAD keeps the plain order
+  const int vb = (SPLIT && !QUAD) ? seq_vblock((int)blockIdx.x, 2, a.B) : (int)blockIdx.x;
+  const int cpart = QUAD ? (vb & 1) : 0;                     // QUAD: column partner
+  const int half_id = QUAD ? (vb >> 1) : vb;                 // SPLIT: (sequence, row half)
+  const int b = SPLIT ? half_id >> 1 : (int)blockIdx.x, rb = SPLIT ? 16 * (half_id & 1) : 0;
+  const bool sv0 = !QUAD || cpart == 0, sv1 = !QUAD || cpart == 1;            // which partner saves what (each activation once)
   const int d = EXACT ? DP : a.d, F = a.F;
   const size_t r0 = (size_t)b * 32;                          // first token row of this sequence
   const float* const zp = gt_zero_ptr();
@@ -1068,7 +1204,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         v.y = (fmaxf(pre.y, 0.f) + pe.y) * seq_dmul(dk, key, idxd + o + 1);
         v.z = (fmaxf(pre.z, 0.f) + pe.z) * seq_dmul(dk, key, idxd + o + 2);
         v.w = (fmaxf(pre.w, 0.f) + pe.w) * seq_dmul(dk, key, idxd + o + 3);
-        if (!HALF || HF || (row >= rb && row < rb + 16)) {     // saved for the backward: every row once (its owner)
+        if ((!HALF || HF || (row >= rb && row < rb + 16)) && sv0) {     // saved for the backward: every row once (its owner)
           *reinterpret_cast<float4*>(ga0 + o) = pre;
           *reinterpret_cast<float4*>(gx0 + o) = v;
         }
@@ -1084,17 +1220,27 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     const float* pl = prm + (int64_t)l * a.pstride;
     const float* kf = ws + a.pack_f + (int64_t)l * a.kstride;
     GT_STAMP(2 + 10 * l);
-    seq_mm_tiles<NK, (3 * DP / 16 + 7) / 8, EXACT, HF>(sX + rbx * SX, SX, d, kf, 3 * d, pl + a.p0.in_b, wave, lane,
-                                                        [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
-      const int col = n0 + 4 * lg;
-      *reinterpret_cast<float4*>(&sQ[(rbx + l16) * SQ + col]) = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
-      if (!HF) *reinterpret_cast<float4*>(&sQ[(16 + l16) * SQ + col]) = make_float4(c1[0] + bi.x, c1[1] + bi.y, c1[2] + bi.z, c1[3] + bi.w);
-    });
+    if constexpr (QUAD && HF) {
+      // own rows, this partner's half of the 3 d columns (its 12 of the 24 column tiles): the tile leaves for global memory right after
+      const int qc0 = cpart * (3 * d / 2);
+      seq_mm_tiles<NK, (3 * DP / 32 + 7) / 8, EXACT, true>(sX + rbx * SX, SX, d, kf + (size_t)(qc0 >> 4) * NK * 256, 3 * d / 2, pl + a.p0.in_b + qc0,
+                                                           wave, lane, [&](int n0, const f32x4& c0, const f32x4&, const float4& bi) {
+        *reinterpret_cast<float4*>(&sQ[(rbx + l16) * SQ + qc0 + n0 + 4 * lg]) = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
+      });
+    } else {
+      seq_mm_tiles<NK, (3 * DP / 16 + 7) / 8, EXACT, HF>(sX + rbx * SX, SX, d, kf, 3 * d, pl + a.p0.in_b, wave, lane,
+                                                          [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
+        const int col = n0 + 4 * lg;
+        *reinterpret_cast<float4*>(&sQ[(rbx + l16) * SQ + col]) = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
+        if (!HF) *reinterpret_cast<float4*>(&sQ[(16 + l16) * SQ + col]) = make_float4(c1[0] + bi.x, c1[1] + bi.y, c1[2] + bi.z, c1[3] + bi.w);
+      });
+    }
     GT_BARRIER();
     GT_STAMP(2 + 10 * l + 1);
   };
   // ---- the rest of layer l: attention .. norm2 -> the next layer's input in sX (own rows); ends with a barrier
-  auto layer_rest = [&](const int l, const bool save_qkv) {
+  // (returns true when this workgroup is done with the launch: QUAD's partner 1 in the last layer, once its FFN2 partial is on its way)
+  auto layer_rest = [&](const int l, const bool save_qkv) -> bool {
     const float* pl = prm + (int64_t)l * a.pstride;          // this layer's parameters / saved activations (wave-uniform bases)
     const float* kf = ws + a.pack_f + (int64_t)l * a.kstride;                    // its fragment-ordered weights: in_w, out_w, w1, w2
     const float* kf_out = kf + 3 * d * d, *kf_w1 = kf + 4 * d * d, *kf_w2 = kf_w1 + d * F;
@@ -1104,7 +1250,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     // ---- attention: operands from the LDS qkv tile, P to global, ctx to the LDS tile.  Whole: wave pair p takes head h4 + p and the
     // pair's two waves the two query tiles; SPLIT: wave w takes head h8 + w, query tile = the own half.  The qkv tile goes to global
     // here (saved for the backward) -- line-shaped, see seq_tile_out.
-    if (save_qkv) seq_tile_out(wl + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
+    if (save_qkv && sv0) seq_tile_out(wl + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
 #ifndef GT_SEQ_NO_PRE2
     const bool preo = SPLIT && EXACT && DP > 64;              // the out-proj's fragment: in flight under the attention (which loads nothing)
     SeqB<NK> bopre = SeqB<NK>();
@@ -1131,7 +1277,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         if (h < a.H) {
           SeqAttn at;
           at.q = sQ + h * a.hd; at.k = at.q + d; at.v = at.q + 2 * d; at.ldq = SQ; at.hd = a.hd; at.scale = ascale;
-          at.pidx = (uint32_t)((b * a.H + h) * 1024); at.P = wl + a.w0.P + (size_t)(b * a.H + h) * 1024;
+          at.pidx = (uint32_t)((b * a.H + h) * 1024); at.P = sv0 ? wl + a.w0.P + (size_t)(b * a.H + h) * 1024 : nullptr;
           seq_attn_fwd<HD, PAD>(at, sC + h * a.hd, SX, dk, key, HALF ? (rb >> 4) : (wave & 1), lane);
         }
       }
@@ -1140,7 +1286,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     GT_STAMP(sb + 2);
     // ---- out-proj (raw product -> sR part 0); the ctx tile also goes to global here (operand of the out-proj weight gradient)
     {
-      seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid, rb, NROW);
+      if (sv1) seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid, rb, NROW);
       if (DP <= 64 && !SPLIT) seq_mm_square(sC, SX, d, kf_out, sR, SRS, wave, lane);
       else
         seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kf_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
@@ -1159,17 +1305,19 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         SeqVec<CW>::ld(z, &sR[row * SRS + c0]); SeqVec<CW>::ld(bi, bo + c0); SeqVec<CW>::ld(xr, &sX[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, wl + a.w0.x1 + r0 * d, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb);
+      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, sv1 ? wl + a.w0.x1 + r0 * d : nullptr, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 4);
-    // ---- FFN1: hact = drop(relu(x1 W1^T + b1))
+    // ---- FFN1: hact = drop(relu(x1 W1^T + b1))     (QUAD: this partner's half of the columns, fc0 .. fc0 + F / 2)
+    const int fc0 = QUAD ? cpart * (F >> 1) : 0, fcn = QUAD ? F >> 1 : F;
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_FFN);
       GT_SUBSET(l == 1);                                         // (diagnostic builds: sub-stage stamps of this stage, wave 0)
-      seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT, HALF>(sX1 + rb * SX, SX, d, kf_w1, F, pl + a.p0.b1, wave, lane,
-                                                       [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
-        const int col = n0 + 4 * lg;
+      seq_mm_tiles<NK, GT_SEQ_FMAX / (QUAD ? 256 : 128), EXACT, HALF>(sX1 + rb * SX, SX, d, kf_w1 + (size_t)(fc0 >> 4) * (d >> 4) * 256, fcn,
+                                                                      pl + a.p0.b1 + fc0, wave, lane,
+                                                                      [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
+        const int col = fc0 + n0 + 4 * lg;
 #pragma unroll
         for (int h2 = 0; h2 < NH; ++h2) {
           const int row = rb + 16 * h2 + l16;
@@ -1184,10 +1332,14 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         }
       });
     }
+    const int nkf = F >> 4, kq0 = QUAD ? cpart * (nkf >> 1) : 0;            // QUAD: this partner's k-steps of FFN2, kq0 .. kq0 + nkf / 2
 #ifndef GT_SEQ_NO_PRE
-    const bool pre2 = SPLIT && seq_splitk_pre_ok(F, d);
+    const bool pre2 = QUAD ? ((nkf >> 1) & 7) == 0 : (SPLIT && seq_splitk_pre_ok(F, d));
     SeqB<8> b2pre = SeqB<8>();
-    if (pre2) b2pre = seq_splitk_first(kf_w2, F, d, wave, lane);     // FFN2's first chunk: in flight across the barrier and the tile store
+    if (pre2) {                                                      // FFN2's first chunk: in flight across the barrier and the tile store
+      if (QUAD) seq_b_load<8, true>(b2pre, kf_w2, nkf, wave, kq0, 8, lane);
+      else b2pre = seq_splitk_first(kf_w2, F, d, wave, lane);
+    }
 #else
     const bool pre2 = false;
     const SeqB<8> b2pre = SeqB<8>();
@@ -1196,8 +1348,26 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     GT_SUBSET(false);
     GT_STAMP(sb + 5);
     // ---- FFN2 (K = F: split over the waves) -> partial tiles; the FFN tile goes to global (saved for the backward)
-    seq_tile_out(wl + a.w0.hact + r0 * F, sH, SH, F, tid, rb, NROW);
-    seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kf_w2, d, sR + rb * SRS, SRS, wave, lane, pre2, b2pre);
+    if constexpr (QUAD) {
+      // this partner's K half, one column tile per wave; its partial tile goes to the partner (and to sR part `cpart`), the partner's
+      // arrives as part 1 - cpart: both sum part 0 + part 1, in that order, and continue on identical values
+      seq_tile_out_cols(wl + a.w0.hact + r0 * F, F, sH, SH, fc0, fcn, tid, rb, NROW);
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      seq_mm_krange<true>(acc0, acc1, sH + rb * SH + l16 * SH + 4 * lg, SH, kf_w2, nkf, wave, kq0, kq0 + (nkf >> 1), lane, pre2, b2pre);
+      GT_STAMP(300 + 4 * l);
+      unsigned long long* const xq = reinterpret_cast<unsigned long long*>(ws + a.xchg) + 8;       // (granule 0..7: the region's header)
+      const bool last = l + 1 == a.L;                               // last layer: partner 1 only sends (partner 0 runs the output layer alone)
+      if (!last || cpart == 1) seq_xchg_put(xq + (size_t)vb * GT_XCHG_WG_GRANULES, acc0, tid);
+      if (last && cpart == 1) return true;                          // (workgroup-uniform)
+      *reinterpret_cast<float4*>(&sR[(16 * cpart + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+      GT_STAMP(301 + 4 * l);
+      const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg));
+      GT_STAMP(302 + 4 * l);
+      *reinterpret_cast<float4*>(&sR[(16 * (1 - cpart) + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(oth[0], oth[1], oth[2], oth[3]);
+    } else {
+      seq_tile_out(wl + a.w0.hact + r0 * F, sH, SH, F, tid, rb, NROW);
+      seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kf_w2, d, sR + rb * SRS, SRS, wave, lane, pre2, b2pre);
+    }
     GT_BARRIER();
     GT_STAMP(sb + 6);
     // ---- z2 = drop(sum of the parts + b2) + x1;  norm2 -> the next layer's input
@@ -1207,13 +1377,22 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       const int parts = seq_splitk_parts(d);
       seq_ln_fwd<DP, HALF>([&](int row, int c0, float (&z)[CW]) {
         float bi[CW], xr[CW];
-        seq_parts_sum<CW>(z, sR, SRS, parts, row, c0); SeqVec<CW>::ld(bi, b2 + c0); SeqVec<CW>::ld(xr, &sX1[row * SX + c0]);
+        if constexpr (QUAD) {                                        // sR rows 0..15: partner 0's partial tile of the own rows, 16..31: partner 1's
+          float u[CW];
+          SeqVec<CW>::ld(z, &sR[(row - rb) * SRS + c0]); SeqVec<CW>::ld(u, &sR[(16 + row - rb) * SRS + c0]);
+#pragma unroll
+          for (int e = 0; e < CW; ++e) z[e] += u[e];
+        } else {
+          seq_parts_sum<CW>(z, sR, SRS, parts, row, c0);
+        }
+        SeqVec<CW>::ld(bi, b2 + c0); SeqVec<CW>::ld(xr, &sX1[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, wl + a.w0.xout + r0 * d, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid, rb);
+      }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, sv0 ? wl + a.w0.xout + r0 * d : nullptr, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 7);
+    return false;
   };
   // ---- final encoder norm -> memory, then the output layer: [h logits | sigmoid v | 0.5 tanh o]
   auto output_layer = [&]() {
@@ -1239,6 +1418,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       }
     });
     if (a.loss_y == nullptr) return;
+    const unsigned lwg_n = QUAD ? gridDim.x >> 1 : gridDim.x, lwg_id = QUAD ? (unsigned)half_id : blockIdx.x;   // workgroups that run the output layer
     // ---- fused loss: one thread per (own row, voice); partial sums of this workgroup -> loss_part[blockIdx][4]; the last workgroup
     // to arrive (ticket) adds all partials in a fixed order -> bitwise-reproducible statistics, as in loss_kernel
     GT_BARRIER();
@@ -1261,18 +1441,19 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       for (int q = 0; q < 4; ++q) {
         float t = red[q];
         for (int w = 1; w < GT_SEQ_WAVES; ++w) t += red[w * 4 + q];
-        a.loss_part[blockIdx.x * 4 + q] = t;
+        seq_pub_store(a.loss_part + lwg_id * 4 + q, t);
       }
-      __threadfence();                                        // release: partials before the ticket
-      const unsigned t = atomicAdd(a.loss_ticket, 1u);
-      red[32] = (t == gridDim.x - 1) ? 1.0f : 0.0f;
-      if (t == gridDim.x - 1) __threadfence();                // acquire: the other workgroups' partials
+      // the four partials are write-through (agent-scope) stores, drained before the ticket; the last arriver -- told by the value its
+      // add returns -- reads all partials with agent-scope loads: no __threadfence(), which would write back every dirty line of this
+      // XCD's L2 (the activations just saved: microseconds, in every workgroup) -- MI355X_MICROARCH.md, valid hand-off forms, row 1
+      const unsigned t = seq_pub_ticket(a.loss_ticket);
+      red[32] = (t == lwg_n - 1) ? 1.0f : 0.0f;
     }
     GT_BARRIER();
     if (red[32] == 0.0f) return;
     if (wave < 4) {                                           // wave q sums quantity q: lane l takes workgroups l, l + 64, ..., then the xor tree
       float acc = 0.f;
-      for (unsigned bk = lane; bk < gridDim.x; bk += 64) acc += a.loss_part[bk * 4 + wave];
+      for (unsigned bk = lane; bk < lwg_n; bk += 64) acc += seq_pub_load(a.loss_part + bk * 4 + wave);
       acc = gt_wave_sum(acc);
       if (lane == 0) red[40 + wave] = acc * invM;
     }
@@ -1296,7 +1477,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   if (!SPLIT) {
     GT_STAMP(0);
     input_layer(OwnRows{});
-    for (int l = 0; l < a.L; ++l) { in_proj(l, OwnRows{}); layer_rest(l, true); }
+    for (int l = 0; l < a.L; ++l) { in_proj(l, OwnRows{}); (void)layer_rest(l, true); }
     output_layer();
     GT_STAMP(2 + 10 * a.L);
   } else {
@@ -1304,23 +1485,38 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     // the whole sequence's q / k / v from the workspace], attention .. norm2 of layer l on the own rows, then in-proj(l + 1) of the own
     // rows (saved: the next launch's operands) or the output layer + loss
     const int l = a.phase;
+    if constexpr (QUAD) {
+      // a.quad_pro: a PROLOGUE launch (a.phase < 0) computes the input layer and in-proj(0) once -- own rows, own column half, like every
+      // later in-proj -- instead of all four workgroups of a sequence computing them for all 32 rows inside phase 0
+      if (l < 0) {
+        input_layer(OwnRows{});
+        in_proj(0, OwnRows{});
+        seq_tile_out_cols(ws + a.w0.qkv + r0 * 3 * d, 3 * d, sQ, SQ, cpart * (3 * d / 2), 3 * d / 2, tid, rb, NROW);
+        return;
+      }
+    }
+    const bool pro = QUAD && a.quad_pro != 0;
     GT_STAMP(60 + 2 * (l + 1));
-    if (l == 0) {
+    GT_WGSTAMP(0);
+    if (l == 0 && !pro) {
       input_layer(AllRows{});
       in_proj(0, AllRows{});
     } else {
-      load_rows(sX, SX, ws + (int64_t)(l - 1) * a.wstride + a.w0.xout + r0 * d, d, rb, NROW);                      // own rows of the layer input
+      load_rows(sX, SX, ws + (l == 0 ? a.x0 : (int64_t)(l - 1) * a.wstride + a.w0.xout) + r0 * d, d, rb, NROW);   // own rows of the layer input
       load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                          // q / k / v of the whole sequence
       GT_BARRIER();
     }
     GT_STAMP(2 + 10 * l + 1);
-    layer_rest(l, l == 0);
+    if (layer_rest(l, l == 0 && !pro)) return;
     if (l + 1 < a.L) {
       in_proj(l + 1, OwnRows{});
-      seq_tile_out(ws + (int64_t)(l + 1) * a.wstride + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
+      float* const gq = ws + (int64_t)(l + 1) * a.wstride + a.w0.qkv + r0 * 3 * d;
+      if (QUAD) seq_tile_out_cols(gq, 3 * d, sQ, SQ, cpart * (3 * d / 2), 3 * d / 2, tid, rb, NROW);
+      else seq_tile_out(gq, sQ, SQ, 3 * d, tid, rb, NROW);
     } else {
       output_layer();
     }
+    GT_WGSTAMP(1);
     GT_STAMP(61 + 2 * (l + 1));
   }
 }
@@ -1353,7 +1549,8 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   float* const sQ = sU;
   float* const sH = ALIAS ? sU : sU + G::QKV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
-  const int b = SPLIT ? blockIdx.x >> 1 : blockIdx.x, rb = SPLIT ? 16 * (blockIdx.x & 1) : 0;
+  const int vb = SPLIT ? seq_vblock((int)blockIdx.x, 2, a.B) : (int)blockIdx.x;      // (riders: blocks >= 2 B keep their index)
+  const int b = SPLIT ? vb >> 1 : (int)blockIdx.x, rb = SPLIT ? 16 * (vb & 1) : 0;
   const int d = EXACT ? DP : a.d, F = a.F;
   const size_t r0 = (size_t)b * 32;
   if constexpr (SPLIT && DP == 128) {

@@ -22,6 +22,9 @@ struct SeqArgs {
   int64_t dctx;                                              // SPLIT kernels: two [M][d] hand-over buffers of the backward phases (phase p writes
                                                              // buffer p & 1 and reads the other: a fast workgroup must not overwrite rows its
                                                              // partner has yet to read)
+  int64_t xchg;                                              // QUAD forward: the pair-exchange region (8 header granules, then one 16 KB slot per
+                                                             // workgroup; zero between launches -- gt_workspace_init); -1: none
+  int quad_pro;                                              // QUAD forward: input layer + in-proj(0) ran as a prologue launch (phase -1)
   int phase;                                                 // SPLIT kernels: which phase this launch runs
   // fused loss (gt_train_step): the launch that runs the output layer also computes the loss terms, d loss / d logits and the
   // step's statistics (loss_y == nullptr: off).  Same arithmetic as loss_kernel<true, true> (gt_loss_elem), one partial per workgroup
@@ -44,6 +47,8 @@ void gt_seq_launch_pack(const SeqArgs& a, unsigned nblocks, hipStream_t s);
 // optimizer update (algo 0 sgd / 1 adam, the arithmetic of gt_misc.h's kernels) + the next step's fragment-ordered weights
 void gt_seq_launch_update_pack(const SeqArgs& a, int algo, float* params, float* grads, float* m, float* v, int64_t n, const gt_step_state* st,
                                int step_advanced, hipStream_t s);
-void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s);
+void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s, bool quad = false);
+// floats of the QUAD forward's pair-exchange region for a batch: 8 header granules + 4 x batch slots of 4 x 512 8-byte granules
+static inline int64_t gt_seq_xchg_floats(int batch) { return 16 + (int64_t)4 * batch * 4 * 512 * 2; }
 void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s);
 void gt_seq_launch_tail(const SeqArgs& a, unsigned nblocks, hipStream_t s);

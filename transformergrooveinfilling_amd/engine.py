@@ -44,6 +44,7 @@ class _Slot:
         self.cfg = _lib.make_config(B, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
                                     d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
         self.ws = torch.empty(eng.lib.workspace_floats(self.cfg), **f32)
+        eng.lib.call("gt_workspace_init", ctypes.byref(self.cfg), _ptr(self.ws), eng.stream)   # (zeroes the regions whose protocol relies on it)
         self.x = torch.zeros(B, 32, d["embedding_size_src"], **f32)
         self.y = torch.zeros(B, 32, 27, **f32)
         self.hvo = torch.zeros(B, 32, 27, **f32)
@@ -427,6 +428,7 @@ class StepEngine:
                 cfg = _lib.make_config(m, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
                                        d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
                 ws = torch.empty(self.lib.workspace_floats(cfg), dtype=torch.float32, device=self.device)
+                self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)
                 tgt = torch.empty(m, 32, 27, dtype=torch.float32, device=self.device) if not self.encoder_only else None
                 self._predict_ws[m] = (cfg, ws, tgt)
             cfg, ws, tgt = self._predict_ws[m]
