@@ -1093,11 +1093,15 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
         const int pcut = L - split_.split_layer + 1;                 // last backward phase of the first half (split_.nb == 2)
         const int p_lo = phase == 2 ? pcut + 1 : 0, p_hi = phase == 1 ? pcut : L;
         a.ln_nwg = nwg;
+        static const int quad_bwd0 = [] { const char* e = getenv("GT_SEQ_QUAD_BWD0"); return (e && e[0] == '0') ? 0 : 1; }();
+        const bool quad0 = quad_bwd0 && seq_quad(*cfg);
         for (int p = p_lo; p <= p_hi; ++p) {
           SeqArgs ap = a;
           ap.phase = p;
           if (p > p_lo) gt_prof_tag("seq_bwd", 0.0, 0.0);
-          gt_seq_launch_bwd(ap, d, hc, true, a.nseq + (p == 0 ? 0 : R), x.s);
+          // phase 0 has no riders: four workgroups per sequence there (column partners, gt_seq.h QUAD) while they fit the chip
+          if (p == 0 && quad0) gt_seq_launch_bwd(ap, d, hc, true, 2 * a.nseq, x.s, true);
+          else gt_seq_launch_bwd(ap, d, hc, true, a.nseq + (p == 0 ? 0 : R), x.s);
         }
         if (phase == 1) {      // bucket 0 reaches to the END of the buffer: the output layer's gradient now, by a launch of its own
           a.phase = 0; a.tail_phase = 0; a.tail_ksplit = 2; a.bump = nullptr;

@@ -24,8 +24,10 @@
   if ((dm) <= 32) GT_SEQ_LAUNCH_DP(K, 32, dm, hc, grid, block, s, a)           \
   else if ((dm) <= 64) GT_SEQ_LAUNCH_DP(K, 64, dm, hc, grid, block, s, a)      \
   else GT_SEQ_LAUNCH_DP(K, 128, dm, hc, grid, block, s, a)
-void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s) {
+void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s, bool quad) {
   const dim3 grid(nblocks), block(GT_SEQ_NT);
+  // QUAD: phase 0 with four workgroups per sequence (d_model 128; no attention in that phase, so one head-dim class serves all)
+  if (quad) { gt_launch(seq_bwd_kernel<128, 32, true, true, true>, grid, block, s, a); return; }
   if (split) { GT_SEQ_LAUNCH_SPLIT(seq_bwd_kernel, d_model, hc, grid, block, s, a) }
   else { GT_SEQ_DISPATCH(seq_bwd_kernel, d_model, hc, grid, block, s, a) }
 }

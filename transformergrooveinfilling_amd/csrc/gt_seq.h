@@ -1530,8 +1530,13 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
 // second launch), each keeping its own rows of dq / dk / dv.  phase 0: output-layer dgrad .. out-proj dgrad of layer L-1;
 // phase p: attention backward + in-proj dgrad of layer L-p, then norm2 backward .. out-proj dgrad of layer L-p-1 (or the input
 // layer's backward).
-template <int DP, int HDC, bool EXACT, bool SPLIT>
+// QUAD (round 4): backward phase 0 -- the one phase without riders, so half of the chip idles -- with four workgroups per sequence, as in
+// the forward: the column partners of a row half split the FFN2 dgrad by columns of dhid and the FFN1 dgrad by its contraction (one
+// pair exchange of the [16][128] partial results), split the out-proj dgrad's columns (dctx goes to the hand-over buffer anyway), and
+// compute the output-layer dgrad and the LayerNorm backward passes twice; partner 0 writes what both computed.  Phase 0 only.
+template <int DP, int HDC, bool EXACT, bool SPLIT, bool QUAD = false>
 __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
+  static_assert(!QUAD || (SPLIT && EXACT && DP == 128), "QUAD: the SPLIT kernels of d_model 128");
   using G = SeqGeo<DP>;
   constexpr int SX = G::SX, SH = G::SH, SQ = G::SQ, SRS = G::SRS, CW = G::CW, NK = G::NK;
   constexpr int HD = SeqHd<HDC>::HD;
@@ -1549,11 +1554,13 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   float* const sQ = sU;
   float* const sH = ALIAS ? sU : sU + G::QKV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
-  const int vb = SPLIT ? seq_vblock((int)blockIdx.x, 2, a.B) : (int)blockIdx.x;      // (riders: blocks >= 2 B keep their index)
-  const int b = SPLIT ? vb >> 1 : (int)blockIdx.x, rb = SPLIT ? 16 * (vb & 1) : 0;
+  const int vb = (SPLIT && !QUAD) ? seq_vblock((int)blockIdx.x, 2, a.B) : (int)blockIdx.x;      // (riders: blocks >= 2 B keep their index)
+  const int cpart = QUAD ? (vb & 1) : 0, half_id = QUAD ? (vb >> 1) : vb;               // QUAD: column partner; (sequence, row half)
+  const int b = SPLIT ? half_id >> 1 : (int)blockIdx.x, rb = SPLIT ? 16 * (half_id & 1) : 0;
+  const bool sv0 = !QUAD || cpart == 0;                                                  // this workgroup writes what both partners compute
   const int d = EXACT ? DP : a.d, F = a.F;
   const size_t r0 = (size_t)b * 32;
-  if constexpr (SPLIT && DP == 128) {
+  if constexpr (SPLIT && DP == 128 && !QUAD) {
     // rider workgroups (gt_seq_wg.h): the blocks behind the sequence workgroups compute the weight gradients whose operands the
     // earlier phases left in the workspace -- same kernel, same LDS footprint, hence always on a CU no sequence workgroup occupies
     if (a.grd != nullptr && (int)blockIdx.x >= a.nseq) {
@@ -1569,7 +1576,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   const uint32_t idxd = (uint32_t)(r0 * d);
   const float mscale = dk.thr ? dk.scale : 1.0f;
   const float ascale = 1.0f / sqrtf((float)a.hd);
-  auto part_at = [&](int job) { return ws + a.ln_part + (int64_t)job * a.ln_part_stride + (size_t)blockIdx.x * 2 * d; };
+  auto part_at = [&](int job) { return ws + a.ln_part + (int64_t)job * a.ln_part_stride + (size_t)(QUAD ? half_id : (int)blockIdx.x) * 2 * d; };
   // rows rb_ .. rb_ + nrows - 1 of a [32][ncol] tile of this sequence, global -> LDS, 16 bytes per thread and pass
   auto load_rows = [&](float* dst, const int str, const float* src, const int ncol, const int rb_, const int nrows) {
     const int q4 = ncol >> 2;
@@ -1601,7 +1608,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
                            ws + a.enc_rstd + r0, prm + a.encn_w, nd, 0u, 0u, nullptr, nullptr, sP, tid, rb);
     }
     GT_BARRIER();
-    seq_ln_part<DP, HALF>(sP, part_at(0), d, tid);
+    if (sv0) seq_ln_part<DP, HALF>(sP, part_at(0), d, tid);
     GT_BARRIER();                                                 // (sP is rewritten by the first norm2 backward below)
     GT_STAMP(101);
   };
@@ -1622,8 +1629,10 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     // (norm2 bwd 7.5 k cycles against norm1 bwd's 3.6 k)
     static_assert(16 * GT_SEQ_FMAX / 4 <= 4 * GT_SEQ_NT, "four 16-byte loads per thread cover the 16 x F tile");
     float4 hp0 = make_float4(0.f, 0.f, 0.f, 0.f), hp1 = hp0, hp2 = hp0, hp3 = hp0;     // (named: an indexed array went to scratch)
-    const int hq4 = F >> 2, hn = 16 * hq4;
-    auto hoff = [&](const int u) { const int e = tid + u * GT_SEQ_NT, ec = e < hn ? e : hn - 1; return (unsigned)((rb + ec / hq4) * F + (ec % hq4) * 4); };
+    // (QUAD: this partner's half of the columns, fc0 .. fc0 + F / 2)
+    const int fc0 = QUAD ? cpart * (F >> 1) : 0, fcn = QUAD ? F >> 1 : F;
+    const int hq4 = fcn >> 2, hn = 16 * hq4;
+    auto hoff = [&](const int u) { const int e = tid + u * GT_SEQ_NT, ec = e < hn ? e : hn - 1; return (unsigned)((rb + ec / hq4) * F + fc0 + (ec % hq4) * 4); };
     if (SPLIT) {
       const float* src = wl + a.w0.hact + r0 * F;
       hp0 = *reinterpret_cast<const float4*>(src + hoff(0)); hp1 = *reinterpret_cast<const float4*>(src + hoff(1));
@@ -1642,20 +1651,20 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
 #pragma unroll
           for (int e = 0; e < CW; ++e) g[e] += r[e];
         }
-      }, sDZ, sC, SX, d, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, pl + a.p0.n2w, dk, key, idxd, tl + a.t0.dzA + r0 * d,
-                           dk.thr ? tl + a.t0.dzAm + r0 * d : nullptr, sP, tid, rb);
+      }, sDZ, sC, SX, d, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, pl + a.p0.n2w, dk, key, idxd, sv0 ? tl + a.t0.dzA + r0 * d : nullptr,
+                           (dk.thr && sv0) ? tl + a.t0.dzAm + r0 * d : nullptr, sP, tid, rb);
     }
     if (SPLIT) {
-      auto hst = [&](const int u, const float4& v) { const int e = tid + u * GT_SEQ_NT; if (e < hn) *reinterpret_cast<float4*>(sH + (rb + e / hq4) * SH + (e % hq4) * 4) = v; };
+      auto hst = [&](const int u, const float4& v) { const int e = tid + u * GT_SEQ_NT; if (e < hn) *reinterpret_cast<float4*>(sH + (rb + e / hq4) * SH + fc0 + (e % hq4) * 4) = v; };
       hst(0, hp0); hst(1, hp1); hst(2, hp2); hst(3, hp3);
     }
     GT_BARRIER();
     GT_STAMP(sb);
     // ---- FFN2 dgrad: dhid = (dz2m W2) * [hact != 0] * 1/(1-p), in place over the hact tile in sH
-    seq_ln_part<DP, HALF>(sP, part_at(jb), d, tid);
-    seq_mm_tiles<NK, GT_SEQ_FMAX / 128, EXACT, HALF>(sC + rb * SX, SX, d, kb_w2, F, nullptr, wave, lane,
-                                                     [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
-      const int col = n0 + 4 * lg;
+    if (sv0) seq_ln_part<DP, HALF>(sP, part_at(jb), d, tid);
+    seq_mm_tiles<NK, GT_SEQ_FMAX / (QUAD ? 256 : 128), EXACT, HALF>(sC + rb * SX, SX, d, kb_w2 + (size_t)(fc0 >> 4) * (d >> 4) * 256, fcn, nullptr, wave, lane,
+                                                                    [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
+      const int col = fc0 + n0 + 4 * lg;
 #pragma unroll
       for (int h2 = 0; h2 < (HALF ? 1 : 2); ++h2) {
         float* hp = &sH[(rb + 16 * h2 + l16) * SH + col];
@@ -1665,10 +1674,14 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
                                                      ha.z != 0.f ? c[2] * mscale : 0.f, ha.w != 0.f ? c[3] * mscale : 0.f);
       }
     });
+    const int nkf = F >> 4, kq0 = QUAD ? cpart * (nkf >> 1) : 0;            // QUAD: this partner's k-steps of the FFN1 dgrad
 #ifndef GT_SEQ_NO_PRE
-    const bool pre1 = SPLIT && seq_splitk_pre_ok(F, d);
+    const bool pre1 = QUAD ? ((nkf >> 1) & 7) == 0 : (SPLIT && seq_splitk_pre_ok(F, d));
     SeqB<8> b1pre = SeqB<8>();
-    if (pre1) b1pre = seq_splitk_first(kb_w1, F, d, wave, lane);     // FFN1 dgrad's first chunk: in flight across the barrier and the tile store
+    if (pre1) {                                                      // FFN1 dgrad's first chunk: in flight across the barrier and the tile store
+      if (QUAD) seq_b_load<8, true>(b1pre, kb_w1, nkf, wave, kq0, 8, lane);
+      else b1pre = seq_splitk_first(kb_w1, F, d, wave, lane);
+    }
 #else
     const bool pre1 = false;
     const SeqB<8> b1pre = SeqB<8>();
@@ -1676,8 +1689,21 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     GT_BARRIER();
     GT_STAMP(sb + 1);
     // ---- FFN1 dgrad (K = F: split over the waves) -> partial tiles; dhid goes to global (operand of both FFN weight gradients)
-    seq_tile_out(tl + a.t0.dhid + r0 * F, sH, SH, F, tid, rb, NROW);
-    seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kb_w1, d, sR + rb * SRS, SRS, wave, lane, pre1, b1pre);
+    if constexpr (QUAD) {
+      // the own half of the contraction, one column tile per wave; the partial tiles are swapped with the partner (seq_xchg_*), both sum
+      // part 0 + part 1 in that order (sR rows 0..15: partner 0's tile of the own rows, 16..31: partner 1's)
+      seq_tile_out_cols(tl + a.t0.dhid + r0 * F, F, sH, SH, fc0, fcn, tid, rb, NROW);
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      seq_mm_krange<true>(acc0, acc1, sH + rb * SH + l16 * SH + 4 * lg, SH, kb_w1, nkf, wave, kq0, kq0 + (nkf >> 1), lane, pre1, b1pre);
+      unsigned long long* const xq = reinterpret_cast<unsigned long long*>(ws + a.xchg) + 8;
+      seq_xchg_put(xq + (size_t)vb * GT_XCHG_WG_GRANULES, acc0, tid);
+      *reinterpret_cast<float4*>(&sR[(16 * cpart + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+      const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg));
+      *reinterpret_cast<float4*>(&sR[(16 * (1 - cpart) + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(oth[0], oth[1], oth[2], oth[3]);
+    } else {
+      seq_tile_out(tl + a.t0.dhid + r0 * F, sH, SH, F, tid, rb, NROW);
+      seq_mm_splitk<HALF>(sH + rb * SH, SH, F, kb_w1, d, sR + rb * SRS, SRS, wave, lane, pre1, b1pre);
+    }
     GT_BARRIER();
     GT_STAMP(sb + 2);
     // ---- norm1 backward: g1 = parts + dz2 -> dz1 -> sDZ, dz1 * mask(dropout1) -> sC.  Whole: the saved qkv tile of this layer is
@@ -1688,17 +1714,30 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
       const int parts = seq_splitk_parts(d);
       seq_ln_bwd<DP, HALF>([&](int row, int c0, float (&g)[CW]) {
         float r[CW];
-        seq_parts_sum<CW>(g, sR, SRS, parts, row, c0); SeqVec<CW>::ld(r, &sDZ[row * SX + c0]);
+        if constexpr (QUAD) {
+          float u[CW];
+          SeqVec<CW>::ld(g, &sR[(row - rb) * SRS + c0]); SeqVec<CW>::ld(u, &sR[(16 + row - rb) * SRS + c0]);
+#pragma unroll
+          for (int e = 0; e < CW; ++e) g[e] += u[e];
+        } else {
+          seq_parts_sum<CW>(g, sR, SRS, parts, row, c0);
+        }
+        SeqVec<CW>::ld(r, &sDZ[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) g[e] += r[e];
-      }, sDZ, sC, SX, d, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, pl + a.p0.n1w, dk, key, idxd, tl + a.t0.dzB + r0 * d,
-                           dk.thr ? tl + a.t0.dzBm + r0 * d : nullptr, sP, tid, rb);
+      }, sDZ, sC, SX, d, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, pl + a.p0.n1w, dk, key, idxd, sv0 ? tl + a.t0.dzB + r0 * d : nullptr,
+                           (dk.thr && sv0) ? tl + a.t0.dzBm + r0 * d : nullptr, sP, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 3);
     // ---- out-proj dgrad: dctx = dz1m Wo -> sZ (LDS: the attention backward reads it there)
-    seq_ln_part<DP, HALF>(sP, part_at(jb + 1), d, tid);
+    if (sv0) seq_ln_part<DP, HALF>(sP, part_at(jb + 1), d, tid);
     if (DP <= 64 && !SPLIT) seq_mm_square(sC, SX, d, kb_out, sZ, SX, wave, lane);
+    else if constexpr (QUAD)        // this partner's half of the dctx columns (d / 32 tiles, one per wave): they leave for the hand-over buffer
+      seq_mm_tiles<NK, 1, EXACT, true>(sC + rb * SX, SX, d, kb_out + (size_t)cpart * (d >> 5) * NK * 256, d >> 1, nullptr, wave, lane,
+                                       [&](int n0, const f32x4& c0, const f32x4&, const float4&) {
+        *reinterpret_cast<float4*>(&sZ[(rb + l16) * SX + cpart * (d >> 1) + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+      });
     else
       seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kb_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
         *reinterpret_cast<float4*>(&sZ[(rb + l16) * SX + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
@@ -1782,7 +1821,13 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   GT_SUBSET(false);
   GT_BARRIER();
 #endif
-  if (!SPLIT) {
+  if constexpr (QUAD) {
+    GT_STAMP(160);
+    prologue();
+    chain(a.L - 1, true);
+    seq_tile_out_cols(ws + a.dctx + r0 * d, d, sZ, SX, cpart * (d >> 1), d >> 1, tid, rb, NROW);
+    GT_STAMP(161);
+  } else if (!SPLIT) {
     GT_STAMP(100);
     prologue();
     for (int l = a.L - 1; l >= 0; --l) { chain(l, l == a.L - 1); attn_inproj(l); }

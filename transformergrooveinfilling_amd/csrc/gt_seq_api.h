@@ -50,5 +50,5 @@ void gt_seq_launch_update_pack(const SeqArgs& a, int algo, float* params, float*
 void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s, bool quad = false);
 // floats of the QUAD forward's pair-exchange region for a batch: 8 header granules + 4 x batch slots of 4 x 512 8-byte granules
 static inline int64_t gt_seq_xchg_floats(int batch) { return 16 + (int64_t)4 * batch * 4 * 512 * 2; }
-void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s);
+void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s, bool quad = false);
 void gt_seq_launch_tail(const SeqArgs& a, unsigned nblocks, hipStream_t s);
