@@ -132,6 +132,34 @@ __device__ static inline float gt_wave_sum(float v) {
 }
 __device__ static inline float gt_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Partial results of many workgroups meeting in the LAST ARRIVER of a launch, without fences: the partials are write-through
+// (agent-scope) stores, drained before one lane takes a ticket (agent-scope returning add); the workgroup whose add came last reads
+// them with agent-scope loads, behind a workgroup barrier its ticket lane joins.  (MI355X_MICROARCH.md, valid hand-off forms, row 1.
+// A __threadfence() pair instead writes back every dirty line of the XCD's L2 -- the activations just saved -- in every workgroup:
+// 3.8 us of the headline's last forward phase.)
+__device__ __forceinline__ void gt_pub_store(float* p, const float v) {
+#ifdef GT_EMU
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ float gt_pub_load(const float* p) {
+#ifdef GT_EMU
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ unsigned gt_pub_ticket(unsigned* counter) {       // (after this lane's seq_pub_store calls)
+#ifdef GT_EMU
+  return atomicAdd(counter, 1u);
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // scheduling hints (no-ops in the host emulator): GT_SGB = sched_group_barrier, GT_SCHED_FENCE = sched_barrier(0)
 #ifdef GT_EMU
 #define GT_SGB(mask, n)

@@ -428,11 +428,9 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ hvo
   }
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) partials[blockIdx.x * 4 + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
-    __threadfence();                                        // release: partials before the ticket
-    const unsigned t = atomicAdd(ticket, 1u);
+    for (int q = 0; q < 4; ++q) gt_pub_store(partials + blockIdx.x * 4 + q, red[0][q] + red[1][q] + red[2][q] + red[3][q]);
+    const unsigned t = gt_pub_ticket(ticket);               // (write-through partials, drained; no fences: gt_common.h)
     is_last = (t == gridDim.x - 1) ? 1 : 0;
-    if (is_last) __threadfence();                           // acquire: the other workgroups' partials
   }
   __syncthreads();
   if (!is_last) return;
@@ -441,7 +439,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ hvo
   {
     const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
     float acc = 0.f;
-    for (unsigned bk = l; bk < gridDim.x; bk += 64) acc += partials[bk * 4 + q];
+    for (unsigned bk = l; bk < gridDim.x; bk += 64) acc += gt_pub_load(partials + bk * 4 + q);
     acc = gt_wave_sum(acc);
     if (l == 0) red[0][q] = acc * invM;
   }

@@ -121,29 +121,6 @@ __device__ __forceinline__ uint32_t gt_f2u(float f) { return __builtin_bit_cast(
 __device__ __forceinline__ float gt_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 #define GT_XTAG_NOW GT_XTAG
 #endif
-// one value / one arrival counter shared between workgroups of a launch without fences: write-through store, drained; returning add
-__device__ __forceinline__ void seq_pub_store(float* p, const float v) {
-#ifdef GT_EMU
-  *p = v;
-#else
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ float seq_pub_load(const float* p) {
-#ifdef GT_EMU
-  return *p;
-#else
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ unsigned seq_pub_ticket(unsigned* counter) {       // (after this lane's seq_pub_store calls)
-#ifdef GT_EMU
-  return atomicAdd(counter, 1u);
-#else
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
 __device__ __forceinline__ void seq_xchg_put(unsigned long long* slot, const f32x4& v, const int tid) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1150,7 +1127,8 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
   // (sequence, part) of this block.  Measured at the headline shape: the map takes the SPLIT backward phases from 103.7 to 101.5 us per step;
   // the QUAD forward LOSES 3 us with its four workgroups on one XCD (78.1 -> 81.1 us: they read the same lines of one L2 at the same
-  // moments, and a write-through granule leaves the L2 it was written through), so QUAD keeps the plain order
+  // moments, and a write-through granule leaves the L2 it was written through; only the two ROW halves of a (sequence, partner) on one
+  // XCD, partners on neighbouring ones: 0.2026 -> 0.2035 ms), so QUAD keeps the plain order
   const int vb = (SPLIT && !QUAD) ? seq_vblock((int)blockIdx.x, 2, a.B) : (int)blockIdx.x;
   const int cpart = QUAD ? (vb & 1) : 0;                     // QUAD: column partner
   const int half_id = QUAD ? (vb >> 1) : vb;                 // SPLIT: (sequence, row half)
@@ -1441,19 +1419,19 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       for (int q = 0; q < 4; ++q) {
         float t = red[q];
         for (int w = 1; w < GT_SEQ_WAVES; ++w) t += red[w * 4 + q];
-        seq_pub_store(a.loss_part + lwg_id * 4 + q, t);
+        gt_pub_store(a.loss_part + lwg_id * 4 + q, t);
       }
       // the four partials are write-through (agent-scope) stores, drained before the ticket; the last arriver -- told by the value its
       // add returns -- reads all partials with agent-scope loads: no __threadfence(), which would write back every dirty line of this
       // XCD's L2 (the activations just saved: microseconds, in every workgroup) -- MI355X_MICROARCH.md, valid hand-off forms, row 1
-      const unsigned t = seq_pub_ticket(a.loss_ticket);
+      const unsigned t = gt_pub_ticket(a.loss_ticket);
       red[32] = (t == lwg_n - 1) ? 1.0f : 0.0f;
     }
     GT_BARRIER();
     if (red[32] == 0.0f) return;
     if (wave < 4) {                                           // wave q sums quantity q: lane l takes workgroups l, l + 64, ..., then the xor tree
       float acc = 0.f;
-      for (unsigned bk = lane; bk < lwg_n; bk += 64) acc += seq_pub_load(a.loss_part + bk * 4 + wave);
+      for (unsigned bk = lane; bk < lwg_n; bk += 64) acc += gt_pub_load(a.loss_part + bk * 4 + wave);
       acc = gt_wave_sum(acc);
       if (lane == 0) red[40 + wave] = acc * invM;
     }
@@ -1503,7 +1481,19 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       in_proj(0, AllRows{});
     } else {
       load_rows(sX, SX, ws + (l == 0 ? a.x0 : (int64_t)(l - 1) * a.wstride + a.w0.xout) + r0 * d, d, rb, NROW);   // own rows of the layer input
-      load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                          // q / k / v of the whole sequence
+      // k / v of the whole sequence, q of the own rows (the other half's queries are its own business: a sixth of the bytes less)
+      {
+        const float* gq = ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d;
+        const int q4k = (2 * d) >> 2, q4q = d >> 2;
+        for (int e = tid; e < 32 * q4k; e += GT_SEQ_NT) {
+          const int r = e / q4k, c = d + (e % q4k) * 4;
+          *reinterpret_cast<float4*>(sQ + r * SQ + c) = *reinterpret_cast<const float4*>(gq + (unsigned)(r * 3 * d + c));
+        }
+        for (int e = tid; e < NROW * q4q; e += GT_SEQ_NT) {
+          const int r = rb + e / q4q, c = (e % q4q) * 4;
+          *reinterpret_cast<float4*>(sQ + r * SQ + c) = *reinterpret_cast<const float4*>(gq + (unsigned)(r * 3 * d + c));
+        }
+      }
       GT_BARRIER();
     }
     GT_STAMP(2 + 10 * l + 1);
