@@ -253,6 +253,20 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
         _close(G[pre + prev_norm + ".bias"], db, "grad " + pre + prev_norm + ".bias", tol=1e-4)
         n += 4
 
+    if Ld:
+        # encoder half of the encoder-decoder backward: the memory gradient = the sum of the decoder layers' cross-attention k / v
+        # dgrads; through the final encoder norm and the top layer's closing norm it becomes that layer's dz (one fused row pass on the device)
+        dmem = np.zeros((M, d))
+        for l in range(Ld):
+            dkvx = f64(r.ws_get("dqkvx", L + l))[M * d:].reshape(M, 2 * d)
+            dmem += rb(dkvx) @ rb(P["Decoder.Decoder.layers.%d.multihead_attn.in_proj_weight" % l][d:])
+        _close(ws("dmem"), dmem, "memory gradient (sum of the cross-attention k / v dgrads)", tol=1e-4)
+        g_top, dg, db = ln_bwd(ws("dmem"), ws("enc_xhat"), ws("enc_rstd", 0, 1), P["Encoder.Encoder.norm.weight"])
+        _close(G["Encoder.Encoder.norm.weight"], dg, "grad Encoder.Encoder.norm.weight", tol=1e-4)
+        _close(G["Encoder.Encoder.norm.bias"], db, "grad Encoder.Encoder.norm.bias", tol=1e-4)
+        want, _, _ = ln_bwd(g_top, ws("xhat2", L - 1), ws("rstd2", L - 1, 1), P["Encoder.Encoder.layers.%d.norm2.weight" % (L - 1)])
+        _close(tmp("dzA", L - 1, d), want, "final encoder norm + top layer's norm2 backward", tol=1e-4)
+        n += 4
     for l in reversed(range(L)):
         pre = "Encoder.Encoder.layers.%d." % l
         ffn_bwd(pre, l, ws("x1", l), "dzA", "xhat1", "rstd1", "norm1", "dzB")
@@ -262,8 +276,6 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
         wgrad(dz1m, ws("ctx", l), pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias")
         dqkv = tmp("dqkv", l, 3 * d)
         wgrad(dqkv, enc_in[l], pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias")
-        if Ld:
-            continue            # encoder-decoder: the encoder's incoming gradient also carries the memory path; covered by the fp32 tests
         dx = rb(dqkv) @ rb(P[pre + "self_attn.in_proj_weight"]) + dz1
         if l > 0:
             pp = "Encoder.Encoder.layers.%d." % (l - 1)
@@ -368,6 +380,21 @@ def check_optimizers(backend, cfg, B):
             assert np.abs(got[k] - cur[k]).max() < 2e-6, (t, k)
 
 
+def expected_packs(Pd, cfg):
+    """Fragment-ordered weight copies of the sequence-resident kernels (csrc/gt_seq.h, seq_pack_kernel) from a name -> array dict:
+    per layer [in_w | out_w | w1 | w2]; pack[((t * nkt + u) * 64 + lane) * 4 + j] = B(16 u + 4 lg + j, 16 t + l16), lane = l16 + 16 lg;
+    forward copy: B(k, n) = W[n][k], dgrad copy: B(k, n) = W[k][n]."""
+    pf, pb = [], []
+    for l in range(cfg["num_encoder_layers"]):
+        pre = "Encoder.Encoder.layers.%d." % l
+        for name in ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"):
+            W = np.asarray(Pd[pre + name], np.float32)
+            R, C = W.shape
+            pf.append(W.reshape(R // 16, 16, C // 16, 4, 4).transpose(0, 2, 3, 1, 4).reshape(-1))      # (t, l16, u, lg, j) -> (t, u, lg, l16, j)
+            pb.append(W.reshape(R // 16, 4, 4, C // 16, 16).transpose(3, 0, 1, 4, 2).reshape(-1))      # (u, lg, j, t, l16) -> (t, u, lg, l16, j)
+    return np.concatenate(pf), np.concatenate(pb)
+
+
 def check_train_step(backend, cfg, B, p, algo=0, seq=True):
     """gt_train_step == forward+loss+backward+update with the oracle's masks; second step uses step+1."""
     cfg = dict(cfg, dropout=p)
@@ -397,6 +424,18 @@ def check_train_step(backend, cfg, B, p, algo=0, seq=True):
             # (adam: an element whose gradient is numerically zero moves by lr * g / (|g| + eps) -- its sign is noise; skip those)
             live = np.abs(G[k]) > 1e-6 if algo == 1 else np.ones(G[k].shape, bool)
             assert np.abs(got[k] - cur[k])[live].max(initial=0) < (1e-3 if algo == 1 else 2e-5) * max(1.0, np.abs(cur[k]).max()), (step, k)
+            if algo == 1:
+                # Adam divides by sqrt(v): an element's error is the gradient's error (bar 2e-4 of the tensor's largest entry) over |g|.
+                # Where the gradient is well conditioned -- within a factor 10 of the largest -- the update keeps a tight bar
+                strong = np.abs(G[k]) > 0.1 * np.abs(G[k]).max()
+                assert np.abs(got[k] - cur[k])[strong].max(initial=0) < 1e-4 * max(1.0, np.abs(cur[k]).max()), (step, k, "well-conditioned elements")
+        if folded and cfg["d_model"] % 16 == 0:
+            # the folded update + pack kernel wrote the NEXT step's fragment-ordered weights: bitwise what packing the updated parameters gives
+            ef, eb = expected_packs(got, cfg)
+            for name, want in (("pack_f", ef), ("pack_b", eb)):
+                o, c = r.lib.ws_find(r.c, name)
+                assert c == want.size, (name, c, want.size)
+                assert np.array_equal(r.ws.numpy()[o:o + c].view(np.uint32), want.view(np.uint32)), (step, name)
     assert r.step_state().step == (3 if folded else 2)
 
 

@@ -121,6 +121,39 @@ def test_train_loop_fast_path_checkpoint_and_resume(tmp_path):
     assert torch.equal(torch.cat([h, v, o], -1), model2.predict_hvo(x[:10]))
 
 
+def test_train_loop_exposes_gradients_every_watch_log_freq_batches():
+    """ref:train.py:150 wandb.watch(model, log_freq=1000): the fused step consumes its gradients inside its last launch, so every
+    model.watch_log_freq batches train_loop runs the step split (backward | gradients visible | update) and logs them under wandb.watch's
+    names -- same parameters afterwards as the all-fused epoch, bit for bit (one owner per gradient tile on both paths)."""
+    from BaseGrooveTransformers import calculate_loss, initialize_model, train_loop
+    from torch.utils.data import DataLoader, TensorDataset
+    import train as train_cli
+    x, y = train_cli.synthetic_tensors(128, 16, 0)
+
+    class Triples(TensorDataset):
+        def __getitem__(self, i):
+            return self.tensors[0][i], self.tensors[1][i], i
+
+    bce, mse = torch.nn.BCEWithLogitsLoss(reduction="none"), torch.nn.MSELoss(reduction="none")
+    finals = []
+    for freq in (0, 3):
+        torch.manual_seed(5)                                                         # (the weights are drawn from torch's generator)
+        model, opt, _ = initialize_model(_params(d=128, H=4, F=64, L=2, dropout=0.1, lr=0.05, pen=0.38))
+        model.watch_log_freq = freq
+        dl = DataLoader(Triples(x, y), batch_size=16, shuffle=False)
+        train_loop(dataloader=dl, groove_transformer=model, encoder_only=1, opt=opt, epoch=0, loss_fn=calculate_loss, bce_fn=bce, mse_fn=mse,
+                   device="cuda", hit_loss_penalty=0.38, log_every=4)
+        torch.cuda.synchronize()
+        finals.append(model.engine.params.clone())
+        if freq:
+            rec = model.last_watch                                                   # batches 3 and 6 of 8 took the split step
+            assert set(rec) == {"gradients/" + n for n, _ in model.named_parameters()}
+            g = rec["gradients/Encoder.Encoder.layers.0.linear1.weight"]
+            assert g.shape == (64, 128) and np.isfinite(g).all() and np.abs(g).max() > 0
+            assert model.engine.state_struct().step == 8
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_adam_paths_agree_with_oracle():
     from BaseGrooveTransformers import calculate_loss, initialize_model
     p = _params(algo="adam", lr=1e-3)

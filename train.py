@@ -69,6 +69,7 @@ def build_parser():
     p.add_argument("--host-loader", action="store_true",
                    help="feed batches through torch's DataLoader from host memory (the reference's way) instead of keeping the "
                         "dataset in HBM and gathering batches on the device")
+    p.add_argument("--watch-log-freq", type=int, default=1000, help="gradient histograms to wandb every N batches (ref:train.py:150 wandb.watch log_freq; 0 = off)")
     p.add_argument("--save-dir", default=None, help="where checkpoints go (default: wandb run dir or ./checkpoints)")
     p.add_argument("--override", action="append", default=[], metavar="KEY=VALUE", help="override a YAML key (bench shapes)")
     p.add_argument("--seed", default=0, type=int)
@@ -198,6 +199,9 @@ def main(argv=None):
     params["seed"] = args.seed                # dropout stream of this run (the data-parallel rank is mixed in by the model)
     model, optimizer, initial_epoch = initialize_model(params)
     model.eval_log = []                       # the evaluation leg's records (also what the tests read)
+    # ref:train.py:150 wandb.watch(model, log_freq=1000): on the fused path the gradients never pass through autograd, so the hooks
+    # wandb installs would never fire -- train_loop logs the same "gradients/<name>" histograms itself every watch_log_freq batches
+    model.watch_log_freq = args.watch_log_freq if wb is not None else 0
     if args.deterministic:
         model.engine.lib.cdll.gt_set_deterministic(1)
     parallel.broadcast_parameters(model.engine.params)

@@ -285,6 +285,8 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   else if (n == "dec_final") set(W.dec_final, M * d); else if (n == "dlogits") set(W.dlogits, M * GT_TGT);
   else if (n == "dmem") set(W.dmem, M * d); else if (n == "dctx") set(W.dctx, M * d);
   else if (n == "seq_xchg") set(W.seq_xchg, W.seq_xchg_n);
+  else if (n == "pack_f" && W.pack_f >= 0) set(W.pack_f, W.pack_stride * c.n_enc_layers);
+  else if (n == "pack_b" && W.pack_b >= 0) set(W.pack_b, W.pack_stride * c.n_enc_layers);
 #ifdef GT_SEQ_STAMPS
   else if (n == "stamps") set(W.stamps, 2048 + 2 * 4 * 512);
 #endif

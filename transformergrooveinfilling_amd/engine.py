@@ -120,6 +120,9 @@ class StepEngine:
         env = os.environ.get("GT_DP_OVERLAP")
         self.overlap_allreduce = (env == "1") if env in ("0", "1") else (4 * self.total >= OVERLAP_MIN_BYTES)
         self.reduce_stats = True       # data-parallel: the logged 8-float stats are averaged over ranks (one tiny all-reduce)
+        # GT_DP_GRAPH=1: the whole data-parallel step (collectives included) as ONE captured hipGraph per step (measured with
+        # bench.py --force-dp; off by default: it could not be exercised with more than one rank on the 1-GPU boxes of the build)
+        self.dp_graph = os.environ.get("GT_DP_GRAPH", "0") == "1"
         self._slots = {}
         # Fused whole steps on the sequence-resident path end with an update that also writes the next step's fragment-ordered
         # weights into the slot's workspace (GT_STEP_PACKS_CURRENT): valid while nothing else has written the parameters --
@@ -254,10 +257,11 @@ class StepEngine:
             return s.use_graph
         return bool(self.use_graph)
 
-    def _replay(self, s, key, fn, aux=False):
+    def _replay(self, s, key, fn, aux=False, force=False):
         """Replay the hipGraph captured for `key` on slot s (captured on first use).  aux=True: a graph that continues a
-        step another graph began (second half of a bucketed backward) -- it keeps the slot's other graphs."""
-        if not self.graph_for(s):
+        step another graph began (second half of a bucketed backward) -- it keeps the slot's other graphs.  force=True: a graph
+        whatever graph_for says (the one-enqueue data-parallel step)."""
+        if not (force or self.graph_for(s)):
             fn()
             return
         if key not in s.graphs:
@@ -284,9 +288,19 @@ class StepEngine:
         s.graphs[key] = g                         # (most recently used last)
         g.replay()
 
-    def train_step(self, x=None, y=None, B=None):
+    def _watched_step(self, s, on_grads):
+        """One step with the gradients VISIBLE between backward and update: forward + loss + backward (skip_update = 1), on_grads() --
+        the caller reads self.grads / the Parameters' .grad views --, then the fused update.  The fused whole step consumes and
+        re-zeroes the gradients inside its last launch, so nothing (wandb.watch's hooks included, ref:train.py:150) ever sees them;
+        train_loop takes this path every `watch_log_freq` batches instead."""
+        self._enqueue_step(s, 1)
+        on_grads()
+        self.enqueue_update(slot=s)
+
+    def train_step(self, x=None, y=None, B=None, on_grads=None):
         """One optimisation step on (x, y) (device or host tensors; None = reuse the static buffers).
-        Returns the device stats tensor [loss, hit_acc, -, bce, mse_v, mse_o, -, -] without syncing."""
+        Returns the device stats tensor [loss, hit_acc, -, bce, mse_v, mse_o, -, -] without syncing.
+        on_grads: called between backward and update of THIS step (single process; see _watched_step)."""
         s = self.slot(x.shape[0] if x is not None else (B or self.B))
         self._train_B = s.B
         s.fwd_id += 1
@@ -294,13 +308,33 @@ class StepEngine:
             s.x.copy_(x, non_blocking=True)
         if y is not None:
             s.y.copy_(y, non_blocking=True)
-        if self.world_size == 1 and not self.force_dp:
+        if self.world_size == 1 and not self.force_dp and on_grads is not None:
+            self._watched_step(s, on_grads)
+        elif self.world_size == 1 and not self.force_dp:
             if self.graph_for(s):
                 self._note_fused_step(s)          # (a replay updates the parameters without running _enqueue_step)
             self._replay(s, ("fused", self.algo, self.penalty), lambda: self._enqueue_step(s, 0))
         else:
             import torch.distributed as dist
             buckets = self.lib.grad_buckets(s.cfg) if self.overlap_allreduce else []
+            if self.dp_graph and on_grads is None and not self.on_host:
+                # ONE enqueue per step: forward + backward, the all-reduce(s) and the update captured in one hipGraph -- the collectives are
+                # nodes of the graph (RCCL enqueues on its own stream: fork / join edges), nothing returns to Python between the halves
+                def whole():
+                    if len(buckets) == 2:
+                        (o0, c0), (o1, c1) = buckets
+                        self._enqueue_step(s, 2)
+                        w0 = dist.all_reduce(self.grads[o0:o0 + c0], async_op=True)
+                        self._enqueue_step(s, 3)
+                        w1 = dist.all_reduce(self.grads[o1:o1 + c1], async_op=True)
+                        w0.wait(); w1.wait()
+                    else:
+                        self._enqueue_step(s, 1)
+                        dist.all_reduce(self.grads)
+                    self.enqueue_update(slot=s)
+                self._note_fused_step(s)
+                self._replay(s, ("dp_whole", self.algo, self.penalty, len(buckets)), whole, force=True)
+                return s.stats
             if len(buckets) == 2:
                 # bucketed overlap: graph A ends as soon as the upper bucket's gradients are final; its
                 # all-reduce (RCCL stream) runs under graph B, the rest of backward.  The collectives stay OUTSIDE the
@@ -316,10 +350,12 @@ class StepEngine:
             else:
                 self._replay(s, ("fwdbwd", self.algo, self.penalty), lambda: self._enqueue_step(s, 1))
                 dist.all_reduce(self.grads)                  # RCCL sum over xGMI; averaged by grad_scale
+            if on_grads is not None:
+                on_grads()                        # (data-parallel: the all-reduced sums; the update averages them by grad_scale)
             self.enqueue_update(slot=s)
         return s.stats
 
-    def train_step_indexed(self, xs, ys, idx):
+    def train_step_indexed(self, xs, ys, idx, on_grads=None):
         """One optimisation step on rows `idx` (device int64, len B) of a dataset resident in HBM (xs (N,32,S), ys (N,32,27)):
         the gather into the static step inputs is the first launch of the step's hipGraph (gt_gather_batch), nothing is
         copied on the host side but the B indices into their static buffer.  Data-parallel: as train_step."""
@@ -333,6 +369,9 @@ class StepEngine:
             self.lib.call("gt_gather_batch", _ptr(xs), _ptr(ys), _ptr(s.idx), ctypes.c_int64(xs.shape[0]), int(s.B),
                           int(self.dims["embedding_size_src"]), _ptr(s.x), _ptr(s.y), self.stream)
 
+        if on_grads is not None:
+            gather()
+            return self.train_step(B=s.B, on_grads=on_grads)
         if self.world_size == 1 and not self.force_dp:
             gkey = ("fused_idx", self.algo, self.penalty) + key
             if self.graph_for(s):

@@ -290,10 +290,27 @@ def train_loop(dataloader, groove_transformer, encoder_only, opt, epoch, loss_fn
     indexed = fast and hasattr(dataloader, "index_batches") and getattr(dataloader, "x", None) is not None \
         and dataloader.x.device == eng.device
     batches = ((None, None, i) for i in dataloader.index_batches()) if indexed else dataloader
+    # wandb.watch(model, log_freq=1000) (ref:train.py:150) hooks the Parameters' gradients; the fused step never materialises a .grad
+    # autograd could hook (it consumes and re-zeroes the flat gradient buffer inside its last launch).  Equivalent: every
+    # model.watch_log_freq batches (0 = never) the step runs split -- backward, gradients visible, update -- and their histograms
+    # are logged under the names wandb.watch uses ("gradients/<parameter>").
+    watch = int(getattr(model, "watch_log_freq", 0) or 0) if fast else 0
+
+    def watch_cb():
+        rec = {}
+        for n, g in eng.views(eng.grads).items():
+            a = g.detach().float().cpu().numpy()
+            rec["gradients/" + n] = wandb.Histogram(a) if (_wandb_active() and hasattr(wandb, "Histogram")) else a
+        model.last_watch = rec
+        if _wandb_active():
+            wandb.log(rec, commit=False)
+
     for batch, (X, y, _idx) in enumerate(batches):
         n_batches += 1
+        model._watch_step = getattr(model, "_watch_step", 0) + 1
+        on_grads = watch_cb if (watch and model._watch_step % watch == 0) else None
         if indexed:
-            stats = eng.train_step_indexed(dataloader.x, dataloader.y, _idx)
+            stats = eng.train_step_indexed(dataloader.x, dataloader.y, _idx, on_grads=on_grads)
             X = _idx                           # (only its length is used below)
             if (batch + 1) % log_every == 0:
                 last = _metrics_dict("train/", eng.mean_stats(eng.slot(X.shape[0])).tolist())
@@ -307,7 +324,7 @@ def train_loop(dataloader, groove_transformer, encoder_only, opt, epoch, loss_fn
         X = X.to(device, torch.float32, non_blocking=True)
         y = y.to(device, torch.float32, non_blocking=True)
         if fast:
-            stats = eng.train_step(X, y)
+            stats = eng.train_step(X, y, on_grads=on_grads)
             if (batch + 1) % log_every == 0:
                 last = _metrics_dict("train/", eng.mean_stats(eng.slot(X.shape[0])).tolist())
         else:
