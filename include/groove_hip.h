@@ -220,6 +220,13 @@ int gt_set_seq_split(int on);
  * condition (env GT_SEQ_QUAD=0/1).  Results agree with the SPLIT mode to fp32 rounding (the FFN2 contraction is summed as two halves);
  * bitwise repeatable run to run.  Needs gt_workspace_init on the workspace. */
 int gt_set_seq_quad(int on);
+/* gt_config.precision = 1 (BASELINE configs[4]) at d_model 256 / 512 with every Linear of a layer on the big-tile kernel: bf16 SHADOWS of
+ * the GEMM operands -- the producers of every activation / gradient a Linear, dgrad or weight gradient consumes also write a bf16 copy
+ * (8 per layer), a per-step kernel writes bf16 copies of the encoder layers' weights and of their transposes, and the GEMMs stage those
+ * (csrc/gt_gemm32.h gemm32h_kernel: half the bytes per flop; the weight gradients widen them back on their way into LDS).  Results are
+ * bit-identical to the fp32-source path.  1 = on, 0 = off (default: measured neutral, see csrc/groove_hip.hip bf16_shadows), -1 = by the
+ * environment (GT_BF16_SHADOWS=1).  Changes gt_workspace_bytes: set it before sizing a workspace. */
+int gt_set_bf16_shadows(int on);
 /* Weight gradients as RIDER workgroups (csrc/gt_seq_wg.h): in the SPLIT mode at d_model 128 the backward phases' launches carry, on
  * the CUs their 2 x batch sequence workgroups leave idle, the weight gradients whose operands the earlier phases completed; one
  * workgroup owns a 32 x 64 gradient tile over ALL tokens (no atomics: bitwise reproducible), and a tail launch does what cannot ride

@@ -10,6 +10,7 @@ import ctypes
 
 import numpy as np
 
+import harness
 from harness import Runner
 from oracle import numpy_groove as ng
 
@@ -299,6 +300,59 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
         wgrad(tmp("dzCm", gl, d), ws("ctx", gl), pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias")
         wgrad(tmp("dqkv", gl, 3 * d), dec_in[l], pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias")
         n += 3
+    return n
+
+
+def check_bf16_shadows(backend, cfg, B, p):
+    """precision = 1 where the Linears run on the big-tile kernel (csrc/groove_hip.hip bf16_shadows): the producers of every GEMM operand
+    also write a bf16 copy and the GEMMs stage those (gemm32h_kernel) -- each shadow must be, bit for bit, the RNE rounding of the fp32
+    tensor beside it (the value the fp32-source kernel rounds at fragment assembly), for activations, gradients and both weight copies.
+    With that the shadow path's results are those of the fp32-source path; check_step_bf16 on the same shape compares them with the oracle."""
+    cfg = dict(cfg, dropout=p, precision=1)
+    P = ng.init_params(cfg, seed=3, perturb=0.05)
+    x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=5)
+    lib = harness.emu_lib() if backend == "emu" else harness._lib.get_lib()
+    lib.cdll.gt_set_bf16_shadows(1)               # (off by default; process-wide switch: restored below)
+    try:
+        return _check_bf16_shadows(backend, cfg, B, p, P, x, y)
+    finally:
+        lib.cdll.gt_set_bf16_shadows(-1)
+
+
+def _check_bf16_shadows(backend, cfg, B, p, P, x, y):
+    r = Runner(cfg, B, backend, rng=(1234, 99, 7))
+    r.set_params(P)
+    r.forward(x, train=p > 0)
+    _, dpred = r.loss(y, 0.47)
+    r.backward(dpred, train=p > 0)
+    L, d, F = cfg["num_encoder_layers"], cfg["d_model"], cfg["dim_feedforward"]
+
+    def bf(a):
+        return (ng.round_bf16(np.asarray(a, np.float32)).view(np.uint32) >> 16).astype(np.uint16)
+
+    def shadow(name, l):
+        o, c = r.lib.ws_find(r.c, name + "16", l)
+        return r.ws.numpy()[o:o + c].view(np.uint16)
+
+    n = 0
+    for l in range(L):
+        for name in ["ctx", "x1", "hact"] + (["xout"] if l + 1 < L else []) + ["dhid", "dqkv", "dzAm" if p > 0 else "dzA", "dzBm" if p > 0 else "dzB"]:
+            want = bf(r.ws_get(name, l))
+            got = shadow(name, l)[:want.size]
+            assert np.array_equal(got, want), (name, l, int((got != want).sum()), want.size)
+            n += 1
+        pre = "Encoder.Encoder.layers.%d." % l
+        o, c = r.lib.ws_find(r.c, "w16", l)
+        w16 = r.ws.numpy()[o:o + c].view(np.uint16)
+        o, c = r.lib.ws_find(r.c, "w16t", l)
+        w16t = r.ws.numpy()[o:o + c].view(np.uint16)
+        at = 0
+        for wn in ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"):
+            W = np.asarray(P[pre + wn], np.float32)
+            assert np.array_equal(w16[at:at + W.size], bf(W).reshape(-1)), (wn, l)
+            assert np.array_equal(w16t[at:at + W.size], bf(W.T.copy()).reshape(-1)), (wn, l, "transposed")
+            at += W.size
+            n += 2
     return n
 
 

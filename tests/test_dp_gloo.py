@@ -82,12 +82,21 @@ ENGINE_CASES = {
     "seq_d32": (dict(d_model=32, n_heads=4, dim_feedforward=16, num_encoder_layers=2), 4, 1),      # sequence-resident, one launch per direction: one bucket
     "op_d48": (dict(d_model=48, n_heads=4, dim_feedforward=24, num_encoder_layers=2), 4, 2),       # outside the sequence kernels: one kernel per op, bucketed backward
     "ride_d128": (dict(d_model=128, n_heads=4, dim_feedforward=64, num_encoder_layers=3), 4, 2),   # SPLIT phases with rider weight gradients: cut after phase 2
+    # four ranks, two buckets of very different sizes (a 3-layer model cut after its top layer), and a RAGGED last batch: the second step
+    # has half the sequences of the first (another slot, another workspace on every rank)
+    "op_d48_w4": (dict(d_model=48, n_heads=4, dim_feedforward=24, num_encoder_layers=3), (8, 4), 2),
+    "ride_d128_w4": (dict(d_model=128, n_heads=4, dim_feedforward=32, num_encoder_layers=2), (8, 4), 2),
 }
 
 
 def _engine_dims(case):
     dims, B, nb = ENGINE_CASES[case]
     return dict(dims, num_decoder_layers=0, dropout=0.0, embedding_size_src=16), B, nb
+
+
+def _step_sizes(B):
+    """global batch of each of the two steps"""
+    return tuple(B) if isinstance(B, tuple) else (B, B)
 
 
 def _engine_worker(rank, world, port, out, overlap, case):
@@ -102,17 +111,22 @@ def _engine_worker(rank, world, port, out, overlap, case):
     from transformergrooveinfilling_amd.engine import StepEngine
     parallel.init_distributed("gloo")
     dims, B, nb = _engine_dims(case)
-    eng = StepEngine(batch_size=B // world, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3 | (rank << 32),
+    sizes = _step_sizes(B)
+    eng = StepEngine(batch_size=sizes[0] // world, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3 | (rank << 32),
                      device="cpu", world_size=world, lib=emu_lib(), **dims)
     assert eng.overlap_allreduce == bool(overlap)
     if overlap:                                   # the bucketed branch of StepEngine.train_step must really be the one that runs
-        assert len(eng.lib.grad_buckets(eng.slot(B // world).cfg)) == nb
+        bk = eng.lib.grad_buckets(eng.slot(sizes[0] // world).cfg)
+        assert len(bk) == nb
+        if isinstance(B, tuple):
+            assert bk[0][1] != bk[1][1]           # (uneven buckets)
     eng.load_named(layout.init_params(dims, seed=5))
-    x, y = layout.synthetic_batch(B, 16, seed=9)
-    sl = slice(rank * (B // world), (rank + 1) * (B // world))
-    for _ in range(2):
-        eng.train_step(torch.from_numpy(x[sl]), torch.from_numpy(y[sl]))
-    mean = eng.mean_stats(eng.slot(B // world)).clone()
+    x, y = layout.synthetic_batch(max(sizes), 16, seed=9)
+    for n in sizes:
+        sl = slice(rank * (n // world), (rank + 1) * (n // world))
+        eng.train_step(torch.from_numpy(x[:n][sl]), torch.from_numpy(y[:n][sl]))
+    mean = eng.mean_stats(eng.slot(sizes[-1] // world)).clone()
+    eng.B = sizes[-1] // world                    # (eng.stats = the last step's slot)
     torch.save({"params": eng.params.clone(), "stats": eng.stats.clone(), "mean_stats": mean}, out % rank)
     dist.barrier()
     dist.destroy_process_group()
@@ -121,23 +135,28 @@ def _engine_worker(rank, world, port, out, overlap, case):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("case,overlap", [("seq_d32", 0), ("seq_d32", 1), ("op_d48", 1), ("op_d48", 0), ("ride_d128", 1)])
-def test_engine_dp2_matches_single_process(tmp_path, case, overlap):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("case,overlap,world", [("seq_d32", 0, 2), ("seq_d32", 1, 2), ("op_d48", 1, 2), ("op_d48", 0, 2), ("ride_d128", 1, 2),
+                                                ("op_d48_w4", 1, 4), ("ride_d128_w4", 1, 4)])
+def test_engine_dp_matches_single_process(tmp_path, case, overlap, world):
+    port = _free_port()
     out = str(tmp_path / "eng%d.pt")
     mp.start_processes(_engine_worker, args=(world, port, out, overlap, case), nprocs=world, join=True, start_method="spawn")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from harness import emu_lib
     from transformergrooveinfilling_amd import layout
     from transformergrooveinfilling_amd.engine import StepEngine
-    a, b = torch.load(out % 0), torch.load(out % 1)
+    a, b = torch.load(out % 0), torch.load(out % (world - 1))
     dims, B, _ = _engine_dims(case)
-    eng = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3, device="cpu", lib=emu_lib(), **dims)
+    sizes = _step_sizes(B)
+    eng = StepEngine(batch_size=sizes[0], optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.47, seed=3, device="cpu", lib=emu_lib(), **dims)
     eng.load_named(layout.init_params(dims, seed=5))
-    x, y = layout.synthetic_batch(B, 16, seed=9)
-    for _ in range(2):
-        eng.train_step(torch.from_numpy(x), torch.from_numpy(y))
-    assert torch.equal(a["params"], b["params"])                              # replicas stay identical
+    x, y = layout.synthetic_batch(max(sizes), 16, seed=9)
+    for n in sizes:
+        eng.train_step(torch.from_numpy(x[:n]), torch.from_numpy(y[:n]))
+    eng.B = sizes[-1]
+    for r in range(1, world):
+        assert torch.equal(a["params"], torch.load(out % r)["params"])       # replicas stay identical
+    assert torch.equal(a["params"], b["params"])
     assert (a["params"] - eng.params).abs().max() < 1e-6                      # == one process on the whole batch
     assert torch.allclose(a["mean_stats"], b["mean_stats"])                   # logged stats are the all-rank mean ...
     assert abs(float(a["mean_stats"][0]) - float(eng.stats[0])) < 1e-5        # ... = the loss of the whole batch

@@ -187,6 +187,10 @@ struct WLayout {
   int64_t pack_f = -1, pack_b = -1, pack_stride = 0;   // fragment-ordered weight copies of the sequence-resident kernels (gt_seq.h)
   int64_t seq_dctx = -1;                               // hand-over buffer of their two-workgroups-per-sequence (SPLIT) backward phases
   int64_t seq_xchg = -1, seq_xchg_n = 0;               // pair-exchange region of their four-workgroups-per-sequence (QUAD) forward
+  // bf16 shadows (precision = 1, bf16_shadows()): fp32 tensor offset -> offset (in floats) of its bf16 copy, for the activations whose
+  // producers write one; w16 / w16t: the encoder layers' four matrices and their transposes, [in_w | out_w | w1 | w2] per layer
+  std::vector<std::pair<int64_t, int64_t>> sh;
+  int64_t w16 = -1, w16t = -1, w16_stride = 0;
   struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; };
   std::vector<TmpSet> set;                           // 2 alternating sets, or one per layer (wgrad_deferred)
 };
@@ -199,6 +203,28 @@ struct WLayout {
 #endif
 static bool wgrad_deferred(const gt_config& c) { return (int64_t)c.batch * 32 <= GT_WGRAD_DEFER_MAX_M; }
 static bool seq_supported(const gt_config& c);
+// bf16 SHADOWS of the GEMM operands (precision = 1): where the Linears of the encoder layers run on the big-tile kernel -- interior
+// 128-tiles, enough of them -- and the tensors' producers are the kernels that can write a bf16 copy (LayerNorm passes of d_model 256 /
+// 512, the MFMA attention kernels).
+#ifndef GT_T128_BIG_MIN
+#define GT_T128_BIG_MIN 192
+#endif
+// Measured (round 4, C5 bs 512, tools/rejected/bf16_shadows.md): the Linears' forward / dgrad GEMMs get 1.3-1.4x faster, but the shadows
+// are ADDITIONAL bytes -- the producers (attention, LayerNorm passes, FFN epilogues) pay what the GEMMs gain, and the weight gradients are
+// not bound by their operand fetch at all: 4.03-4.07 ms with, 4.04 ms without.  So the path is OFF by default: gt_set_bf16_shadows(1) /
+// GT_BF16_SHADOWS=1 switch it on (results are bit-identical either way; tests cover it).
+static int g_bf16_shadows = -1;
+extern "C" int gt_set_bf16_shadows(int on) { g_bf16_shadows = on < 0 ? -1 : on != 0; return 0; }
+static bool bf16_shadows(const gt_config& c) {
+  if (g_bf16_shadows < 0) { const char* e = getenv("GT_BF16_SHADOWS"); g_bf16_shadows = (e && e[0] == '1') ? 1 : 0; }
+  const int on = g_bf16_shadows;
+  const int64_t M = (int64_t)c.batch * 32;
+  const int hd = c.n_heads > 0 ? c.d_model / c.n_heads : 0;
+  static const int attn_mfma = [] { const char* e = getenv("GT_ATTN_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();      // (ctx / dqkv shadows)
+  const int nmin = c.d_model < c.dim_ff ? c.d_model : c.dim_ff;            // every Linear of a layer on the big-tile kernel (its epilogue writes hact16 / dhid16)
+  return on && attn_mfma && c.precision == 1 && c.n_enc_layers > 0 && (c.d_model == 256 || c.d_model == 512) && c.dim_ff % 128 == 0 &&
+         M % 128 == 0 && (hd == 16 || hd == 32 || hd == 64 || hd == 128) && (M / 128) * (nmin / 128) >= GT_T128_BIG_MIN;
+}
 static WLayout ws_layout(const gt_config& c) {
   WLayout W;
   int64_t cur = 0;
@@ -250,6 +276,23 @@ static WLayout ws_layout(const gt_config& c) {
     W.seq_dctx = add(2 * M * d);
     if (d == 128) { W.seq_xchg_n = gt_seq_xchg_floats(c.batch); W.seq_xchg = add(W.seq_xchg_n); }
   }
+  if (bf16_shadows(c)) {
+    auto sh = [&](int64_t off, int64_t n) { W.sh.emplace_back(off, add((n + 1) / 2)); };
+    for (int l = 0; l < c.n_enc_layers; ++l) {
+      const LayerW& w = W.layers[l];
+      sh(w.ctx, M * d); sh(w.x1, M * d); sh(w.hact, M * F);
+      if (l + 1 < c.n_enc_layers) sh(w.xout, M * d);          // (the top layer's output comes from the two-norm pass, and feeds no big GEMM)
+    }
+    for (size_t k = 0; k < W.set.size(); ++k) {
+      const WLayout::TmpSet& t = W.set[k];
+      // dz / dzm share a shadow: the consumer takes the masked copy when there is dropout, else dz itself (tmp_set)
+      const int64_t a = add((M * d + 1) / 2), b = add((M * d + 1) / 2);
+      W.sh.emplace_back(t.dzA, a); W.sh.emplace_back(t.dzAm, a); W.sh.emplace_back(t.dzB, b); W.sh.emplace_back(t.dzBm, b);
+      sh(t.dhid, M * F); sh(t.dqkv, M * 3 * d);
+    }
+    W.w16_stride = ((int64_t)4 * d * d + (int64_t)2 * d * F + 1) / 2;          // floats per layer
+    W.w16 = add(W.w16_stride * c.n_enc_layers); W.w16t = add(W.w16_stride * c.n_enc_layers);
+  }
 #ifdef GT_SEQ_STAMPS
   W.stamps = add(2048 + 2 * 4 * 512);
 #endif
@@ -276,9 +319,18 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   const gt_config& c = *cfg;
   WLayout W = ws_layout(c);
   const int64_t M = (int64_t)c.batch * 32, d = c.d_model, F = c.dim_ff, BH = (int64_t)c.batch * c.n_heads;
-  const std::string n(name);
+  std::string n(name);
   int64_t off = -1, cnt = 0;
   auto set = [&](int64_t o, int64_t k) { off = o; cnt = k; };
+  // "<tensor>16": the bf16 shadow of a tensor that has one (precision = 1, bf16_shadows()): offset in floats, count = floats it occupies
+  // (two bf16 per float); "w16" / "w16t": the weight shadows of encoder layer `layer`
+  if (n == "w16" || n == "w16t") {
+    if (W.w16 < 0 || layer < 0 || layer >= c.n_enc_layers) return gt_fail("gt_ws_find: no weight shadows for this configuration / layer");
+    *offset = (n == "w16" ? W.w16 : W.w16t) + W.w16_stride * layer; *count = W.w16_stride;
+    return 0;
+  }
+  const bool want16 = n.size() > 2 && n.compare(n.size() - 2, 2, "16") == 0;
+  if (want16) n.resize(n.size() - 2);
   if (n == "x0") set(W.x0, M * d); else if (n == "a0") set(W.a0, M * d);
   else if (n == "enc_xhat") set(W.enc_xhat, M * d); else if (n == "enc_rstd") set(W.enc_rstd, M);
   else if (n == "memory") set(W.memory, M * d); else if (n == "y0") set(W.y0, M * d); else if (n == "b0") set(W.b0, M * d);
@@ -309,6 +361,10 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
     else if (n == "xout") set(w.xout, M * d);
   }
   if (off < 0) return gt_fail("gt_ws_find: unknown or absent buffer '%s'", name);
+  if (want16) {
+    for (const auto& e : W.sh) if (e.first == off) { *offset = e.second; *count = (cnt + 1) / 2; return 0; }
+    return gt_fail("gt_ws_find: '%s' has no bf16 shadow in this configuration", name);
+  }
   *offset = off; *count = cnt;
   return 0;
 }
@@ -339,6 +395,27 @@ static float* ln_job(const Ctx& x, int64_t gamma_off, int nwg) {
   LnJob& j = x.ln->j[x.ln->n++];
   j.part = part; j.dgamma = x.grd + gamma_off; j.dbeta = x.grd + gamma_off + (x.d + 63) / 64 * 64; j.nwg = nwg;
   return part;
+}
+// bf16 shadow of a workspace tensor (nullptr: it has none) / of an encoder-layer weight matrix (transposed: the copy that turns a
+// dgrad into the NT form)
+static uint16_t* sh_act(const Ctx& x, const float* p) {
+  if (x.W.sh.empty() || p == nullptr) return nullptr;
+  const int64_t off = p - x.ws;
+  for (const auto& e : x.W.sh) if (e.first == off) return reinterpret_cast<uint16_t*>(x.ws + e.second);
+  return nullptr;
+}
+static const uint16_t* sh_w(const Ctx& x, const float* W, bool transposed) {
+  if (x.W.w16 < 0) return nullptr;
+  const int64_t off = W - x.prm, d = x.d, F = x.F;
+  for (int l = 0; l < x.c.n_enc_layers; ++l) {
+    const LayerP& p = x.P.enc[l];
+    const uint16_t* base = reinterpret_cast<const uint16_t*>(x.ws + (transposed ? x.W.w16t : x.W.w16) + x.W.w16_stride * l);
+    if (off == p.sa.in_w) return base;
+    if (off == p.sa.out_w) return base + 3 * d * d;
+    if (off == p.w1) return base + 4 * d * d;
+    if (off == p.w2) return base + 4 * d * d + d * F;
+  }
+  return nullptr;
 }
 struct Tmp { float *dzA, *dzAm, *dzB, *dzBm, *dzC, *dzCm, *dhid, *dqkv, *dqkvx; };
 static Tmp tmp_set(const Ctx& x, int gl) {
@@ -375,12 +452,14 @@ static void linear_fwd(const Ctx& x, const float* in, int ldin, const float* W, 
                        int N, int K) {
   GemmArgs g = mk_gemm(in, ldin, W, K, out, ldout, x.M, N, K);
   g.bias = b;
+  if (ldin == K) { g.A16 = sh_act(x, in); g.B16 = sh_w(x, W, false); g.lda16 = g.ldb16 = K; }
   gemm_launch<false, false, EPI_STORE>(g, x.s);
 }
 // dW (N_w x K_w) += dY^T X ; db += colsum(dY)       ("TN", split over tokens, fp32 atomics)
 static void wgrad(const Ctx& x, const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, int Nw, int Kw) {
   GemmArgs g = mk_gemm(dY, ldy, X, ldx, dW, Kw, Nw, Kw, x.M);
   g.dbias = db;
+  if (ldy == Nw && ldx == Kw) { g.A16 = sh_act(x, dY); g.B16 = sh_act(x, X); g.lda16 = Nw; g.ldb16 = Kw; }     // bf16 shadows of dY / X (precision = 1)
   if (x.wb) wgrad_queue(*x.wb, g, x.s);
   else gemm_launch<true, true, EPI_ATOMIC>(g, x.s);
 }
@@ -444,6 +523,7 @@ static void acquire_set(Ctx& x, int set) {
 static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, int ldw, float* dX, int N, int K, int accumulate) {
   GemmArgs g = mk_gemm(dY, ldy, W, ldw, dX, N, x.M, N, K);
   g.accumulate = accumulate;
+  if (ldy == K && ldw == N) { g.A16 = sh_act(x, dY); g.B16 = sh_w(x, W, true); g.lda16 = g.ldb16 = K; }      // (W^T: [N][K], k contiguous)
   gemm_launch<false, true, EPI_STORE>(g, x.s);
 }
 // dz = LNbwd(dY W + res) with the LayerNorm whose (xhat, rstd, gamma) are given; dzm = dz * dropout mask
@@ -496,15 +576,16 @@ static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float*
   gt_prof_tag("ln_bwd", 0, (res ? 16.0 : 12.0) * x.M * x.d);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (part != nullptr && (x.d == 256 || x.d == 512) && al16(dy) && al16(xhat) && al16(dz) && (!res || al16(res)) && (!x.drop || al16(dzm))) {
+    uint16_t* dzm16 = sh_act(x, x.drop ? dzm : dz);
     if (x.d == 512) gt_launch(ln_bwd_v4_kernel<2>, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd, x.prm + gamma_off, dz,
-                              x.drop ? dzm : (float*)nullptr, mk_drop(x, site), part, x.M, rpw);
+                              x.drop ? dzm : (float*)nullptr, mk_drop(x, site), part, x.M, rpw, dzm16);
     else gt_launch(ln_bwd_v4_kernel<1>, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd, x.prm + gamma_off, dz,
-                   x.drop ? dzm : (float*)nullptr, mk_drop(x, site), part, x.M, rpw);
+                   x.drop ? dzm : (float*)nullptr, mk_drop(x, site), part, x.M, rpw, dzm16);
     return;
   }
   gt_launch(ln_bwd_kernel, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd,
             x.prm + gamma_off, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
-            x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d, rpw);
+            x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d, rpw, sh_act(x, x.drop ? dzm : dz));
 }
 // dz = LNbwd_inner(LNbwd_outer(dy)): the final encoder / decoder norm (outer) and the top layer's last norm (inner) sit back
 // to back; one pass over the rows instead of two launches.  Falls back to two passes when the partials table is full.
@@ -521,7 +602,8 @@ static void ln_bwd2(const Ctx& x, const float* dy, const float* xhat_o, const fl
   }
   gt_prof_tag("ln_bwd", 0, 20.0 * x.M * x.d);
   gt_launch(ln_bwd2_kernel, dim3(nblk), dim3(256), x.s, dy, xhat_o, rstd_o, (const float*)(x.prm + gamma_o), part_o, xhat_i, rstd_i,
-            (const float*)(x.prm + gamma_i), part_i, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.M, x.d, rpw);
+            (const float*)(x.prm + gamma_i), part_i, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.M, x.d, rpw,
+            sh_act(x, x.drop ? dzm : dz));
 }
 // second norm applied right after linear_res_ln's (the final encoder / decoder norm after the last layer)
 struct SecondNorm { int64_t gamma_off; float* y; float* xhat; float* rstd; };
@@ -532,6 +614,7 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
   g.bias = x.prm + b_off;
   const int64_t bo = (x.d + 63) / 64 * 64;          // a norm's bias tensor follows its weight
   if (!row_fused(x)) {
+    g.A16 = sh_act(x, in); g.B16 = sh_w(x, x.prm + w_off, false); g.lda16 = g.ldb16 = K;
     gemm_launch<false, false, EPI_STORE>(g, x.s);
     if (second) {
       gt_prof_tag("ln_fwd", 0, 24.0 * x.M * x.d);
@@ -542,7 +625,7 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
     }
     gt_prof_tag("ln_fwd", 0, 16.0 * x.M * x.d);
     gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
-              x.prm + gamma_off + bo, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d);
+              x.prm + gamma_off + bo, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d, sh_act(x, out));
     return 0;
   }
   g.res = res; g.ldres = x.d;
@@ -553,7 +636,7 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
   if (second) {                                     // fused row tile for the first norm: the second one is its own pass
     gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
     gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, (const float*)nullptr, no_drop(),
-              x.prm + second->gamma_off, x.prm + second->gamma_off + bo, second->y, second->xhat, second->rstd, x.M, x.d, x.d, x.d, x.d);
+              x.prm + second->gamma_off, x.prm + second->gamma_off + bo, second->y, second->xhat, second->rstd, x.M, x.d, x.d, x.d, x.d, (uint16_t*)nullptr);
   }
   return 0;
 }
@@ -571,6 +654,7 @@ static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k,
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = P; a.ctx = ctx; a.ldc = x.d;
   a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.causal = causal; a.drop = mk_drop(x, site);
+  a.ctx16 = attn_mfma_hd(x) > 0 ? sh_act(x, ctx) : nullptr;
   gt_prof_tag("attn_fwd", 4.0 * x.M * 32 * x.d, 4.0 * (4.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   const dim3 grid(x.c.batch * x.H);
   switch (attn_mfma_hd(x)) {
@@ -592,6 +676,7 @@ static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k,
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = const_cast<float*>(P);
   a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.drop = mk_drop(x, site);
   a.dctx = dctx; a.lddc = x.d; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddkv; a.lddv = lddkv;
+  if (attn_mfma_hd(x) > 0 && dk == dq + x.d && dv == dq + 2 * x.d && lddq == 3 * x.d && lddkv == 3 * x.d) a.dqkv16 = sh_act(x, dq);
   gt_prof_tag("attn_bwd", 10.0 * x.M * 32 * x.d, 4.0 * (7.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   const dim3 grid(x.c.batch * x.H);
   // head_dim 64 with the chip full: the LDS-staged form (every operand byte requested once, 16 bytes at a time)
@@ -650,6 +735,8 @@ static int ffn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* 
   float* ws = x.ws;
   GemmArgs g = mk_gemm(xin, x.d, x.prm + p.w1, x.d, ws + w.hact, x.F, x.M, x.F, x.d);
   g.bias = x.prm + p.b1; g.drop = mk_drop(x, lsite(gl, GT_SITE_FFN));
+  g.A16 = sh_act(x, xin); g.B16 = sh_w(x, x.prm + p.w1, false); g.lda16 = g.ldb16 = x.d;
+  if (g.A16 && g.B16) { g.C16 = sh_act(x, ws + w.hact); g.ldc16 = x.F; }      // (written by the bf16-source kernel's epilogue only)
   gemm_launch<false, false, EPI_RELU_DROP>(g, x.s);
   return linear_res_ln(x, ws + w.hact, x.F, p.w2, p.b2, xin, norm_w, ws + w.xout, ws + w.xhat2, ws + w.rstd2,
                        lsite(gl, GT_SITE_DROPF), second);
@@ -814,6 +901,17 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
 
 static int encoder_fwd(const Ctx& x, const float* pe, const float* src) {
   float* ws = x.ws;
+  if (x.W.w16 >= 0) {      // bf16 shadows of the encoder layers' weights (and their transposes) for this step's Linears and dgrads
+    const LayerP& p0 = x.P.enc[0];
+    WShadowArgs a;
+    a.prm = x.prm; a.w16 = reinterpret_cast<uint16_t*>(ws + x.W.w16); a.w16t = reinterpret_cast<uint16_t*>(ws + x.W.w16t);
+    a.in_w = p0.sa.in_w; a.out_w = p0.sa.out_w; a.w1 = p0.w1; a.w2 = p0.w2;
+    a.pstride = x.c.n_enc_layers > 1 ? x.P.enc[1].sa.in_w - p0.sa.in_w : 0; a.sstride = 2 * x.W.w16_stride;
+    a.d = x.d; a.F = x.F; a.L = x.c.n_enc_layers;
+    const int tiles = (4 * x.d * x.d + 2 * x.d * x.F) / 1024;
+    gt_prof_tag("weight_shadow", 0.0, 8.0 * x.c.n_enc_layers * tiles * 1024.0);
+    gt_launch(weight_shadow_kernel, dim3((unsigned)(tiles * x.c.n_enc_layers)), dim3(256), x.s, a);
+  }
   input_layer_fwd(x, src, x.c.src_dim, x.P.in_w, x.P.in_b, pe, ws + x.W.a0, ws + x.W.x0, GT_SITE_PE_ENC);
   const float* cur = ws + x.W.x0;
   for (int l = 0; l < x.c.n_enc_layers; ++l) {
@@ -862,7 +960,7 @@ static void step_linear_res_ln(const Ctx& x, int B, const float* in, int ldin, i
                                int64_t gamma_off, float* out, float* xhat, float* rstd) {
   step_linear(x, B, in, ldin, x.prm + w_off, x.prm + b_off, out, x.d, x.d, K);
   gt_launch(ln_fwd_kernel, dim3((B + 3) / 4), dim3(256), x.s, (const float*)out, res, no_drop(), x.prm + gamma_off,
-            x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, B, x.d, 32 * x.d, 32 * x.d, 32 * x.d);
+            x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, B, x.d, 32 * x.d, 32 * x.d, 32 * x.d, (uint16_t*)nullptr);
 }
 static void step_attention(const Ctx& x, int B, const float* q, int ldq, const float* k, const float* v, int ldkv, float* ctx, int nkeys) {
   AttnArgs a;
@@ -901,7 +999,7 @@ static void decoder_step(const Ctx& x, const float* pe, const float* tgt, int t,
     cur = ws + w.xout;
   }
   gt_launch(ln_fwd_kernel, dim3((B + 3) / 4), dim3(256), x.s, cur + r * d, (const float*)nullptr, no_drop(), x.prm + x.P.decn_w,
-            x.prm + x.P.decn_b, ws + x.W.dec_final + r * d, ws + x.W.dec_xhat, ws + x.W.dec_rstd, B, d, 32 * d, 32 * d, 32 * d);
+            x.prm + x.P.decn_b, ws + x.W.dec_final + r * d, ws + x.W.dec_xhat, ws + x.W.dec_rstd, B, d, 32 * d, 32 * d, 32 * d, (uint16_t*)nullptr);
   GemmArgs g = mk_gemm(ws + x.W.dec_final + r * d, 32 * d, x.prm + x.P.out_w, d, hvo_tmp + r * GT_TGT, 32 * GT_TGT, B, GT_TGT, d);
   g.bias = x.prm + x.P.out_b;
   gemm_launch<false, false, EPI_HEADS>(g, x.s);
@@ -953,6 +1051,8 @@ static int ffn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const Tmp& t,
   GemmArgs g = mk_gemm(dzm, x.d, x.prm + p.w2, x.F, t.dhid, x.F, x.M, x.F, x.d);
   g.res = ws + w.hact; g.ldres = x.F;
   g.mask_scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
+  g.A16 = sh_act(x, dzm); g.B16 = sh_w(x, x.prm + p.w2, true); g.lda16 = g.ldb16 = x.d;
+  if (g.A16 && g.B16) { g.C16 = sh_act(x, t.dhid); g.ldc16 = x.F; }
   gemm_launch<false, true, EPI_MASK_NZ>(g, x.s);
   wgrad(x, t.dhid, x.F, xin, x.d, x.grd + p.w1, x.grd + p.b1, x.F, x.d);
   return dgrad_lnbwd(x, t.dhid, x.F, x.prm + p.w1, x.F, dz, xhat_prev, rstd_prev, gamma_prev, dzo, dzom, site_prev);

@@ -27,6 +27,9 @@ struct AttnArgs {
   // backward
   const float* dctx; int lddc;
   float* dq; float* dk; float* dv; int lddq, lddk, lddv;
+  // bf16 copies for the GEMMs that take these outputs as operands at precision = 1 (GemmArgs::A16; the MFMA kernels only):
+  // ctx16 (M, d) beside ctx; dqkv16 (M, 3 d) = [dq | dk | dv] beside a dqkv buffer the three gradients are written into.  nullptr: none
+  uint16_t* ctx16; uint16_t* dqkv16;
 };
 
 __device__ static inline void attn_load_slab(float (*s)[33], const float* src, int ld, int b, int h, int hd, int c0, int tid, const float* zp) {
@@ -283,6 +286,13 @@ __device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const int 
   for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { if (!PAD || 16 * ct + l16 < hdr) orow[(size_t)r * a.ldc + 16 * ct] = o[ct][r]; }
+  if (a.ctx16 != nullptr) {                                 // (dense (M, H hd) rows)
+    uint16_t* __restrict__ o16 = a.ctx16 + (size_t)(b * 32 + 16 * ti + 4 * g) * (a.H * hdr) + h * hdr + l16;
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { if (!PAD || 16 * ct + l16 < hdr) o16[(size_t)r * (a.H * hdr) + 16 * ct] = gt_f2bf(o[ct][r]); }
+  }
 }
 
 template <int HD, bool PAD>
@@ -461,6 +471,19 @@ __device__ __forceinline__ void attn_bwd_store_direct(const AttnArgs& a, const i
       dvrow[(size_t)r * a.lddv + 16 * ct] = ov[ct][r];
       dkrow[(size_t)r * a.lddk + 16 * ct] = ok[ct][r];
     }
+  if (a.dqkv16 != nullptr) {                                // [dq | dk | dv], dense (M, 3 d) rows
+    const int d = a.H * hdr;
+    uint16_t* __restrict__ o16 = a.dqkv16 + (row0 + 16 * w + 4 * g) * (size_t)(3 * d) + hc + l16;
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (PAD && 16 * ct + l16 >= hdr) continue;
+        o16[(size_t)r * (3 * d) + 16 * ct] = gt_f2bf(dq_out[ct][r]);
+        o16[(size_t)r * (3 * d) + 16 * ct + d] = gt_f2bf(ok[ct][r]);
+        o16[(size_t)r * (3 * d) + 16 * ct + 2 * d] = gt_f2bf(ov[ct][r]);
+      }
+  }
 }
 template <int HD, bool PAD>
 __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
@@ -531,6 +554,16 @@ __global__ __launch_bounds__(128) void attn_bwd_lds_kernel(AttnArgs a) {
     *reinterpret_cast<float4*>(a.dq + (row0 + r) * a.lddq + hc + c) = *reinterpret_cast<const float4*>(sm + o);
     *reinterpret_cast<float4*>(a.dk + (row0 + r) * a.lddk + hc + c) = *reinterpret_cast<const float4*>(sm + 32 * LD + o);
     *reinterpret_cast<float4*>(a.dv + (row0 + r) * a.lddv + hc + c) = *reinterpret_cast<const float4*>(sm + 64 * LD + o);
+    if (a.dqkv16 != nullptr) {                              // [dq | dk | dv], dense (M, 3 d) rows
+      const int d = a.H * HD;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        const float4 v = *reinterpret_cast<const float4*>(sm + part * 32 * LD + o);
+        uint2 pk;
+        pk.x = (uint32_t)gt_f2bf(v.x) | ((uint32_t)gt_f2bf(v.y) << 16); pk.y = (uint32_t)gt_f2bf(v.z) | ((uint32_t)gt_f2bf(v.w) << 16);
+        *reinterpret_cast<uint2*>(a.dqkv16 + (row0 + r) * (size_t)(3 * d) + part * d + hc + c) = pk;
+      }
+    }
   }
 }
 

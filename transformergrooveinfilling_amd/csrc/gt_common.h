@@ -28,6 +28,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // "Correctness boundaries")
 __device__ __forceinline__ uint16_t gt_f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 #endif
+#ifdef GT_EMU
+static inline uint32_t gt_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float gt_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+#else
+__device__ __forceinline__ uint32_t gt_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float gt_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+#endif
 __host__ __device__ static inline float gt_bf2f(uint16_t h) {
   union { uint32_t u; float f; } c;
   c.u = (uint32_t)h << 16;

@@ -63,6 +63,13 @@ struct GemmArgs {
   float mask_scale;
   int bf16;                  // gt_config.precision: 1 = the operands go through the matrix cores as bf16 (fp32 accumulate)
   DropArgs drop;
+  // bf16 SHADOWS (precision = 1, round 4): A16 [M][K] / B16 [N][K], k contiguous -- bf16-rounded copies of A and of the weight (for a
+  // dgrad: of its transpose, which turns the product into this same NT form), written by the tensors' producers / the per-step weight
+  // shadow kernel.  With both present the product runs on gemm32h_kernel (gt_gemm32.h): half the bytes staged per flop, bitwise the
+  // results of the fp32-source kernel, which rounds the same values at fragment assembly.  C16 (ldc16): optional bf16 copy of the
+  // OUTPUT, for the next consumer.  nullptr: none.
+  const uint16_t* A16; const uint16_t* B16; int lda16, ldb16;
+  uint16_t* C16; int ldc16;
 };
 
 template <int ROWS, int COLS, int NT>
@@ -801,22 +808,27 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
 #ifndef GT_WGRAD32_UNIFORM_MIN
 #define GT_WGRAD32_UNIFORM_MIN 16384
 #endif
+#define GT_WG_CLASSES 6
 struct WgradBatch {
-  GemmGroup grp[4];            // [0]: 32x32-tile problems, [1]: 64x64, [2]: 128x128, [3]: 128x128 on the big-tile body (gt_gemm32.h)
-  double flops[4], bytes[4];
+  // [0]: 32x32-tile problems, [1]: 64x64, [2]: 128x128, [3]: 128x128 on the big-tile body (gt_gemm32.h); [4] / [5]: the same body with both
+  // operands / only dY staged from their bf16 shadows (precision = 1; GemmArgs::A16 / B16)
+  GemmGroup grp[GT_WG_CLASSES];
+  double flops[GT_WG_CLASSES], bytes[GT_WG_CLASSES];
   int bf16;                    // every problem of a batch shares the step's precision
-  WgradBatch() : bf16(0) { for (int k = 0; k < 4; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
-  bool empty() const { return grp[0].n == 0 && grp[1].n == 0 && grp[2].n == 0 && grp[3].n == 0; }
+  WgradBatch() : bf16(0) { for (int k = 0; k < GT_WG_CLASSES; ++k) { grp[k].n = 0; grp[k].start[0] = 0; flops[k] = bytes[k] = 0; } }
+  bool empty() const { for (int k = 0; k < GT_WG_CLASSES; ++k) if (grp[k].n) return false; return true; }
 };
 static inline bool wgrad32_ok(const GemmArgs& g);
-template <int PREC> __global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp);
+template <int PREC, bool SA16, bool SB16> __global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp);
 static inline void wgrad_flush_one(WgradBatch& wb, int k, hipStream_t s) {
   GemmGroup& G = wb.grp[k];
   if (G.n == 0) return;
   gt_prof_tag("gemm_wgrad", wb.flops[k], wb.bytes[k]);
-  if (k == 3) {
-    if (wb.bf16) gt_launch(wgrad32_group_kernel<1>, dim3(G.start[G.n]), dim3(256), s, G);
-    else         gt_launch(wgrad32_group_kernel<0>, dim3(G.start[G.n]), dim3(256), s, G);
+  if (k == 4) gt_launch(wgrad32_group_kernel<1, true, true>, dim3(G.start[G.n]), dim3(256), s, G);
+  else if (k == 5) gt_launch(wgrad32_group_kernel<1, true, false>, dim3(G.start[G.n]), dim3(256), s, G);
+  else if (k == 3) {
+    if (wb.bf16) gt_launch(wgrad32_group_kernel<1, false, false>, dim3(G.start[G.n]), dim3(256), s, G);
+    else         gt_launch(wgrad32_group_kernel<0, false, false>, dim3(G.start[G.n]), dim3(256), s, G);
   } else if (wb.bf16) {
     if (k == 0)      gt_launch(wgrad_group_kernel<1, 1>, dim3(G.start[G.n]), dim3(256), s, G);
     else if (k == 1) gt_launch(wgrad_group_kernel<2, 1>, dim3(G.start[G.n]), dim3(256), s, G);
@@ -828,7 +840,7 @@ static inline void wgrad_flush_one(WgradBatch& wb, int k, hipStream_t s) {
   }
   G.n = 0; wb.flops[k] = wb.bytes[k] = 0;
 }
-static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) { for (int k = 0; k < 4; ++k) wgrad_flush_one(wb, k, s); }
+static inline void wgrad_flush(WgradBatch& wb, hipStream_t s) { for (int k = 0; k < GT_WG_CLASSES; ++k) wgrad_flush_one(wb, k, s); }
 static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   // tile size by how many workgroups the problem still yields: 128x128 over >= 512-token chunks, else 64x64 over >= 256-token
   // chunks, else 32x32 (C2 at bs 64: 16 64x64-tiles x 8 chunks -> stays 32x32)
@@ -837,6 +849,10 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
           : (g.M >= 64 && g.N >= 64 && t64 * ((g.K + 255) / 256) >= GT_WGRAD_T64_MIN) ? 1 : 0;
   const int tile = 32 << cls;
   if (cls == 2 && wgrad32_ok(g)) cls = 3;             // interior-only 128x128 problems: the prefetch-ring body
+  if (cls == 3 && g.bf16 && g.A16 != nullptr && (g.lda16 & 7) == 0 && (reinterpret_cast<uintptr_t>(g.A16) & 15) == 0) {
+    const bool b16 = g.B16 != nullptr && (g.ldb16 & 7) == 0 && (reinterpret_cast<uintptr_t>(g.B16) & 15) == 0;
+    cls = b16 ? 4 : 5;                                 // ... staged from the operands' bf16 shadows
+  }
   wb.bf16 = g.bf16;
   if (wb.grp[cls].n == GT_GROUP_MAX) wgrad_flush_one(wb, cls, s);
   // (big-tile body: fewer, longer token chunks -- every chunk ends in 64 KB of fp32 atomics per tile, and the chip adds
@@ -846,8 +862,8 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
   // instead of 22-32 -- at 16384 tokens the per-problem target count had the d_model-512 step add ~1 GB of atomic bytes against
   // the chip's ~1.3 TB/s (C4 bs512: 9.79 -> 9.28 ms; at 2048 / 8192 tokens the shorter uneven chunks stay ahead: A/B in DESIGN 3a)
   int splitk;
-  if (cls == 3 && !gt_deterministic() && g.K >= GT_WGRAD32_UNIFORM_MIN) { g.k_chunk = GT_WGRAD32_CHUNK; splitk = (g.K + g.k_chunk - 1) / g.k_chunk; }
-  else splitk = wgrad_split(g, cls == 3 ? GT_WGRAD32_SPLIT : cls ? GT_WGRAD_SPLIT_BIG : GT_WGRAD_SPLIT_SMALL, tile);
+  if (cls >= 3 && !gt_deterministic() && g.K >= GT_WGRAD32_UNIFORM_MIN) { g.k_chunk = GT_WGRAD32_CHUNK; splitk = (g.K + g.k_chunk - 1) / g.k_chunk; }
+  else splitk = wgrad_split(g, cls >= 3 ? GT_WGRAD32_SPLIT : cls ? GT_WGRAD_SPLIT_BIG : GT_WGRAD_SPLIT_SMALL, tile);
   GemmGroup& G = wb.grp[cls];
   const int i = G.n++;
   G.p[i] = g;
@@ -874,6 +890,9 @@ static inline void wgrad_queue(WgradBatch& wb, GemmArgs g, hipStream_t s) {
 static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm);
 template <bool BKM, int EPI>
 static inline void gemm32_launch(const GemmArgs& g, hipStream_t s);
+static inline bool gemm32h_ok(const GemmArgs& g, int epi);
+template <bool BKM, int EPI>
+static inline void gemm32h_launch(const GemmArgs& g, hipStream_t s);
 #ifndef GT_T128_BIG_MIN
 #define GT_T128_BIG_MIN 192     /* 128x128 tiles of the big kernel from this many workgroups (d512 QKV at 2048 tokens: 16 x 12) */
 #endif
@@ -889,6 +908,7 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   }
   if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP)) {
     const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (g.bf16 && b128 >= GT_T128_BIG_MIN && gemm32h_ok(g, EPI)) { gemm32h_launch<BKM, EPI>(g, s); return; }     // both operands as bf16 shadows
     if (g.bf16 && b128 >= GT_T128_BIG_MIN && gemm32_ok(g, EPI, BKM)) { gemm32_launch<BKM, EPI>(g, s); return; }
   }
   if (g.bf16) {

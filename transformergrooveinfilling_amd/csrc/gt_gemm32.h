@@ -42,15 +42,74 @@ static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm) {
   return true;
 }
 
+// The store epilogues of the 128x128 tile (transposed product: lane (r32, h) holds ONE row of C per 32x32 tile and, in registers
+// 4 q .. 4 q + 3, the four consecutive columns 8 q + 4 h + 0..3): two-phase -- every global input first, then compute + 16-byte stores.
+// g.C16: a bf16 copy of the stored values as well (8-byte stores), for a consumer that takes this output as a GEMM operand.
+template <int EPI>
+__device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
+                                                      const int r32, const int h) {
+  const uint32_t dkey = gt_drop_key(g.drop);
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {
+    f32x4 bia[4], rin[2][4], rin2[2][4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
+      bia[q4] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((EPI == EPI_STORE || EPI == EPI_RELU_DROP) && g.bias != nullptr) bia[q4] = *reinterpret_cast<const f32x4*>(g.bias + col);
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta) {
+        const int row = m0 + wm * 64 + ta * 32 + r32;
+        rin[ta][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_STORE && g.accumulate) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.C + (size_t)row * g.ldc + col);
+        if (EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + col);
+        if (EPI == EPI_ADD_RELUMASK_DROP) rin2[ta][q4] = *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.N + col);
+      }
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta) {
+        const int row = m0 + wm * 64 + ta * 32 + r32;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ta][tb][4 * q4 + r];
+          if (EPI == EPI_STORE) v = v + bia[q4][r] + rin[ta][q4][r];
+          else if (EPI == EPI_RELU_DROP) v = fmaxf(v + bia[q4][r], 0.f) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
+          else if (EPI == EPI_MASK_NZ) v = (rin[ta][q4][r] != 0.f) ? v * g.mask_scale : 0.f;
+          else if (EPI == EPI_ADD_RELUMASK_DROP) {
+            v = (v + rin[ta][q4][r]) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
+            v = (rin2[ta][q4][r] > 0.f) ? v : 0.f;
+          }
+          o[r] = v;
+        }
+        *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = o;
+        if (g.C16 != nullptr) {
+          uint2 pk;
+          pk.x = (uint32_t)gt_f2bf(o[0]) | ((uint32_t)gt_f2bf(o[1]) << 16); pk.y = (uint32_t)gt_f2bf(o[2]) | ((uint32_t)gt_f2bf(o[3]) << 16);
+          *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = pk;
+        }
+      }
+    }
+  }
+}
+
 // One 128x128 output tile: rows m0.., columns n0.., contraction range [kbeg, kbeg + nk * 32) (nk even, >= 2).
 // AKM / BKM as in gt_gemm.h: operand stored with the contraction index as its ROW index (weight gradients: both; dgrad: B).
 // PREC = 1 (gt_config.precision = 1): the same staging, fp32 LDS images in source orientation; the operands are rounded to bf16
 // when a lane assembles its fragment (8 consecutive k per lane half, two ds_read_b128 or eight ds_read_b32) and go through
 // v_mfma_f32_32x32x16_bf16.  16x fewer matrix cycles: the loop is then bound by the global -> LDS staging alone, so it runs a
 // plain one-barrier-per-slab schedule on the same two-deep ring.
-template <bool AKM, bool BKM, int EPI, int PREC = 0>
+// SA16 / SB16 (weight gradients at PREC = 1 only: both operands token-major): that operand is staged from its bf16 SHADOW (g.A16 / g.B16,
+// row stride lda16 / ldb16 elements) -- 16-byte loads of 8 elements, widened to fp32 on their way into the SAME fp32 LDS image (a bf16
+// value is its fp32 neighbour's upper half), so everything behind the staging, and every result, is unchanged: half the bytes fetched.
+typedef f32x4 __attribute__((may_alias)) f32x4_raw;          // 16 raw bytes (8 bf16) held in a float4 register set
+template <bool AKM, bool BKM, int EPI, int PREC = 0, bool SA16 = false, bool SB16 = false>
 __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, const int n0, const int kbeg, const int nk, const bool want_dbias,
                                             float* smem) {
+  static_assert((!SA16 && !SB16) || (AKM && BKM && PREC == 1), "bf16 sources: the weight-gradient form at precision 1");
   typedef Gemm32Cfg Cfg;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
   constexpr int SA_STR = Cfg::str<AKM>(), SA_SZ = Cfg::sz<AKM>(), SB_STR = Cfg::str<BKM>(), SB_SZ = Cfg::sz<BKM>();
@@ -82,17 +141,34 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
       pb[i] = reinterpret_cast<const char*>(g.B + (size_t)(n0 + r) * g.ldb + kbeg + c);
       sb_off[i] = r * SB_STR + c;
     }
+    // bf16 sources (row-contiguous only): chunk = (k, 8 rows) = 16 bytes; PER / 2 chunks per thread and slab, sets [0 .. PER / 2) in use
+    if (i < PER / 2) {
+      const int kr16 = ch >> 4, cn16 = (ch & 15) * 8;
+      if (SA16) { pa[i] = reinterpret_cast<const char*>(g.A16 + (size_t)(kbeg + kr16) * g.lda16 + m0 + cn16); sa_off[i] = kr16 * SA_STR + cn16; }
+      if (SB16) { pb[i] = reinterpret_cast<const char*>(g.B16 + (size_t)(kbeg + kr16) * g.ldb16 + n0 + cn16); sb_off[i] = kr16 * SB_STR + cn16; }
+    }
   }
-  const size_t astep = AKM ? (size_t)g.lda * 4 : 4, bstep = BKM ? (size_t)g.ldb * 4 : 4;    // bytes per k
+  const size_t astep = SA16 ? (size_t)g.lda16 * 2 : AKM ? (size_t)g.lda * 4 : 4, bstep = SB16 ? (size_t)g.ldb16 * 2 : BKM ? (size_t)g.ldb * 4 : 4;    // bytes per k
+  // 8 bf16 in a register set -> two float4: element 2 w is the low half of word w, 2 w + 1 its high half
+  auto widen_lo = [](const f32x4& v) { return f32x4{gt_u2f(gt_f2u(v[0]) << 16), gt_u2f(gt_f2u(v[0]) & 0xFFFF0000u), gt_u2f(gt_f2u(v[1]) << 16), gt_u2f(gt_f2u(v[1]) & 0xFFFF0000u)}; };
+  auto widen_hi = [](const f32x4& v) { return f32x4{gt_u2f(gt_f2u(v[2]) << 16), gt_u2f(gt_f2u(v[2]) & 0xFFFF0000u), gt_u2f(gt_f2u(v[3]) << 16), gt_u2f(gt_f2u(v[3]) & 0xFFFF0000u)}; };
 #define G32_LD(XA, XB, k0)                                                                     \
   _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
-    XA[i] = *reinterpret_cast<const f32x4*>(pa[i] + (size_t)(k0) * astep);                     \
-    XB[i] = *reinterpret_cast<const f32x4*>(pb[i] + (size_t)(k0) * bstep);                     \
+    if (!SA16 || i < PER / 2) XA[i] = *reinterpret_cast<const f32x4_raw*>(pa[i] + (size_t)(k0) * astep); \
+    if (!SB16 || i < PER / 2) XB[i] = *reinterpret_cast<const f32x4_raw*>(pb[i] + (size_t)(k0) * bstep); \
   }
 #define G32_ST(XA, XB, buf)                                                                    \
   _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
-    *reinterpret_cast<f32x4*>(&smem[(buf) * SA_SZ + sa_off[i]]) = XA[i];                       \
-    *reinterpret_cast<f32x4*>(&smem[2 * SA_SZ + (buf) * SB_SZ + sb_off[i]]) = XB[i];           \
+    if (!SA16) *reinterpret_cast<f32x4*>(&smem[(buf) * SA_SZ + sa_off[i]]) = XA[i];            \
+    else if (i < PER / 2) {                                                                    \
+      *reinterpret_cast<f32x4*>(&smem[(buf) * SA_SZ + sa_off[i]]) = widen_lo(XA[i]);           \
+      *reinterpret_cast<f32x4*>(&smem[(buf) * SA_SZ + sa_off[i] + 4]) = widen_hi(XA[i]);       \
+    }                                                                                          \
+    if (!SB16) *reinterpret_cast<f32x4*>(&smem[2 * SA_SZ + (buf) * SB_SZ + sb_off[i]]) = XB[i]; \
+    else if (i < PER / 2) {                                                                    \
+      *reinterpret_cast<f32x4*>(&smem[2 * SA_SZ + (buf) * SB_SZ + sb_off[i]]) = widen_lo(XB[i]); \
+      *reinterpret_cast<f32x4*>(&smem[2 * SA_SZ + (buf) * SB_SZ + sb_off[i] + 4]) = widen_hi(XB[i]); \
+    }                                                                                          \
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -223,53 +299,116 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
         }
     return;
   }
-  // ---- epilogue (two-phase: every global input first, then compute + 16-byte stores) ----
-  const uint32_t dkey = gt_drop_key(g.drop);
-#pragma unroll
-  for (int tb = 0; tb < 2; ++tb) {
-    f32x4 bia[4], rin[2][4], rin2[2][4];
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
-      bia[q4] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if ((EPI == EPI_STORE || EPI == EPI_RELU_DROP) && g.bias != nullptr) bia[q4] = *reinterpret_cast<const f32x4*>(g.bias + col);
-#pragma unroll
-      for (int ta = 0; ta < 2; ++ta) {
-        const int row = m0 + wm * 64 + ta * 32 + r32;
-        rin[ta][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI == EPI_STORE && g.accumulate) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.C + (size_t)row * g.ldc + col);
-        if (EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + col);
-        if (EPI == EPI_ADD_RELUMASK_DROP) rin2[ta][q4] = *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.N + col);
-      }
-    }
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
-#pragma unroll
-      for (int ta = 0; ta < 2; ++ta) {
-        const int row = m0 + wm * 64 + ta * 32 + r32;
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[ta][tb][4 * q4 + r];
-          if (EPI == EPI_STORE) v = v + bia[q4][r] + rin[ta][q4][r];
-          else if (EPI == EPI_RELU_DROP) v = fmaxf(v + bia[q4][r], 0.f) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
-          else if (EPI == EPI_MASK_NZ) v = (rin[ta][q4][r] != 0.f) ? v * g.mask_scale : 0.f;
-          else if (EPI == EPI_ADD_RELUMASK_DROP) {
-            v = (v + rin[ta][q4][r]) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
-            v = (rin2[ta][q4][r] > 0.f) ? v : 0.f;
-          }
-          o[r] = v;
-        }
-        *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = o;
-      }
-    }
-  }
+  gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h);
 #undef G32_LD
 #undef G32_ST
 #undef G32_RD
 #undef G32_MM
 #undef G32_SLAB
+}
+
+// ================================================================================================================ bf16 SOURCES
+// gt_config.precision = 1 at sizes where the loop above is bound by the global -> LDS staging (fp32 sources: 32 KB per 128x128x32
+// slab): both operands come as bf16 SHADOWS (g.A16 [M][K], g.B16 [N][K], k contiguous: activations written by their producers next to
+// the fp32 tensors, weights by weight_shadow_kernel -- the transposed copy makes a dgrad this same NT form).  Same bytes per slab, twice
+// the k: 128x128x64 slabs, bf16 LDS images [128][64 + 8] (144-byte rows: a fragment = one ds_read_b128, conflict-free), a three-deep
+// register ring, v_mfma_f32_32x32x16_bf16 with the k -> (lane half, element) map of the PREC = 1 body above: the sums are the same
+// numbers.  Measured in isolation (round 3, tools/rejected/gemm32h_bf16_shadows.md): 1.28-1.34x the fp32-source kernel at K = 512.
+struct Gemm32hCfg {
+  static constexpr int BK = 64, STR = BK + 8, SZ = 128 * STR;           // bf16 elements
+};
+#ifdef GT_EMU
+struct __attribute__((may_alias, aligned(16))) G32hRegs { uint32_t v[4]; };       // 16 bytes = 8 bf16
+#else
+typedef uint32_t G32hRegs __attribute__((ext_vector_type(4)));                    // (one global_load_dwordx4 / ds_write_b128 each)
+#endif
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm32h_kernel(GemmArgs g) {
+  typedef Gemm32hCfg Cfg;
+  constexpr int BK = Cfg::BK, STR = Cfg::STR, SZ = Cfg::SZ, PER = 4;
+  __shared__ __attribute__((aligned(16))) uint16_t sm[4 * SZ];           // [buffer][A | B]
+  const int gx = gridDim.x, nb = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+  const int xcd = lin & 7, q = nb >> 3, rr = nb & 7;
+  const int bid = xcd * q + (xcd < rr ? xcd : rr) + (lin >> 3);
+  const int m0 = (bid / gx) * 128, n0 = (bid % gx) * 128, nk = g.K / BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  G32hRegs a0[PER], b0[PER], a1[PER], b1[PER], a2[PER], b2[PER];
+  const uint16_t* pa[PER];
+  const uint16_t* pb[PER];
+  int so[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ch = tid + i * 256, r = ch >> 3, c = (ch & 7) * 8;         // (row, 8 k) = 16 bytes
+    pa[i] = g.A16 + (size_t)(m0 + r) * g.lda16 + c;
+    pb[i] = g.B16 + (size_t)(n0 + r) * g.ldb16 + c;
+    so[i] = r * STR + c;
+  }
+#define G32H_LD(XA, XB, k0)                                                                    \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
+    XA[i] = *reinterpret_cast<const G32hRegs*>(pa[i] + (k0));                                  \
+    XB[i] = *reinterpret_cast<const G32hRegs*>(pb[i] + (k0));                                  \
+  }
+#define G32H_ST(XA, XB, buf)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
+    *reinterpret_cast<G32hRegs*>(&sm[(buf) * 2 * SZ + so[i]]) = XA[i];                         \
+    *reinterpret_cast<G32hRegs*>(&sm[(buf) * 2 * SZ + SZ + so[i]]) = XB[i];                    \
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int fa = (wm * 64 + r32) * STR + 8 * h, fb = SZ + (wn * 64 + r32) * STR + 8 * h;
+  // a three-deep register ring: the A panel comes from HBM once per 128 rows and every slab waits for its slowest load
+  auto kof = [&](const int t) { return (t < nk ? t : nk - 1) * BK; };
+  G32H_LD(a0, b0, 0)
+  G32H_LD(a1, b1, kof(1))
+  G32H_LD(a2, b2, kof(2))
+  G32H_ST(a0, b0, 0)
+  G32H_LD(a0, b0, kof(3))
+  __syncthreads();
+  // slab t from LDS buffer CUR; (NA, NB) hold slab t + 1: written to the other buffer, then reloaded with slab t + 4
+#define G32H_SLAB(CUR, NA, NB, t)                                                              \
+  if ((t) < nk) {                                                                              \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                           \
+    bf16x8 a16[2], b16[2];                                                                     \
+    _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) {                                         \
+      a16[ti] = *reinterpret_cast<const bf16x8*>(&sm[(CUR) * 2 * SZ + fa + ti * 32 * STR + 16 * s_]); \
+      b16[ti] = *reinterpret_cast<const bf16x8*>(&sm[(CUR) * 2 * SZ + fb + ti * 32 * STR + 16 * s_]); \
+    }                                                                                          \
+    _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                           \
+    _Pragma("unroll") for (int tb = 0; tb < 2; ++tb)                                           \
+      acc[ta][tb] = GT_MFMA32_BF16(b16[tb], a16[ta], acc[ta][tb]);                             \
+  }                                                                                            \
+  G32H_ST(NA, NB, (CUR) ^ 1)                                                                   \
+  G32H_LD(NA, NB, kof((t) + 4))                                                                \
+  __syncthreads();                                                                             \
+  }
+  for (int kt = 0; kt < nk; kt += 6) {
+    G32H_SLAB(0, a1, b1, kt) G32H_SLAB(1, a2, b2, kt + 1) G32H_SLAB(0, a0, b0, kt + 2)
+    G32H_SLAB(1, a1, b1, kt + 3) G32H_SLAB(0, a2, b2, kt + 4) G32H_SLAB(1, a0, b0, kt + 5)
+  }
+#undef G32H_SLAB
+#undef G32H_LD
+#undef G32H_ST
+  gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h);
+}
+// host side: shadows present, interior tiles, 16-byte rows
+static inline bool gemm32h_ok(const GemmArgs& g, int epi) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!g.A16 || !g.B16 || (g.lda16 & 7) || (g.ldb16 & 7) || !al16(g.A16) || !al16(g.B16)) return false;
+  if (g.C16 && ((g.ldc16 & 3) || (reinterpret_cast<uintptr_t>(g.C16) & 7))) return false;
+  if (g.accumulate) return false;
+  GemmArgs t = g; t.A = reinterpret_cast<const float*>(g.A16); t.B = reinterpret_cast<const float*>(g.B16); t.lda = t.ldb = 4;
+  return gemm32_ok(t, epi, false);
+}
+template <bool BKM, int EPI>
+static inline void gemm32h_launch(const GemmArgs& g, hipStream_t s) {
+  gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + 4.0 * (double)g.M * g.N);
+  gt_launch(gemm32h_kernel<EPI>, dim3(g.N / 128, g.M / 128), dim3(256), s, g);
 }
 
 // ================================================================================================================ row-owning tiles
@@ -410,7 +549,7 @@ static inline bool wgrad32_ok(const GemmArgs& g) {
   return g.M % 128 == 0 && g.N % 128 == 0 && g.K % 64 == 0 && g.K >= 64 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 &&
          al16(g.A) && al16(g.B);
 }
-template <int PREC>
+template <int PREC, bool SA16, bool SB16>
 __global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp) {
   __shared__ __attribute__((aligned(16))) float smem[Gemm32Cfg::smem<true, true>()];
   const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
@@ -422,5 +561,5 @@ __global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp) {
   const int bx = local % grp.gx[i], t = local / grp.gx[i], by = t % grp.gy[i], bz = t / grp.gy[i];
   const int kbeg = bz * g.k_chunk;
   const int kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
-  gemm32_body<true, true, EPI_ATOMIC, PREC>(g, by * 128, bx * 128, kbeg, (kend - kbeg) / 32, g.dbias != nullptr && bx == 0, smem);
+  gemm32_body<true, true, EPI_ATOMIC, PREC, SA16, SB16>(g, by * 128, bx * 128, kbeg, (kend - kbeg) / 32, g.dbias != nullptr && bx == 0, smem);
 }

@@ -15,7 +15,8 @@
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float* __restrict__ res, DropArgs drop,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* y,
                                                      float* __restrict__ xhat, float* __restrict__ rstd_out, int M, int N,
-                                                     int ldx, int ldres, int ldy) {
+                                                     int ldx, int ldres, int ldy, uint16_t* __restrict__ y16 = nullptr) {
+  // y16: a bf16 copy of y (dense rows of N), for the GEMM that takes y as its operand at precision = 1 (GemmArgs::A16)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* const zp = gt_zero_ptr();
@@ -49,7 +50,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
     if (c < N) {
       const float xh = (z[i] - mean) * rstd;
       xhat[(size_t)row * N + c] = xh;
-      y[(size_t)row * ldy + c] = xh * ga[i] + be[i];
+      const float yv = xh * ga[i] + be[i];
+      y[(size_t)row * ldy + c] = yv;
+      if (y16 != nullptr) y16[(size_t)row * N + c] = gt_f2bf(yv);
     }
   }
   if (lane == 0) rstd_out[row] = rstd;
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      float* dz, float* __restrict__ dz_masked, DropArgs drop,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part,
-                                                     int M, int N, int rows_per_wave) {
+                                                     int M, int N, int rows_per_wave, uint16_t* __restrict__ dzm16 = nullptr) {
   __shared__ float sred[4][2][GT_MAX_D];
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
@@ -99,7 +102,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
         const size_t e = (size_t)row * N + c;
         const float v = rs * (d[i] * ga[i] - m1 - xh[i] * m2);
         dz[e] = v;
-        if (dz_masked) dz_masked[e] = v * gt_drop_mul(drop, dkey, (uint32_t)e);
+        const float vm = dz_masked ? v * gt_drop_mul(drop, dkey, (uint32_t)e) : v;
+        if (dz_masked) dz_masked[e] = vm;
+        if (dzm16) dzm16[e] = gt_f2bf(vm);
       }
     }
   }
@@ -132,7 +137,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* dy, const float* __restrict__ res, const float* __restrict__ xhat,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                         float* dz, float* __restrict__ dz_masked, DropArgs drop,
-                                                        float* __restrict__ part, int M, int rows_per_wave) {
+                                                        float* __restrict__ part, int M, int rows_per_wave, uint16_t* __restrict__ dzm16 = nullptr) {
+  // dzm16: a bf16 copy of the tensor the next dgrad / weight gradient takes as its operand (dz_masked, or dz when there is no mask)
   constexpr int N = 256 * NV;
   __shared__ float sred[4][2][N];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -178,11 +184,17 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* dy, const f
       v.x = rs * (d[i].x * ga[i].x - m1 - xh[i].x * m2); v.y = rs * (d[i].y * ga[i].y - m1 - xh[i].y * m2);
       v.z = rs * (d[i].z * ga[i].z - m1 - xh[i].z * m2); v.w = rs * (d[i].w * ga[i].w - m1 - xh[i].w * m2);
       *reinterpret_cast<float4*>(dz + base + 256 * i) = v;
+      float4 vm = v;
       if (dz_masked) {
         const uint32_t e = (uint32_t)(base + 256 * i);
-        *reinterpret_cast<float4*>(dz_masked + base + 256 * i) =
-            make_float4(v.x * gt_drop_mul(drop, dkey, e), v.y * gt_drop_mul(drop, dkey, e + 1), v.z * gt_drop_mul(drop, dkey, e + 2),
-                        v.w * gt_drop_mul(drop, dkey, e + 3));
+        vm = make_float4(v.x * gt_drop_mul(drop, dkey, e), v.y * gt_drop_mul(drop, dkey, e + 1), v.z * gt_drop_mul(drop, dkey, e + 2),
+                         v.w * gt_drop_mul(drop, dkey, e + 3));
+        *reinterpret_cast<float4*>(dz_masked + base + 256 * i) = vm;
+      }
+      if (dzm16 != nullptr) {
+        uint2 pk;
+        pk.x = (uint32_t)gt_f2bf(vm.x) | ((uint32_t)gt_f2bf(vm.y) << 16); pk.y = (uint32_t)gt_f2bf(vm.z) | ((uint32_t)gt_f2bf(vm.w) << 16);
+        *reinterpret_cast<uint2*>(dzm16 + base + 256 * i) = pk;
       }
     }
   }
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const float* dy, const flo
                                                       const float* __restrict__ xhat1, const float* __restrict__ rstd1,
                                                       const float* __restrict__ gamma1, float* __restrict__ part1,
                                                       float* dz, float* __restrict__ dz_masked, DropArgs drop, int M, int N,
-                                                      int rows_per_wave) {
+                                                      int rows_per_wave, uint16_t* __restrict__ dzm16 = nullptr) {
   __shared__ float sred[4][2][GT_MAX_D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row0 = (blockIdx.x * 4 + w) * rows_per_wave;
@@ -313,7 +325,9 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const float* dy, const flo
         const size_t e = (size_t)row * N + c;
         const float v = rs * (d[i] * gB[i] - m1 - xb[i] * m2);
         dz[e] = v;
-        if (dz_masked) dz_masked[e] = v * gt_drop_mul(drop, dkey, (uint32_t)e);
+        const float vm = dz_masked ? v * gt_drop_mul(drop, dkey, (uint32_t)e) : v;
+        if (dz_masked) dz_masked[e] = vm;
+        if (dzm16) dzm16[e] = gt_f2bf(vm);
       }
     }
   }
@@ -612,4 +626,44 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restri
   src = src < 0 ? 0 : (src >= n_seq ? n_seq - 1 : src);        // a bad index must not read outside the dataset
   if (r < qx) reinterpret_cast<float4*>(x)[(size_t)b * qx + r] = reinterpret_cast<const float4*>(xs)[(size_t)src * qx + r];
   else        reinterpret_cast<float4*>(y)[(size_t)b * qy + (r - qx)] = reinterpret_cast<const float4*>(ys)[(size_t)src * qy + (r - qx)];
+}
+
+// ---- bf16 shadows of the encoder layers' weight matrices (gt_config.precision = 1, GemmArgs::B16): for each of the four matrices W
+// (R x C) of every layer, W16 = bf16(W) in place order and W16T = bf16(W^T) -- the copy that turns a dgrad (dX = dY W) into the forward's
+// NT form.  One workgroup per 32 x 32 tile, transposed through LDS; both outputs leave as 64-byte row segments.  Runs at the head of
+// every forward (the optimizer has just rewritten the weights): 2 x 19 MB at d_model 512 / 6 layers, ~10 us.
+struct WShadowArgs {
+  const float* prm; uint16_t* w16; uint16_t* w16t;
+  int64_t in_w, out_w, w1, w2, pstride, sstride;       // layer 0's parameter offsets, floats per layer, bf16 elements per layer of a shadow
+  int d, F, L;
+};
+__global__ __launch_bounds__(256) void weight_shadow_kernel(WShadowArgs a) {
+  __shared__ float t[32][33];
+  const int d = a.d, F = a.F, d32 = d >> 5, f32 = F >> 5;
+  const int n0 = 3 * d32 * d32, n1 = d32 * d32, n2 = f32 * d32, T = n0 + n1 + 2 * n2;
+  const int l = blockIdx.x / T;
+  int f = blockIdx.x % T, R, C;
+  int64_t src, so;
+  if (f < n0) { src = a.in_w; R = 3 * d; C = d; so = 0; }
+  else if (f < n0 + n1) { f -= n0; src = a.out_w; R = d; C = d; so = (int64_t)3 * d * d; }
+  else if (f < n0 + n1 + n2) { f -= n0 + n1; src = a.w1; R = F; C = d; so = (int64_t)4 * d * d; }
+  else { f -= n0 + n1 + n2; src = a.w2; R = d; C = F; so = (int64_t)4 * d * d + (int64_t)d * F; }
+  const int tc = C >> 5, tr = f / tc, tcx = f % tc;
+  const float* W = a.prm + src + (int64_t)l * a.pstride;
+  uint16_t* o = a.w16 + (int64_t)l * a.sstride + so;
+  uint16_t* ot = a.w16t + (int64_t)l * a.sstride + so;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = ty + 8 * k;
+    const float v = W[(size_t)(32 * tr + r) * C + 32 * tcx + tx];
+    t[r][tx] = v;
+    o[(size_t)(32 * tr + r) * C + 32 * tcx + tx] = gt_f2bf(v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = ty + 8 * k;                                  // row of W^T = column of W
+    ot[(size_t)(32 * tcx + c) * R + 32 * tr + tx] = gt_f2bf(t[tx][c]);
+  }
 }

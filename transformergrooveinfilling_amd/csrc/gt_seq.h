@@ -113,12 +113,8 @@ __device__ __forceinline__ float seq_row16_sum(float v) {
 #define GT_XCHG_SPIN_MAX (1 << 22)
 #endif
 #ifdef GT_EMU
-static inline uint32_t gt_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-static inline float gt_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 #define GT_XTAG_NOW (GT_XTAG + emu::launch_serial)     /* (the emulator re-runs a waiting workgroup: a per-launch tag instead of the reset) */
 #else
-__device__ __forceinline__ uint32_t gt_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
-__device__ __forceinline__ float gt_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 #define GT_XTAG_NOW GT_XTAG
 #endif
 __device__ __forceinline__ void seq_xchg_put(unsigned long long* slot, const f32x4& v, const int tid) {
