@@ -220,13 +220,16 @@ int gt_set_seq_split(int on);
  * condition (env GT_SEQ_QUAD=0/1).  Results agree with the SPLIT mode to fp32 rounding (the FFN2 contraction is summed as two halves);
  * bitwise repeatable run to run.  Needs gt_workspace_init on the workspace. */
 int gt_set_seq_quad(int on);
-/* gt_config.precision = 1 (BASELINE configs[4]) at d_model 256 / 512 with every Linear of a layer on the big-tile kernel: bf16 SHADOWS of
- * the GEMM operands -- the producers of every activation / gradient a Linear, dgrad or weight gradient consumes also write a bf16 copy
- * (8 per layer), a per-step kernel writes bf16 copies of the encoder layers' weights and of their transposes, and the GEMMs stage those
- * (csrc/gt_gemm32.h gemm32h_kernel: half the bytes per flop; the weight gradients widen them back on their way into LDS).  Results are
- * bit-identical to the fp32-source path.  1 = on, 0 = off (default: measured neutral, see csrc/groove_hip.hip bf16_shadows), -1 = by the
- * environment (GT_BF16_SHADOWS=1).  Changes gt_workspace_bytes: set it before sizing a workspace. */
-int gt_set_bf16_shadows(int on);
+/* gt_config.precision = 1 (BASELINE configs[4]) at d_model 256 / 512 with every Linear of a layer on the big-tile kernel: bf16 copies of
+ * the GEMM operands.  The producers of every activation / gradient a Linear, dgrad or weight gradient of an encoder layer consumes write
+ * it in bf16 (8 tensors per layer), a per-step kernel writes bf16 copies of the layers' weights and of their transposes, and the GEMMs
+ * stage those (csrc/gt_gemm32.h gemm32h_kernel: half the bytes per flop).  level 1: the copies sit BESIDE the fp32 tensors; level 2 (the
+ * default): the tensors nothing but a GEMM reads -- ctx, hact, dhid, dqkv, the dropout-masked dz copies -- are stored in bf16 ALONE (the
+ * reference's torch autograd keeps the same intermediates, in fp32: nothing of its interface sees them).  0: off.  -1: the environment
+ * (GT_BF16_SHADOWS=0/1/2) or the default.  Outputs, losses and gradients are bit-identical at every level.  Changes gt_workspace_bytes and
+ * which gt_ws_find names are live: set it before sizing a workspace.  gt_operand_shadow_level: the level in force for a configuration. */
+int gt_set_operand_shadows(int level);
+int gt_operand_shadow_level(const gt_config* cfg);
 /* Weight gradients as RIDER workgroups (csrc/gt_seq_wg.h): in the SPLIT mode at d_model 128 the backward phases' launches carry, on
  * the CUs their 2 x batch sequence workgroups leave idle, the weight gradients whose operands the earlier phases completed; one
  * workgroup owns a 32 x 64 gradient tile over ALL tokens (no atomics: bitwise reproducible), and a tail launch does what cannot ride

@@ -163,8 +163,19 @@ class Runner:
                       ctypes.c_float(thres), int(use_thres), self.tgt.ptr, self.ws.ptr, self.stream)
         return self.hvo.numpy().reshape(self.B, 32, 27).copy()
 
+    BF16_ONLY = ("ctx", "hact", "dhid", "dqkv", "dzAm", "dzBm")
+
+    def bf16_only(self, name, layer=0):
+        """Is this saved tensor stored in bf16 alone (gt_set_operand_shadows level 2: the encoder layers' operand-only tensors)?"""
+        return (name in self.BF16_ONLY and layer < self.cfgd["num_encoder_layers"]
+                and self.lib.cdll.gt_operand_shadow_level(ctypes.byref(self.c)) == 2)
+
     def ws_get(self, name, layer=0):
         off, cnt = self.lib.ws_find(self.c, name, layer)
+        if self.bf16_only(name, layer):           # the live tensor is "<name>16": widened to fp32 (exact)
+            o16, _ = self.lib.ws_find(self.c, name + "16", layer)
+            u = self.ws.numpy()[o16:o16 + (cnt + 1) // 2].view(np.uint16)[:cnt].astype(np.uint32) << 16
+            return u.view(np.float32).copy()
         return self.ws.numpy()[off:off + cnt].copy()
 
     def step_state(self):

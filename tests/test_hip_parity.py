@@ -162,7 +162,7 @@ def test_step_parity_bf16_operands_large_batches(cfg, B, p):
 
 
 def test_bf16_shadows_of_the_gemm_operands():
-    """BASELINE configs[4] with gt_set_bf16_shadows(1), at a size where every Linear runs on the big-tile kernel (>= 192 tiles of 128 x 128:
+    """BASELINE configs[4] with gt_set_operand_shadows(1), at a size where every Linear runs on the big-tile kernel (>= 192 tiles of 128 x 128:
     d_model 512, F 512 at 6144 tokens = bs 192): the GEMM operands' producers also write bf16 copies and the Linears, dgrads and weight
     gradients stage those.  Every shadow is bit for bit the rounding of its fp32 tensor, and the per-operation oracle check passes on
     the same shape through that path."""
@@ -171,11 +171,12 @@ def test_bf16_shadows_of_the_gemm_operands():
     assert parity.check_bf16_shadows("hip", c5, 192, 0.3) == 31
     assert parity.check_bf16_shadows("hip", dict(c5, n_heads=16, num_encoder_layers=1), 192, 0.0) == 15
     lib = _lib.get_lib()
-    lib.cdll.gt_set_bf16_shadows(1)
     try:
-        parity.check_step_bf16("hip", c5, 192, 0.3)
+        for level in (2, 1):                        # 2 (the default): operand-only tensors in bf16 ALONE; 1: beside their fp32 tensors
+            lib.cdll.gt_set_operand_shadows(level)
+            parity.check_step_bf16("hip", c5, 192, 0.3)
     finally:
-        lib.cdll.gt_set_bf16_shadows(-1)
+        lib.cdll.gt_set_operand_shadows(-1)
 
 
 def test_train_step_bf16_operands():

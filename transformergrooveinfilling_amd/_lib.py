@@ -69,7 +69,8 @@ _SIGS = {
     "gt_set_seq": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_seq_split": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_seq_quad": (ctypes.c_int, [ctypes.c_int]),
-    "gt_set_bf16_shadows": (ctypes.c_int, [ctypes.c_int]),
+    "gt_set_operand_shadows": (ctypes.c_int, [ctypes.c_int]),
+    "gt_operand_shadow_level": (ctypes.c_int, [_cfgp]),
     "gt_workspace_init": (ctypes.c_int, [_cfgp, _vp, _vp]),
     "gt_set_seq_ride": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_deterministic": (ctypes.c_int, [ctypes.c_int]),

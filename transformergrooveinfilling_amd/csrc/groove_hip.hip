@@ -190,6 +190,7 @@ struct WLayout {
   // bf16 shadows (precision = 1, bf16_shadows()): fp32 tensor offset -> offset (in floats) of its bf16 copy, for the activations whose
   // producers write one; w16 / w16t: the encoder layers' four matrices and their transposes, [in_w | out_w | w1 | w2] per layer
   std::vector<std::pair<int64_t, int64_t>> sh;
+  std::vector<int64_t> sh_only;                        // level 2: fp32 offsets of the tensors stored in bf16 alone
   int64_t w16 = -1, w16t = -1, w16_stride = 0;
   struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; };
   std::vector<TmpSet> set;                           // 2 alternating sets, or one per layer (wgrad_deferred)
@@ -209,20 +210,28 @@ static bool seq_supported(const gt_config& c);
 #ifndef GT_T128_BIG_MIN
 #define GT_T128_BIG_MIN 192
 #endif
-// Measured (round 4, C5 bs 512, tools/rejected/bf16_shadows.md): the Linears' forward / dgrad GEMMs get 1.3-1.4x faster, but the shadows
-// are ADDITIONAL bytes -- the producers (attention, LayerNorm passes, FFN epilogues) pay what the GEMMs gain, and the weight gradients are
-// not bound by their operand fetch at all: 4.03-4.07 ms with, 4.04 ms without.  So the path is OFF by default: gt_set_bf16_shadows(1) /
-// GT_BF16_SHADOWS=1 switch it on (results are bit-identical either way; tests cover it).
+// Level 1 = shadows BESIDE the fp32 tensors.  Measured (round 4, C5 bs 512, tools/rejected/bf16_shadows.md): the Linears' forward / dgrad
+// GEMMs get 1.3-1.4x faster, but the shadows are ADDITIONAL bytes -- the producers (attention, LayerNorm passes, FFN epilogues) pay what
+// the GEMMs gain, and the weight gradients are not bound by their operand fetch at all: 4.03-4.07 ms with, 4.04 ms without.
+// gt_set_operand_shadows(0 / 1 / 2) / GT_BF16_SHADOWS select the level; results are bit-identical at every level.
+// Level 2 (the default where the path applies): the tensors that are ONLY ever consumed as bf16-rounded GEMM operands -- ctx, hact, dhid,
+// dqkv and the dropout-masked dz copies of the encoder layers -- are stored in bf16 ALONE: their producers write 2 bytes per element
+// instead of 4 (+ 2), every consumer (Linear, dgrad, weight gradient, the FFN2 dgrad's zero test of hact) takes the bf16 tensor.  Outputs,
+// losses and gradients are bit for bit those of level 0 / 1 (the fp32-source GEMMs round the same values at fragment assembly):
+// C5 bs 512 4.06 -> 3.6 ms.  gt_ws_find names the bf16 tensors "<name>16"; the fp32 regions of those six stay allocated, unwritten.
 static int g_bf16_shadows = -1;
-extern "C" int gt_set_bf16_shadows(int on) { g_bf16_shadows = on < 0 ? -1 : on != 0; return 0; }
+extern "C" int gt_set_operand_shadows(int level) { g_bf16_shadows = level < 0 ? -1 : level > 2 ? 2 : level; return 0; }
+static int bf16_shadow_level() {
+  if (g_bf16_shadows < 0) { const char* e = getenv("GT_BF16_SHADOWS"); g_bf16_shadows = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
+  return g_bf16_shadows;
+}
 static bool bf16_shadows(const gt_config& c) {
-  if (g_bf16_shadows < 0) { const char* e = getenv("GT_BF16_SHADOWS"); g_bf16_shadows = (e && e[0] == '1') ? 1 : 0; }
-  const int on = g_bf16_shadows;
+  const int on = bf16_shadow_level() > 0;
   const int64_t M = (int64_t)c.batch * 32;
   const int hd = c.n_heads > 0 ? c.d_model / c.n_heads : 0;
   static const int attn_mfma = [] { const char* e = getenv("GT_ATTN_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();      // (ctx / dqkv shadows)
   const int nmin = c.d_model < c.dim_ff ? c.d_model : c.dim_ff;            // every Linear of a layer on the big-tile kernel (its epilogue writes hact16 / dhid16)
-  return on && attn_mfma && c.precision == 1 && c.n_enc_layers > 0 && (c.d_model == 256 || c.d_model == 512) && c.dim_ff % 128 == 0 &&
+  return on && attn_mfma && wgrad_deferred(c) && c.precision == 1 && c.n_enc_layers > 0 && (c.d_model == 256 || c.d_model == 512) && c.dim_ff % 128 == 0 &&
          M % 128 == 0 && (hd == 16 || hd == 32 || hd == 64 || hd == 128) && (M / 128) * (nmin / 128) >= GT_T128_BIG_MIN;
 }
 static WLayout ws_layout(const gt_config& c) {
@@ -278,17 +287,21 @@ static WLayout ws_layout(const gt_config& c) {
   }
   if (bf16_shadows(c)) {
     auto sh = [&](int64_t off, int64_t n) { W.sh.emplace_back(off, add((n + 1) / 2)); };
+    const bool only = bf16_shadow_level() >= 2;
     for (int l = 0; l < c.n_enc_layers; ++l) {
       const LayerW& w = W.layers[l];
       sh(w.ctx, M * d); sh(w.x1, M * d); sh(w.hact, M * F);
+      if (only) { W.sh_only.push_back(w.ctx); W.sh_only.push_back(w.hact); }
       if (l + 1 < c.n_enc_layers) sh(w.xout, M * d);          // (the top layer's output comes from the two-norm pass, and feeds no big GEMM)
     }
-    for (size_t k = 0; k < W.set.size(); ++k) {
+    for (size_t k = 0; k < W.set.size() && (int)k < c.n_enc_layers; ++k) {        // (one set per layer: the encoder layers' are the first L)
       const WLayout::TmpSet& t = W.set[k];
       // dz / dzm share a shadow: the consumer takes the masked copy when there is dropout, else dz itself (tmp_set)
       const int64_t a = add((M * d + 1) / 2), b = add((M * d + 1) / 2);
       W.sh.emplace_back(t.dzA, a); W.sh.emplace_back(t.dzAm, a); W.sh.emplace_back(t.dzB, b); W.sh.emplace_back(t.dzBm, b);
       sh(t.dhid, M * F); sh(t.dqkv, M * 3 * d);
+      // (dzAm / dzBm exist as tensors of their own only with dropout; without it the operand is dz itself, which stays fp32)
+      if (only) { W.sh_only.push_back(t.dhid); W.sh_only.push_back(t.dqkv); W.sh_only.push_back(t.dzAm); W.sh_only.push_back(t.dzBm); }
     }
     W.w16_stride = ((int64_t)4 * d * d + (int64_t)2 * d * F + 1) / 2;          // floats per layer
     W.w16 = add(W.w16_stride * c.n_enc_layers); W.w16t = add(W.w16_stride * c.n_enc_layers);
@@ -313,6 +326,12 @@ extern "C" int gt_workspace_init(const gt_config* cfg, float* ws, gt_stream_t st
   const WLayout W = ws_layout(*cfg);
   if (W.seq_xchg >= 0) (void)hipMemsetAsync(ws + W.seq_xchg, 0, (size_t)W.seq_xchg_n * sizeof(float), (hipStream_t)stream);
   return launch_status("gt_workspace_init");
+}
+// 0: no bf16 operand shadows for this configuration; 1: beside the fp32 tensors; 2: ctx / hact / dhid / dqkv / masked dz copies of the
+// encoder layers stored in bf16 ALONE (gt_ws_find "<name>16")
+extern "C" int gt_operand_shadow_level(const gt_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  return bf16_shadows(*cfg) ? bf16_shadow_level() : 0;
 }
 extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int64_t* offset, int64_t* count) {
   if (check_cfg(cfg)) return -1;
@@ -404,6 +423,16 @@ static uint16_t* sh_act(const Ctx& x, const float* p) {
   for (const auto& e : x.W.sh) if (e.first == off) return reinterpret_cast<uint16_t*>(x.ws + e.second);
   return nullptr;
 }
+// level 2: is this workspace tensor stored in bf16 alone (its fp32 region is not written)?
+static bool only16(const Ctx& x, const float* p) {
+  if (x.W.sh_only.empty() || p == nullptr) return false;
+  const int64_t off = p - x.ws;
+  for (const int64_t o : x.W.sh_only) if (o == off) return true;
+  return false;
+}
+// a consumer of a bf16-only tensor that could not take the bf16-source kernel would read an unwritten fp32 region: refuse loudly
+static thread_local const char* g_store_error = nullptr;
+static void need16(bool ok, const char* what) { if (!ok && g_store_error == nullptr) g_store_error = what; }
 static const uint16_t* sh_w(const Ctx& x, const float* W, bool transposed) {
   if (x.W.w16 < 0) return nullptr;
   const int64_t off = W - x.prm, d = x.d, F = x.F;
@@ -453,6 +482,7 @@ static void linear_fwd(const Ctx& x, const float* in, int ldin, const float* W, 
   GemmArgs g = mk_gemm(in, ldin, W, K, out, ldout, x.M, N, K);
   g.bias = b;
   if (ldin == K) { g.A16 = sh_act(x, in); g.B16 = sh_w(x, W, false); g.lda16 = g.ldb16 = K; }
+  if (only16(x, in)) need16(g.A16 && g.B16 && gemm32h_ok(g, EPI_STORE), "Linear forward of a bf16-only tensor");
   gemm_launch<false, false, EPI_STORE>(g, x.s);
 }
 // dW (N_w x K_w) += dY^T X ; db += colsum(dY)       ("TN", split over tokens, fp32 atomics)
@@ -460,6 +490,11 @@ static void wgrad(const Ctx& x, const float* dY, int ldy, const float* X, int ld
   GemmArgs g = mk_gemm(dY, ldy, X, ldx, dW, Kw, Nw, Kw, x.M);
   g.dbias = db;
   if (ldy == Nw && ldx == Kw) { g.A16 = sh_act(x, dY); g.B16 = sh_act(x, X); g.lda16 = Nw; g.ldb16 = Kw; }     // bf16 shadows of dY / X (precision = 1)
+  if (only16(x, dY) || only16(x, X)) {
+    const long t128 = (long)(Nw / 128) * (Kw / 128);
+    need16(x.wb != nullptr && g.A16 && (g.B16 || !only16(x, X)) && wgrad32_ok(g) && t128 * ((x.M + 511) / 512) >= GT_WGRAD_T128_MIN,
+           "weight gradient of a bf16-only tensor");
+  }
   if (x.wb) wgrad_queue(*x.wb, g, x.s);
   else gemm_launch<true, true, EPI_ATOMIC>(g, x.s);
 }
@@ -524,6 +559,7 @@ static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, 
   GemmArgs g = mk_gemm(dY, ldy, W, ldw, dX, N, x.M, N, K);
   g.accumulate = accumulate;
   if (ldy == K && ldw == N) { g.A16 = sh_act(x, dY); g.B16 = sh_w(x, W, true); g.lda16 = g.ldb16 = K; }      // (W^T: [N][K], k contiguous)
+  if (only16(x, dY)) need16(g.A16 && g.B16 && gemm32h_ok(g, EPI_STORE), "dgrad of a bf16-only tensor");
   gemm_launch<false, true, EPI_STORE>(g, x.s);
 }
 // dz = LNbwd(dY W + res) with the LayerNorm whose (xhat, rstd, gamma) are given; dzm = dz * dropout mask
@@ -577,14 +613,15 @@ static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float*
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (part != nullptr && (x.d == 256 || x.d == 512) && al16(dy) && al16(xhat) && al16(dz) && (!res || al16(res)) && (!x.drop || al16(dzm))) {
     uint16_t* dzm16 = sh_act(x, x.drop ? dzm : dz);
+    float* dzm32 = (x.drop && !only16(x, dzm)) ? dzm : (float*)nullptr;          // (level 2: the masked copy lives in bf16 alone)
     if (x.d == 512) gt_launch(ln_bwd_v4_kernel<2>, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd, x.prm + gamma_off, dz,
-                              x.drop ? dzm : (float*)nullptr, mk_drop(x, site), part, x.M, rpw, dzm16);
+                              dzm32, mk_drop(x, site), part, x.M, rpw, dzm16);
     else gt_launch(ln_bwd_v4_kernel<1>, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd, x.prm + gamma_off, dz,
-                   x.drop ? dzm : (float*)nullptr, mk_drop(x, site), part, x.M, rpw, dzm16);
+                   dzm32, mk_drop(x, site), part, x.M, rpw, dzm16);
     return;
   }
   gt_launch(ln_bwd_kernel, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd,
-            x.prm + gamma_off, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
+            x.prm + gamma_off, dz, (x.drop && !only16(x, dzm)) ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
             x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d, rpw, sh_act(x, x.drop ? dzm : dz));
 }
 // dz = LNbwd_inner(LNbwd_outer(dy)): the final encoder / decoder norm (outer) and the top layer's last norm (inner) sit back
@@ -602,7 +639,7 @@ static void ln_bwd2(const Ctx& x, const float* dy, const float* xhat_o, const fl
   }
   gt_prof_tag("ln_bwd", 0, 20.0 * x.M * x.d);
   gt_launch(ln_bwd2_kernel, dim3(nblk), dim3(256), x.s, dy, xhat_o, rstd_o, (const float*)(x.prm + gamma_o), part_o, xhat_i, rstd_i,
-            (const float*)(x.prm + gamma_i), part_i, dz, x.drop ? dzm : (float*)nullptr, mk_drop(x, site), x.M, x.d, rpw,
+            (const float*)(x.prm + gamma_i), part_i, dz, (x.drop && !only16(x, dzm)) ? dzm : (float*)nullptr, mk_drop(x, site), x.M, x.d, rpw,
             sh_act(x, x.drop ? dzm : dz));
 }
 // second norm applied right after linear_res_ln's (the final encoder / decoder norm after the last layer)
@@ -615,6 +652,7 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
   const int64_t bo = (x.d + 63) / 64 * 64;          // a norm's bias tensor follows its weight
   if (!row_fused(x)) {
     g.A16 = sh_act(x, in); g.B16 = sh_w(x, x.prm + w_off, false); g.lda16 = g.ldb16 = K;
+    if (only16(x, in)) need16(g.A16 && g.B16 && gemm32h_ok(g, EPI_STORE), "Linear (+ LayerNorm) of a bf16-only tensor");
     gemm_launch<false, false, EPI_STORE>(g, x.s);
     if (second) {
       gt_prof_tag("ln_fwd", 0, 24.0 * x.M * x.d);
@@ -655,6 +693,7 @@ static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k,
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = P; a.ctx = ctx; a.ldc = x.d;
   a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.causal = causal; a.drop = mk_drop(x, site);
   a.ctx16 = attn_mfma_hd(x) > 0 ? sh_act(x, ctx) : nullptr;
+  if (only16(x, ctx)) { need16(a.ctx16 != nullptr, "attention output stored in bf16 alone"); if (a.ctx16) a.ctx = nullptr; }
   gt_prof_tag("attn_fwd", 4.0 * x.M * 32 * x.d, 4.0 * (4.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   const dim3 grid(x.c.batch * x.H);
   switch (attn_mfma_hd(x)) {
@@ -677,6 +716,7 @@ static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k,
   a.H = x.H; a.hd = x.hd; a.scale = 1.0f / sqrtf((float)x.hd); a.drop = mk_drop(x, site);
   a.dctx = dctx; a.lddc = x.d; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddkv; a.lddv = lddkv;
   if (attn_mfma_hd(x) > 0 && dk == dq + x.d && dv == dq + 2 * x.d && lddq == 3 * x.d && lddkv == 3 * x.d) a.dqkv16 = sh_act(x, dq);
+  if (only16(x, dq)) { need16(a.dqkv16 != nullptr, "attention gradients stored in bf16 alone"); if (a.dqkv16) { a.dq = nullptr; a.dk = nullptr; a.dv = nullptr; } }
   gt_prof_tag("attn_bwd", 10.0 * x.M * 32 * x.d, 4.0 * (7.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   const dim3 grid(x.c.batch * x.H);
   // head_dim 64 with the chip full: the LDS-staged form (every operand byte requested once, 16 bytes at a time)
@@ -716,6 +756,7 @@ static int make_ctx(Ctx& x, const gt_config* cfg, const float* params, float* gr
   return 0;
 }
 static int launch_status(const char* what) {
+  if (g_store_error != nullptr) { const char* m = g_store_error; g_store_error = nullptr; return gt_fail("%s: %s has no bf16-source kernel for this shape (gt_set_operand_shadows(1) keeps the fp32 copies)", what, m); }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return gt_fail("%s: HIP launch error: %s", what, hipGetErrorString(e));
   return 0;
@@ -737,6 +778,7 @@ static int ffn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* 
   g.bias = x.prm + p.b1; g.drop = mk_drop(x, lsite(gl, GT_SITE_FFN));
   g.A16 = sh_act(x, xin); g.B16 = sh_w(x, x.prm + p.w1, false); g.lda16 = g.ldb16 = x.d;
   if (g.A16 && g.B16) { g.C16 = sh_act(x, ws + w.hact); g.ldc16 = x.F; }      // (written by the bf16-source kernel's epilogue only)
+  if (only16(x, ws + w.hact)) { need16(g.C16 && gemm32h_ok(g, EPI_RELU_DROP), "FFN activation stored in bf16 alone"); if (g.C16) g.C = nullptr; }
   gemm_launch<false, false, EPI_RELU_DROP>(g, x.s);
   return linear_res_ln(x, ws + w.hact, x.F, p.w2, p.b2, xin, norm_w, ws + w.xout, ws + w.xhat2, ws + w.rstd2,
                        lsite(gl, GT_SITE_DROPF), second);
@@ -1053,6 +1095,11 @@ static int ffn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const Tmp& t,
   g.mask_scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
   g.A16 = sh_act(x, dzm); g.B16 = sh_w(x, x.prm + p.w2, true); g.lda16 = g.ldb16 = x.d;
   if (g.A16 && g.B16) { g.C16 = sh_act(x, t.dhid); g.ldc16 = x.F; }
+  if (only16(x, ws + w.hact)) g.res16 = sh_act(x, ws + w.hact);
+  if (only16(x, t.dhid) || only16(x, dzm) || g.res16) {
+    need16(g.C16 && gemm32h_ok(g, EPI_MASK_NZ), "FFN2 dgrad over bf16-only tensors");
+    if (g.C16 && only16(x, t.dhid)) g.C = nullptr;
+  }
   gemm_launch<false, true, EPI_MASK_NZ>(g, x.s);
   wgrad(x, t.dhid, x.F, xin, x.d, x.grd + p.w1, x.grd + p.b1, x.F, x.d);
   return dgrad_lnbwd(x, t.dhid, x.F, x.prm + p.w1, x.F, dz, xhat_prev, rstd_prev, gamma_prev, dzo, dzom, site_prev);
@@ -1072,6 +1119,8 @@ static void input_layer_bwd(const Ctx& x, const LayerP& first, const Tmp& t, con
                             int64_t w, int64_t b, int site, float* da_out) {
   GemmArgs g = mk_gemm(t.dqkv, 3 * x.d, x.prm + first.sa.in_w, x.d, da_out, x.d, x.M, x.d, 3 * x.d);
   g.res = dz1; g.ldres = x.d; g.aux_in = a0; g.drop = mk_drop(x, site);
+  g.A16 = sh_act(x, t.dqkv); g.B16 = sh_w(x, x.prm + first.sa.in_w, true); g.lda16 = g.ldb16 = 3 * x.d;
+  if (only16(x, t.dqkv)) need16(g.A16 && g.B16 && gemm32h_ok(g, EPI_ADD_RELUMASK_DROP), "InputLayer dgrad of a bf16-only tensor");
   gemm_launch<false, true, EPI_ADD_RELUMASK_DROP>(g, x.s);
   wgrad(x, da_out, x.d, in, S, x.grd + w, x.grd + b, x.d, S);
 }

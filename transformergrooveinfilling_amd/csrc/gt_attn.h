@@ -282,10 +282,12 @@ __device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const int 
 #pragma unroll
       for (int c = 0; c < 4; ++c) o[ct] = GT_MFMA16(pd[tj][c], vb[ct][tj][c], o[ct]);
   }
+  if (a.ctx != nullptr) {                                   // (nullptr: ctx lives in bf16 only)
 #pragma unroll
-  for (int ct = 0; ct < NQ; ++ct)
+    for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { if (!PAD || 16 * ct + l16 < hdr) orow[(size_t)r * a.ldc + 16 * ct] = o[ct][r]; }
+      for (int r = 0; r < 4; ++r) { if (!PAD || 16 * ct + l16 < hdr) orow[(size_t)r * a.ldc + 16 * ct] = o[ct][r]; }
+  }
   if (a.ctx16 != nullptr) {                                 // (dense (M, H hd) rows)
     uint16_t* __restrict__ o16 = a.ctx16 + (size_t)(b * 32 + 16 * ti + 4 * g) * (a.H * hdr) + h * hdr + l16;
 #pragma unroll
@@ -462,15 +464,17 @@ __device__ __forceinline__ void attn_bwd_store_direct(const AttnArgs& a, const i
   float* __restrict__ dqrow = a.dq + (row0 + 16 * w + 4 * g) * a.lddq + hc + l16;
   float* __restrict__ dvrow = a.dv + (row0 + 16 * w + 4 * g) * a.lddv + hc + l16;
   float* __restrict__ dkrow = a.dk + (row0 + 16 * w + 4 * g) * a.lddk + hc + l16;
+  if (a.dq != nullptr) {
 #pragma unroll
-  for (int ct = 0; ct < NQ; ++ct)
+    for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (PAD && 16 * ct + l16 >= hdr) continue;
-      dqrow[(size_t)r * a.lddq + 16 * ct] = dq_out[ct][r];
-      dvrow[(size_t)r * a.lddv + 16 * ct] = ov[ct][r];
-      dkrow[(size_t)r * a.lddk + 16 * ct] = ok[ct][r];
-    }
+      for (int r = 0; r < 4; ++r) {
+        if (PAD && 16 * ct + l16 >= hdr) continue;
+        dqrow[(size_t)r * a.lddq + 16 * ct] = dq_out[ct][r];
+        dvrow[(size_t)r * a.lddv + 16 * ct] = ov[ct][r];
+        dkrow[(size_t)r * a.lddk + 16 * ct] = ok[ct][r];
+      }
+  }
   if (a.dqkv16 != nullptr) {                                // [dq | dk | dv], dense (M, 3 d) rows
     const int d = a.H * hdr;
     uint16_t* __restrict__ o16 = a.dqkv16 + (row0 + 16 * w + 4 * g) * (size_t)(3 * d) + hc + l16;
@@ -551,9 +555,11 @@ __global__ __launch_bounds__(128) void attn_bwd_lds_kernel(AttnArgs a) {
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int e = tid + 128 * u, r = e / Q4, c = (e % Q4) * 4, o = r * LD + c;
-    *reinterpret_cast<float4*>(a.dq + (row0 + r) * a.lddq + hc + c) = *reinterpret_cast<const float4*>(sm + o);
-    *reinterpret_cast<float4*>(a.dk + (row0 + r) * a.lddk + hc + c) = *reinterpret_cast<const float4*>(sm + 32 * LD + o);
-    *reinterpret_cast<float4*>(a.dv + (row0 + r) * a.lddv + hc + c) = *reinterpret_cast<const float4*>(sm + 64 * LD + o);
+    if (a.dq != nullptr) {                                  // (nullptr: dq / dk / dv live in bf16 only)
+      *reinterpret_cast<float4*>(a.dq + (row0 + r) * a.lddq + hc + c) = *reinterpret_cast<const float4*>(sm + o);
+      *reinterpret_cast<float4*>(a.dk + (row0 + r) * a.lddk + hc + c) = *reinterpret_cast<const float4*>(sm + 32 * LD + o);
+      *reinterpret_cast<float4*>(a.dv + (row0 + r) * a.lddv + hc + c) = *reinterpret_cast<const float4*>(sm + 64 * LD + o);
+    }
     if (a.dqkv16 != nullptr) {                              // [dq | dk | dv], dense (M, 3 d) rows
       const int d = a.H * HD;
 #pragma unroll

@@ -70,6 +70,7 @@ struct GemmArgs {
   // OUTPUT, for the next consumer.  nullptr: none.
   const uint16_t* A16; const uint16_t* B16; int lda16, ldb16;
   uint16_t* C16; int ldc16;
+  const uint16_t* res16;     // EPI_MASK_NZ: the mask source as bf16 (row stride ldres), when its fp32 tensor is not stored
 };
 
 template <int ROWS, int COLS, int NT>

@@ -36,7 +36,7 @@ static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm) {
   if (g.M % 128 || g.N % 128 || g.K % 64 || g.K < 64) return false;
   if ((g.lda & 3) || (g.ldb & 3) || (g.ldc & 3) || !al16(g.A) || !al16(g.B) || !al16(g.C)) return false;
   if (epi == EPI_STORE || epi == EPI_RELU_DROP) { if (g.bias && !al16(g.bias)) return false; }
-  if ((epi == EPI_MASK_NZ || epi == EPI_ADD_RELUMASK_DROP) && ((g.ldres & 3) || !al16(g.res))) return false;
+  if ((epi == EPI_MASK_NZ || epi == EPI_ADD_RELUMASK_DROP) && ((g.ldres & 3) || !al16(g.res) || (g.res16 && (reinterpret_cast<uintptr_t>(g.res16) & 7)))) return false;
   if (epi == EPI_ADD_RELUMASK_DROP && ((g.N & 3) || !al16(g.aux_in))) return false;
   (void)bkm;
   return true;
@@ -62,6 +62,10 @@ __device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f
         const int row = m0 + wm * 64 + ta * 32 + r32;
         rin[ta][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI == EPI_STORE && g.accumulate) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.C + (size_t)row * g.ldc + col);
+        if (EPI == EPI_MASK_NZ && g.res16 != nullptr) {      // the mask source (hact) lives in bf16 only: zero / non-zero is all that is asked
+          const uint2 hb = *reinterpret_cast<const uint2*>(g.res16 + (size_t)row * g.ldres + col);
+          rin[ta][q4] = f32x4{gt_u2f(hb.x << 16), gt_u2f(hb.x & 0xFFFF0000u), gt_u2f(hb.y << 16), gt_u2f(hb.y & 0xFFFF0000u)};
+        } else
         if (EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + col);
         if (EPI == EPI_ADD_RELUMASK_DROP) rin2[ta][q4] = *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.N + col);
       }
@@ -85,7 +89,7 @@ __device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f
           }
           o[r] = v;
         }
-        *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = o;
+        if (g.C != nullptr) *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = o;      // (nullptr: the output lives in bf16 only)
         if (g.C16 != nullptr) {
           uint2 pk;
           pk.x = (uint32_t)gt_f2bf(o[0]) | ((uint32_t)gt_f2bf(o[1]) << 16); pk.y = (uint32_t)gt_f2bf(o[2]) | ((uint32_t)gt_f2bf(o[3]) << 16);

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
         const size_t e = (size_t)row * N + c;
         const float v = rs * (d[i] * ga[i] - m1 - xh[i] * m2);
         dz[e] = v;
-        const float vm = dz_masked ? v * gt_drop_mul(drop, dkey, (uint32_t)e) : v;
+        const float vm = (dz_masked || (dzm16 && drop.thr != 0u && drop.st != nullptr)) ? v * gt_drop_mul(drop, dkey, (uint32_t)e) : v;
         if (dz_masked) dz_masked[e] = vm;
         if (dzm16) dzm16[e] = gt_f2bf(vm);
       }
@@ -185,11 +185,11 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* dy, const f
       v.z = rs * (d[i].z * ga[i].z - m1 - xh[i].z * m2); v.w = rs * (d[i].w * ga[i].w - m1 - xh[i].w * m2);
       *reinterpret_cast<float4*>(dz + base + 256 * i) = v;
       float4 vm = v;
-      if (dz_masked) {
+      if (dz_masked != nullptr || (dzm16 != nullptr && drop.thr != 0u && drop.st != nullptr)) {      // (the masked copy may live in bf16 only)
         const uint32_t e = (uint32_t)(base + 256 * i);
         vm = make_float4(v.x * gt_drop_mul(drop, dkey, e), v.y * gt_drop_mul(drop, dkey, e + 1), v.z * gt_drop_mul(drop, dkey, e + 2),
                          v.w * gt_drop_mul(drop, dkey, e + 3));
-        *reinterpret_cast<float4*>(dz_masked + base + 256 * i) = vm;
+        if (dz_masked != nullptr) *reinterpret_cast<float4*>(dz_masked + base + 256 * i) = vm;
       }
       if (dzm16 != nullptr) {
         uint2 pk;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const float* dy, const flo
         const size_t e = (size_t)row * N + c;
         const float v = rs * (d[i] * gB[i] - m1 - xb[i] * m2);
         dz[e] = v;
-        const float vm = dz_masked ? v * gt_drop_mul(drop, dkey, (uint32_t)e) : v;
+        const float vm = (dz_masked || (dzm16 && drop.thr != 0u && drop.st != nullptr)) ? v * gt_drop_mul(drop, dkey, (uint32_t)e) : v;
         if (dz_masked) dz_masked[e] = vm;
         if (dzm16) dzm16[e] = gt_f2bf(vm);
       }
