@@ -58,6 +58,10 @@ void block_sync();
 // after the others (its writes so far are repeated with the same values).  launch_serial: a per-launch number for the exchange tags.
 [[noreturn]] void block_retry();
 extern unsigned launch_serial;
+// ds_read_b64_tr_b16 (gfx950): per group of 16 consecutive lanes a 4-row x 16-column block of 16-bit elements, delivered column-major --
+// lane 4 q + p of the group supplies the address of row q, columns 4 p .. 4 p + 3; lane i receives column i, row q in its element q
+struct tr16x4 { uint16_t v[4]; };
+tr16x4 lds_tr16(const uint16_t* addr);
 void wave_rendezvous();     // all live lanes of the calling wave (hardware: lanes run in lock-step; the emulator: fibers do not)
 float wave_shfl(float v, int src_lane);
 f32x4 mfma16(float a, float b, f32x4 c);
@@ -207,6 +211,18 @@ float wave_shfl(float v, int src_lane) {
   scratchA[w][l] = v;
   wave_sync();
   float r = scratchA[w][src_lane];
+  wave_sync();
+  return r;
+}
+
+static const uint16_t* scratchP[16][64];
+tr16x4 lds_tr16(const uint16_t* addr) {
+  int w = cur / 64, l = cur % 64;
+  scratchP[w][l] = addr;
+  wave_sync();
+  const int g0 = l & ~15, i = l & 15;
+  tr16x4 r;
+  for (int q = 0; q < 4; ++q) r.v[q] = scratchP[w][g0 + 4 * q + (i >> 2)][i & 3];
   wave_sync();
   return r;
 }

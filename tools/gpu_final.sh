@@ -1,7 +1,7 @@
 # final measurements of a revision (run on the GPU box through gpurun): tools/gpu_final.sh TAG
 # (build first: csrc/build.sh, tools/build_variant.sh stamps groove_hip,groove_seq_fwd,groove_seq_bwd -DGT_SEQ_STAMPS, tools/ubench/gemm_bench)
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 O=gpurun_out/final_$TAG
 L=$PWD/transformergrooveinfilling_amd/lib
 mkdir -p $O
@@ -9,6 +9,9 @@ python tools/shape_bench.py --only 2 --steps 200 > /dev/null 2>&1     # (a fresh
 python tools/shape_bench.py --steps 200 2>/dev/null > $O/shapes.txt
 for i in 0 1 2 3; do GT_SEQ=0 python tools/shape_bench.py --only $i --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ=0 (one kernel per op) /' >> $O/shapes.txt; done
 GT_SEQ_SPLIT=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_SPLIT=0 (one workgroup per sequence) /' >> $O/shapes.txt
+GT_SEQ_QUAD=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_QUAD=0 (two workgroups per sequence in every phase: round 3) /' >> $O/shapes.txt
+GT_SEQ_QUAD_BWD0=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_QUAD_BWD0=0 (four workgroups per sequence in the forward only) /' >> $O/shapes.txt
+for l in 0 1 2; do GT_BF16_SHADOWS=$l python tools/shape_bench.py --only 11 --steps 30 --warmup 5 2>/dev/null | tail -1 | sed "s/^/GT_BF16_SHADOWS=$l /" >> $O/shapes.txt; done
 GT_SEQ_RIDE=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_RIDE=0 (grouped weight gradients at the end) /' >> $O/shapes.txt
 GT_PACK_FOLD=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_PACK_FOLD=0 (packing launch at the head of every step) /' >> $O/shapes.txt
 for b in 16 32 80 96 128 192; do python tools/shape_bench.py --only 2 --batch $b --steps 200 2>/dev/null | tail -1 >> $O/shapes.txt; done
@@ -16,6 +19,9 @@ python bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_style_1.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_style_2.json 2>/dev/null
 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp.json 2>/dev/null
+GT_DP_GRAPH=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_graph.json 2>/dev/null
+GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_overlap.json 2>/dev/null
+GT_DP_GRAPH=1 GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_overlap_graph.json 2>/dev/null
 for i in 0 1; do GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py $i > $O/seq_stamps_$i.txt 2>&1; done
 GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py 2 > $O/seq_stamps_c2.txt 2>&1
 python tools/wg_unit_bench.py 64 > $O/wg_unit_bench.txt 2>&1

@@ -821,11 +821,16 @@ struct WgradBatch {
 };
 static inline bool wgrad32_ok(const GemmArgs& g);
 template <int PREC, bool SA16, bool SB16> __global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp);
+__global__ __launch_bounds__(256, 2) void wgrad32t_group_kernel(GemmGroup grp);
+#ifndef GT_WGRAD32T
+#define GT_WGRAD32T 1           /* class 4 (both operands bf16) on the transposed-LDS-read kernel; 0: widened into the fp32 image */
+#endif
 static inline void wgrad_flush_one(WgradBatch& wb, int k, hipStream_t s) {
   GemmGroup& G = wb.grp[k];
   if (G.n == 0) return;
   gt_prof_tag("gemm_wgrad", wb.flops[k], wb.bytes[k]);
-  if (k == 4) gt_launch(wgrad32_group_kernel<1, true, true>, dim3(G.start[G.n]), dim3(256), s, G);
+  if (k == 4 && GT_WGRAD32T) gt_launch(wgrad32t_group_kernel, dim3(G.start[G.n]), dim3(256), s, G);
+  else if (k == 4) gt_launch(wgrad32_group_kernel<1, true, true>, dim3(G.start[G.n]), dim3(256), s, G);
   else if (k == 5) gt_launch(wgrad32_group_kernel<1, true, false>, dim3(G.start[G.n]), dim3(256), s, G);
   else if (k == 3) {
     if (wb.bf16) gt_launch(wgrad32_group_kernel<1, false, false>, dim3(G.start[G.n]), dim3(256), s, G);

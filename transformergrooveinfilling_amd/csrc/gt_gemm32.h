@@ -553,6 +553,136 @@ static inline bool wgrad32_ok(const GemmArgs& g) {
   return g.M % 128 == 0 && g.N % 128 == 0 && g.K % 64 == 0 && g.K >= 64 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 &&
          al16(g.A) && al16(g.B);
 }
+// ---- weight gradients with BOTH operands as bf16 shadows (precision = 1, class 4 of the grouped dispatch): the fp32-image body above
+// assembles a token-major fragment from eight 4-byte LDS reads per lane -- at the bf16 MFMA rate the LDS read issue, not the matrix
+// pipe and not the operand fetch, bounds it (halving the fetched bytes changed nothing: 916 vs 895 us at C5 bs 512).  Here the slabs
+// stay bf16 and token-major in LDS ([32 tokens][128 + 32 columns]: 320-byte rows put the four token rows of a transposed read on
+// disjoint bank groups) and a fragment is TWO ds_read_b64_tr_b16 -- the hardware transpose read: per 16 lanes a 4-token x 16-column
+// block, delivered column-major (cdna_hip_programming.md T10) -- which is exactly the 32x32x16 operand map: lane (r32, h), element j =
+// token 16 s + 8 h + j.  Same operand values, same instruction, same k order as the fp32-image body: the per-chunk sums are the same
+// numbers.  EXEC is all ones at every transposed read (no divergence above them).
+struct Wg32tCfg { static constexpr int BK = 32, STR = 160, SZ = BK * STR; };            // bf16 elements
+#ifdef GT_EMU
+struct __attribute__((may_alias, aligned(8))) Wg32tFrag { uint16_t v[4]; };
+__device__ __forceinline__ Wg32tFrag wg32t_tr(const uint16_t* p) { const emu::tr16x4 t = emu::lds_tr16(p); Wg32tFrag r; for (int j = 0; j < 4; ++j) r.v[j] = t.v[j]; return r; }
+#else
+typedef short Wg32tFrag __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Wg32tFrag wg32t_tr(const uint16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) Wg32tFrag*)(p));
+}
+#endif
+__device__ __forceinline__ bf16x8 wg32t_join(const Wg32tFrag& lo, const Wg32tFrag& hi) {
+  bf16x8 r;
+#ifdef GT_EMU
+  for (int j = 0; j < 4; ++j) { r.v[j] = lo.v[j]; r.v[4 + j] = hi.v[j]; }
+#else
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 t = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  r = __builtin_bit_cast(bf16x8, t);
+#endif
+  return r;
+}
+__device__ __forceinline__ void wgrad32t_body(const GemmArgs& g, const int m0, const int n0, const int kbeg, const int nk, const bool want_dbias,
+                                              uint16_t* sm) {
+  typedef Wg32tCfg Cfg;
+  constexpr int BK = Cfg::BK, STR = Cfg::STR, SZ = Cfg::SZ, PER = 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  G32hRegs a0[PER], b0[PER], a1[PER], b1[PER], a2[PER], b2[PER];
+  const uint16_t* pa[PER];
+  const uint16_t* pb[PER];
+  int so[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ch = tid + i * 256, kr = ch >> 4, c8 = (ch & 15) * 8;        // (token, 8 columns) = 16 bytes
+    pa[i] = g.A16 + (size_t)(kbeg + kr) * g.lda16 + m0 + c8;
+    pb[i] = g.B16 + (size_t)(kbeg + kr) * g.ldb16 + n0 + c8;
+    so[i] = kr * STR + c8;
+  }
+  const size_t astep = (size_t)g.lda16 * BK, bstep = (size_t)g.ldb16 * BK;       // elements per slab
+#define W32T_LD(XA, XB, t)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
+    XA[i] = *reinterpret_cast<const G32hRegs*>(pa[i] + (size_t)(t) * astep);                   \
+    XB[i] = *reinterpret_cast<const G32hRegs*>(pb[i] + (size_t)(t) * bstep);                   \
+  }
+#define W32T_ST(XA, XB, buf)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
+    *reinterpret_cast<G32hRegs*>(&sm[(buf) * 2 * SZ + so[i]]) = XA[i];                         \
+    *reinterpret_cast<G32hRegs*>(&sm[(buf) * 2 * SZ + SZ + so[i]]) = XB[i];                    \
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // transposed read of this lane: group gq = lane >> 4 -> columns + 16 (gq & 1), tokens + 8 (gq >> 1) = + 8 h; inside the group lane
+  // 4 q + p addresses token row q, columns 4 p ..
+  const int L16 = lane & 15, tq = L16 >> 2, tp = L16 & 3;
+  const int toff = (8 * h + tq) * STR + 16 * ((lane >> 4) & 1) + 4 * tp;
+  const int fa = toff + wm * 64, fb = SZ + toff + wn * 64;
+  float bsum = 0.f;
+  auto tof = [&](const int t) { return t < nk ? t : nk - 1; };
+  W32T_LD(a0, b0, 0)
+  W32T_LD(a1, b1, tof(1))
+  W32T_LD(a2, b2, tof(2))
+  W32T_ST(a0, b0, 0)
+  W32T_LD(a0, b0, tof(3))
+  __syncthreads();
+#define W32T_SLAB(CUR, NA, NB, t)                                                              \
+  if ((t) < nk) {                                                                              \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                           \
+    bf16x8 a16[2], b16[2];                                                                     \
+    _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) {                                         \
+      const uint16_t* qa = &sm[(CUR) * 2 * SZ + fa + 32 * ti + 16 * s_ * STR];                 \
+      const uint16_t* qb = &sm[(CUR) * 2 * SZ + fb + 32 * ti + 16 * s_ * STR];                 \
+      a16[ti] = wg32t_join(wg32t_tr(qa), wg32t_tr(qa + 4 * STR));                              \
+      b16[ti] = wg32t_join(wg32t_tr(qb), wg32t_tr(qb + 4 * STR));                              \
+    }                                                                                          \
+    _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                           \
+    _Pragma("unroll") for (int tb = 0; tb < 2; ++tb)                                           \
+      acc[ta][tb] = GT_MFMA32_BF16(a16[ta], b16[tb], acc[ta][tb]);                             \
+  }                                                                                            \
+  if (want_dbias && tid < 128) {  /* column sums of the dY slab (the bias gradient) */           \
+    _Pragma("unroll 8") for (int kk_ = 0; kk_ < BK; ++kk_) bsum += gt_bf2f(sm[(CUR) * 2 * SZ + kk_ * STR + tid]); \
+  }                                                                                            \
+  W32T_ST(NA, NB, (CUR) ^ 1)                                                                   \
+  W32T_LD(NA, NB, tof((t) + 4))                                                                \
+  __syncthreads();                                                                             \
+  }
+  for (int kt = 0; kt < nk; kt += 6) {
+    W32T_SLAB(0, a1, b1, kt) W32T_SLAB(1, a2, b2, kt + 1) W32T_SLAB(0, a0, b0, kt + 2)
+    W32T_SLAB(1, a1, b1, kt + 3) W32T_SLAB(0, a2, b2, kt + 4) W32T_SLAB(1, a0, b0, kt + 5)
+  }
+#undef W32T_SLAB
+#undef W32T_LD
+#undef W32T_ST
+  if (want_dbias && tid < 128) atomicAdd(&g.dbias[m0 + tid], bsum);
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + ta * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, col = n0 + wn * 64 + tb * 32 + r32;
+        atomicAdd(&g.C[(size_t)row * g.ldc + col], acc[ta][tb][e]);
+      }
+}
+__global__ __launch_bounds__(256, 2) void wgrad32t_group_kernel(GemmGroup grp) {
+  __shared__ __attribute__((aligned(16))) uint16_t sm[4 * Wg32tCfg::SZ];        // [buffer][A | B]
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+  const int b = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+  int i = 0;
+  while (i + 1 < grp.n && b >= grp.start[i + 1]) ++i;
+  const GemmArgs& g = grp.p[i];
+  const int local = b - grp.start[i];
+  const int bx = local % grp.gx[i], t = local / grp.gx[i], by = t % grp.gy[i], bz = t / grp.gy[i];
+  const int kbeg = bz * g.k_chunk;
+  const int kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
+  wgrad32t_body(g, by * 128, bx * 128, kbeg, (kend - kbeg) / 32, g.dbias != nullptr && bx == 0, sm);
+}
+
 template <int PREC, bool SA16, bool SB16>
 __global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp) {
   __shared__ __attribute__((aligned(16))) float smem[Gemm32Cfg::smem<true, true>()];
