@@ -192,6 +192,7 @@ struct WLayout {
   std::vector<std::pair<int64_t, int64_t>> sh;
   std::vector<int64_t> sh_only;                        // level 2: fp32 offsets of the tensors stored in bf16 alone
   int64_t w16 = -1, w16t = -1, w16_stride = 0;
+  int64_t wT = -1, wT_stride = 0;                      // precision = 1 without shadows: fp32 transposes of the encoder layers' matrices (dgrads as NT)
   struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; };
   std::vector<TmpSet> set;                           // 2 alternating sets, or one per layer (wgrad_deferred)
 };
@@ -224,6 +225,13 @@ extern "C" int gt_set_operand_shadows(int level) { g_bf16_shadows = level < 0 ? 
 static int bf16_shadow_level() {
   if (g_bf16_shadows < 0) { const char* e = getenv("GT_BF16_SHADOWS"); g_bf16_shadows = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
   return g_bf16_shadows;
+}
+// precision = 1 where the shadows do not apply: fp32 W^T copies of the encoder layers' matrices, so that the dgrads run in the NT form
+// (GT_BF16_WT=0 switches it off; results: the same products, summed in the NT kernel's k order)
+static bool bf16_shadows(const gt_config& c);
+static bool bf16_wt(const gt_config& c) {
+  static const int on = [] { const char* e = getenv("GT_BF16_WT"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on && c.precision == 1 && c.n_enc_layers > 0 && c.d_model % 32 == 0 && c.dim_ff % 32 == 0 && !bf16_shadows(c);
 }
 static bool bf16_shadows(const gt_config& c) {
   const int on = bf16_shadow_level() > 0;
@@ -305,6 +313,9 @@ static WLayout ws_layout(const gt_config& c) {
     }
     W.w16_stride = ((int64_t)4 * d * d + (int64_t)2 * d * F + 1) / 2;          // floats per layer
     W.w16 = add(W.w16_stride * c.n_enc_layers); W.w16t = add(W.w16_stride * c.n_enc_layers);
+  } else if (bf16_wt(c)) {
+    W.wT_stride = (int64_t)4 * d * d + (int64_t)2 * d * F;
+    W.wT = add(W.wT_stride * c.n_enc_layers);
   }
 #ifdef GT_SEQ_STAMPS
   W.stamps = add(2048 + 2 * 4 * 512);
@@ -421,6 +432,20 @@ static uint16_t* sh_act(const Ctx& x, const float* p) {
   if (x.W.sh.empty() || p == nullptr) return nullptr;
   const int64_t off = p - x.ws;
   for (const auto& e : x.W.sh) if (e.first == off) return reinterpret_cast<uint16_t*>(x.ws + e.second);
+  return nullptr;
+}
+// fp32 transposed copy of an encoder-layer weight matrix (precision = 1 without shadows), or nullptr
+static const float* wT_of(const Ctx& x, const float* W) {
+  if (x.W.wT < 0) return nullptr;
+  const int64_t off = W - x.prm, d = x.d, F = x.F;
+  for (int l = 0; l < x.c.n_enc_layers; ++l) {
+    const LayerP& p = x.P.enc[l];
+    const float* base = x.ws + x.W.wT + x.W.wT_stride * l;
+    if (off == p.sa.in_w) return base;
+    if (off == p.sa.out_w) return base + 3 * d * d;
+    if (off == p.w1) return base + 4 * d * d;
+    if (off == p.w2) return base + 4 * d * d + d * F;
+  }
   return nullptr;
 }
 // level 2: is this workspace tensor stored in bf16 alone (its fp32 region is not written)?
@@ -556,6 +581,12 @@ static void acquire_set(Ctx& x, int set) {
 }
 // dX = dY W   ("NN")
 static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, int ldw, float* dX, int N, int K, int accumulate) {
+  if (const float* wt = (ldw == N) ? wT_of(x, W) : nullptr) {      // dX = dY (W^T)^T: the NT form over the transposed copy
+    GemmArgs g = mk_gemm(dY, ldy, wt, K, dX, N, x.M, N, K);
+    g.accumulate = accumulate; g.as_dgrad = 1;
+    gemm_launch<false, false, EPI_STORE>(g, x.s);
+    return;
+  }
   GemmArgs g = mk_gemm(dY, ldy, W, ldw, dX, N, x.M, N, K);
   g.accumulate = accumulate;
   if (ldy == K && ldw == N) { g.A16 = sh_act(x, dY); g.B16 = sh_w(x, W, true); g.lda16 = g.ldb16 = K; }      // (W^T: [N][K], k contiguous)
@@ -943,6 +974,17 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
 
 static int encoder_fwd(const Ctx& x, const float* pe, const float* src) {
   float* ws = x.ws;
+  if (x.W.wT >= 0) {       // fp32 transposes of the encoder layers' weights: this step's dgrads run as NT products
+    const LayerP& p0 = x.P.enc[0];
+    WShadowArgs a;
+    a.prm = x.prm; a.w16 = nullptr; a.w16t = nullptr;
+    a.in_w = p0.sa.in_w; a.out_w = p0.sa.out_w; a.w1 = p0.w1; a.w2 = p0.w2;
+    a.pstride = x.c.n_enc_layers > 1 ? x.P.enc[1].sa.in_w - p0.sa.in_w : 0; a.sstride = x.W.wT_stride;
+    a.d = x.d; a.F = x.F; a.L = x.c.n_enc_layers;
+    const int tiles = (4 * x.d * x.d + 2 * x.d * x.F) / 1024;
+    gt_prof_tag("weight_shadow", 0.0, 8.0 * x.c.n_enc_layers * tiles * 1024.0);
+    gt_launch(weight_transpose_kernel, dim3((unsigned)(tiles * x.c.n_enc_layers)), dim3(256), x.s, a, ws + x.W.wT);
+  }
   if (x.W.w16 >= 0) {      // bf16 shadows of the encoder layers' weights (and their transposes) for this step's Linears and dgrads
     const LayerP& p0 = x.P.enc[0];
     WShadowArgs a;
@@ -1090,9 +1132,15 @@ static int ffn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const Tmp& t,
                    const float* xhat_prev, const float* rstd_prev, int64_t gamma_prev, float* dzo, float* dzom, int site_prev) {
   float* ws = x.ws;
   wgrad(x, dzm, x.d, ws + w.hact, x.F, x.grd + p.w2, x.grd + p.b2, x.d, x.F);
-  GemmArgs g = mk_gemm(dzm, x.d, x.prm + p.w2, x.F, t.dhid, x.F, x.M, x.F, x.d);
+  const float* w2t = wT_of(x, x.prm + p.w2);
+  GemmArgs g = w2t ? mk_gemm(dzm, x.d, w2t, x.d, t.dhid, x.F, x.M, x.F, x.d) : mk_gemm(dzm, x.d, x.prm + p.w2, x.F, t.dhid, x.F, x.M, x.F, x.d);
   g.res = ws + w.hact; g.ldres = x.F;
   g.mask_scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
+  if (w2t) {
+    gemm_launch<false, false, EPI_MASK_NZ>(g, x.s);
+    wgrad(x, t.dhid, x.F, xin, x.d, x.grd + p.w1, x.grd + p.b1, x.F, x.d);
+    return dgrad_lnbwd(x, t.dhid, x.F, x.prm + p.w1, x.F, dz, xhat_prev, rstd_prev, gamma_prev, dzo, dzom, site_prev);
+  }
   g.A16 = sh_act(x, dzm); g.B16 = sh_w(x, x.prm + p.w2, true); g.lda16 = g.ldb16 = x.d;
   if (g.A16 && g.B16) { g.C16 = sh_act(x, t.dhid); g.ldc16 = x.F; }
   if (only16(x, ws + w.hact)) g.res16 = sh_act(x, ws + w.hact);
@@ -1117,6 +1165,13 @@ static void self_attn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const 
 // grad of the InputLayer: da = (dqkv Win + dz1) * dropmask * (a0 > 0) -> da_out; dW = da^T in; db = colsum(da)
 static void input_layer_bwd(const Ctx& x, const LayerP& first, const Tmp& t, const float* dz1, const float* a0, const float* in, int S,
                             int64_t w, int64_t b, int site, float* da_out) {
+  if (const float* wt = wT_of(x, x.prm + first.sa.in_w)) {
+    GemmArgs g = mk_gemm(t.dqkv, 3 * x.d, wt, 3 * x.d, da_out, x.d, x.M, x.d, 3 * x.d);
+    g.res = dz1; g.ldres = x.d; g.aux_in = a0; g.drop = mk_drop(x, site);
+    gemm_launch<false, false, EPI_ADD_RELUMASK_DROP>(g, x.s);
+    wgrad(x, da_out, x.d, in, S, x.grd + w, x.grd + b, x.d, S);
+    return;
+  }
   GemmArgs g = mk_gemm(t.dqkv, 3 * x.d, x.prm + first.sa.in_w, x.d, da_out, x.d, x.M, x.d, 3 * x.d);
   g.res = dz1; g.ldres = x.d; g.aux_in = a0; g.drop = mk_drop(x, site);
   g.A16 = sh_act(x, t.dqkv); g.B16 = sh_w(x, x.prm + first.sa.in_w, true); g.lda16 = g.ldb16 = 3 * x.d;

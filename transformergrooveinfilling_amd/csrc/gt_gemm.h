@@ -71,6 +71,7 @@ struct GemmArgs {
   const uint16_t* A16; const uint16_t* B16; int lda16, ldb16;
   uint16_t* C16; int ldc16;
   const uint16_t* res16;     // EPI_MASK_NZ: the mask source as bf16 (row stride ldres), when its fp32 tensor is not stored
+  int as_dgrad;              // profiling label only: an NT product that IS a dgrad (B = a transposed weight copy)
 };
 
 template <int ROWS, int COLS, int NT>
@@ -758,7 +759,8 @@ template <int WM, int WN, int TM, int TN, int BK, bool AKM, bool BKM, int EPI, i
 static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s) {
   typedef GemmCfg<WM, WN, TM, TN, BK, AKM, BKM, EPI, PREC> Cfg;
   static_assert(!Cfg::ROW || (Cfg::BM % Cfg::NG) == 0, "row epilogue: BM must be a multiple of the row-group count");
-  gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+  gt_prof_tag((g.as_dgrad && EPI == EPI_STORE) ? "gemm_dgrad" : gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K,
+              4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
   dim3 grid((g.N + Cfg::BN - 1) / Cfg::BN, (g.M + Cfg::BM - 1) / Cfg::BM, splitk);
   gt_launch(gemm_kernel<WM, WN, TM, TN, BK, AKM, BKM, EPI, PREC>, grid, dim3(Cfg::NT), s, g);
 }

@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmArgs g) {
 
 template <bool BKM, int EPI>
 static inline void gemm32_launch(const GemmArgs& g, hipStream_t s) {
-  gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+  gt_prof_tag((g.as_dgrad && EPI == EPI_STORE) ? "gemm_dgrad" : gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K,
+              4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
   if (g.bf16) gt_launch(gemm32_kernel<BKM, EPI, 1>, dim3(g.N / 128, g.M / 128), dim3(256), s, g);
   else        gt_launch(gemm32_kernel<BKM, EPI, 0>, dim3(g.N / 128, g.M / 128), dim3(256), s, g);
 }
