@@ -46,6 +46,11 @@ def klass(name):
             return EPI.get(epi) or ("gemm_dgrad" if bkm else "gemm_fwd_bias")
         except (ValueError, IndexError):
             return "gemm"
+    m = re.match(r"void gemm32h_kernel<(\d+)>", name)          # bf16-source big-tile kernel: NT for forward AND dgrad (the transposed weight copy)
+    if m:
+        return EPI.get(int(m.group(1))) or "gemm_fwd_bias"      # (EPI 0 = the plain store: forward Linears and dgrads share the kernel)
+    if "wgrad32t_group_kernel" in name:
+        return "gemm_wgrad"
     for k, v in PLAIN:
         if k in name:
             return v
