@@ -497,6 +497,11 @@ def check_train_step(backend, cfg, B, p, algo=0, seq=True):
                 assert c == want.size, (name, c, want.size)
                 assert np.array_equal(r.ws.numpy()[o:o + c].view(np.uint32), want.view(np.uint32)), (step, name)
     assert r.step_state().step == (3 if folded else 2)
+    try:                                             # QUAD forward: no pair exchange timed out (error word of the region's header)
+        o, _ = r.lib.ws_find(r.c, "seq_xchg")
+        assert r.ws.numpy()[o:o + 1].view(np.uint32)[0] == 0
+    except Exception as e:
+        assert "seq_xchg" in str(e) or "absent" in str(e) or "unknown" in str(e), e
 
 
 def check_predict(backend, cfg, B, use_thres=True, thres=0.5, out_tol=OUT_TOL, margin_tol=1e-4, pd_seed=None):

@@ -56,6 +56,7 @@ class _Slot:
         self.use_graph = None          # StepEngine.graph_for's decision for this slot (use_graph="auto")
         self.fwd_id = 0                # bumped by every call that overwrites the saved activations (see StepEngine.forward)
         self.pack_epoch = -1           # StepEngine._pepoch at which this workspace's fragment-ordered weight copies were written
+        self.xchg_off = None           # workspace offset of the QUAD pair-exchange region's error word (-1: none; looked up lazily)
 
 
 class _LossSlot:
@@ -481,7 +482,21 @@ class StepEngine:
             del self._predict_ws[m]               # (stream-ordered free: the caching allocator keeps the block until the launches ran)
         return out
 
+    def check_exchange(self, s):
+        """The QUAD forward's pair exchange spins with a bound: a partner workgroup that never arrives (the two were not resident at the
+        same time) raises an error word in the exchange region instead of hanging the GPU -- the step's numbers are then garbage.
+        Called where the host synchronises anyway (the logging path): raises if the word is set."""
+        if s.xchg_off is None:
+            try:
+                s.xchg_off = self.lib.ws_find(s.cfg, "seq_xchg")[0]
+            except Exception:
+                s.xchg_off = -1
+        if s.xchg_off >= 0 and int(s.ws[s.xchg_off:s.xchg_off + 1].view(torch.int32).item()) != 0:
+            raise RuntimeError("sequence kernels: a pair exchange of the four-workgroups-per-sequence forward timed out "
+                               "(partner workgroups not co-resident); set GT_SEQ_QUAD=0")
+
     def mean_stats(self, s):
+        self.check_exchange(s)
         """The slot's 8-float stats averaged over the data-parallel ranks (one tiny all-reduce; every rank must call it).
         Single process: the stats tensor itself."""
         if self.world_size == 1 or not self.reduce_stats:
