@@ -84,7 +84,7 @@ def test_big_tile_kernel_variant():
     import sys
     from harness import ROOT
     so = os.path.join(ROOT, "tests", "emu", "libgroove_emu_big.so")
-    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh"), "-DGT_T128_BIG_MIN=1", "-DGT_WGRAD_T128_MIN=1", "-DGT_ROW32_MIN_M=64", "-DGT_ROW_FUSE_MIN_M=64", "-DGT_ATTN_BWD_LDS_MIN=1"],
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh"), "-DGT_T128_BIG_MIN=1", "-DGT_T128H_MIN=1", "-DGT_WGRAD_T128_MIN=1", "-DGT_ROW32_MIN_M=64", "-DGT_ROW_FUSE_MIN_M=64", "-DGT_ATTN_BWD_LDS_MIN=1"],
                           env=dict(os.environ, GT_EMU_OUT=so),
                           stdout=subprocess.DEVNULL)
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"

@@ -206,7 +206,7 @@ struct WLayout {
 static bool wgrad_deferred(const gt_config& c) { return (int64_t)c.batch * 32 <= GT_WGRAD_DEFER_MAX_M; }
 static bool seq_supported(const gt_config& c);
 // bf16 SHADOWS of the GEMM operands (precision = 1): where the Linears of the encoder layers run on the big-tile kernel -- interior
-// 128-tiles, enough of them -- and the tensors' producers are the kernels that can write a bf16 copy (LayerNorm passes of d_model 256 /
+// 128-tiles, at least GT_T128H_MIN of them -- and the tensors' producers are the kernels that can write a bf16 copy (LayerNorm passes of d_model 256 /
 // 512, the MFMA attention kernels).
 #ifndef GT_T128_BIG_MIN
 #define GT_T128_BIG_MIN 192
@@ -240,7 +240,7 @@ static bool bf16_shadows(const gt_config& c) {
   static const int attn_mfma = [] { const char* e = getenv("GT_ATTN_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();      // (ctx / dqkv shadows)
   const int nmin = c.d_model < c.dim_ff ? c.d_model : c.dim_ff;            // every Linear of a layer on the big-tile kernel (its epilogue writes hact16 / dhid16)
   return on && attn_mfma && wgrad_deferred(c) && c.precision == 1 && c.n_enc_layers > 0 && (c.d_model == 256 || c.d_model == 512) && c.dim_ff % 128 == 0 &&
-         M % 128 == 0 && (hd == 16 || hd == 32 || hd == 64 || hd == 128) && (M / 128) * (nmin / 128) >= GT_T128_BIG_MIN;
+         M % 128 == 0 && (hd == 16 || hd == 32 || hd == 64 || hd == 128) && (M / 128) * (nmin / 128) >= GT_T128H_MIN;
 }
 static WLayout ws_layout(const gt_config& c) {
   WLayout W;

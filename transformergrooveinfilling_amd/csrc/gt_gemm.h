@@ -904,6 +904,11 @@ static inline void gemm32h_launch(const GemmArgs& g, hipStream_t s);
 #ifndef GT_T128_BIG_MIN
 #define GT_T128_BIG_MIN 192     /* 128x128 tiles of the big kernel from this many workgroups (d512 QKV at 2048 tokens: 16 x 12) */
 #endif
+#ifndef GT_T128H_MIN
+#define GT_T128H_MIN 64         /* ... the bf16-SOURCE kernel (operand shadows, precision 1) already from 64: at the bf16 MFMA rate a 128x128 tile is short, and
+                                   the bf16-only storage it comes with pays by itself -- C5 at 64 sequences per GPU 1.282 -> 1.206 ms (the fp32 body at 64
+                                   tiles: C4 bs 64 1.65 -> 2.75 ms) */
+#endif
 // standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
 template <bool AKM, bool BKM, int EPI>
 static inline void gemm_launch(GemmArgs g, hipStream_t s) {
@@ -916,7 +921,7 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
   }
   if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP)) {
     const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (g.bf16 && b128 >= GT_T128_BIG_MIN && gemm32h_ok(g, EPI)) { gemm32h_launch<BKM, EPI>(g, s); return; }     // both operands as bf16 shadows
+    if (g.bf16 && b128 >= GT_T128H_MIN && gemm32h_ok(g, EPI)) { gemm32h_launch<BKM, EPI>(g, s); return; }     // both operands as bf16 shadows
     if (g.bf16 && b128 >= GT_T128_BIG_MIN && gemm32_ok(g, EPI, BKM)) { gemm32_launch<BKM, EPI>(g, s); return; }
   }
   if (g.bf16) {
