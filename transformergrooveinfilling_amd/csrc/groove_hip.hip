@@ -177,6 +177,7 @@ extern "C" int gt_param_layout(const gt_config* cfg, int64_t* offsets, int64_t* 
 // ------------------------------------------------------------------------------------ workspace layout
 struct LayerW {
   int64_t qkv, P, ctx, xhat1, rstd1, x1;            // self-attention block
+  int64_t amask;                                    // dropout keep bits of P, one word per (sequence, head, query): head_dim-2 attention of gt_seq.h
   int64_t qx, kvx, Px, ctxx, xhatx, rstdx, x2;      // decoder cross-attention block
   int64_t hact, xhat2, rstd2, xout;                 // FFN block (xhat2/rstd2 = the layer's LAST norm)
 };
@@ -252,7 +253,7 @@ static WLayout ws_layout(const gt_config& c) {
   W.layers.resize(nl);
   for (int l = 0; l < nl; ++l) {
     LayerW& w = W.layers[l];
-    w.qkv = add(M * 3 * d); w.P = add(BH * 1024); w.ctx = add(M * d);
+    w.qkv = add(M * 3 * d); w.P = add(BH * 1024); w.ctx = add(M * d); w.amask = add(BH * 32);
     w.xhat1 = add(M * d); w.rstd1 = add(M); w.x1 = add(M * d);
     if (l >= c.n_enc_layers) {
       w.qx = add(M * d); w.kvx = add(M * 2 * d); w.Px = add(BH * 1024); w.ctxx = add(M * d);
@@ -383,6 +384,7 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
     if (layer < 0 || layer >= (int)W.layers.size()) return gt_fail("gt_ws_find: layer %d out of range", layer);
     const LayerW& w = W.layers[layer];
     if (n == "qkv") set(w.qkv, M * 3 * d); else if (n == "P") set(w.P, BH * 1024); else if (n == "ctx") set(w.ctx, M * d);
+    else if (n == "amask") set(w.amask, BH * 32);
     else if (n == "xhat1") set(w.xhat1, M * d); else if (n == "rstd1") set(w.rstd1, M); else if (n == "x1") set(w.x1, M * d);
     else if (n == "qx") set(w.qx, M * d); else if (n == "kvx") set(w.kvx, M * 2 * d); else if (n == "Px") set(w.Px, BH * 1024);
     else if (n == "ctxx") set(w.ctxx, M * d); else if (n == "xhatx") set(w.xhatx, M * d); else if (n == "x2") set(w.x2, M * d);
@@ -923,7 +925,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.p0 = SeqLayerP{p.sa.in_w, p.sa.in_b, p.sa.out_w, p.sa.out_b, p.w1, p.b1, p.w2, p.b2, p.n1w, p.n1b, p.n2w, p.n2b};
   a.pstride = x.c.n_enc_layers > 1 ? x.P.enc[1].sa.in_w - p.sa.in_w : x.P.encn_w - p.sa.in_w;   // (one layer: its span -- the update kernel's range test)
   const LayerW& w = x.W.layers[0];
-  a.w0 = SeqLayerW{w.qkv, w.P, w.ctx, w.xhat1, w.rstd1, w.x1, w.hact, w.xhat2, w.rstd2, w.xout};
+  a.w0 = SeqLayerW{w.qkv, w.P, w.ctx, w.xhat1, w.rstd1, w.x1, w.hact, w.xhat2, w.rstd2, w.xout, w.amask};
   a.wstride = x.c.n_enc_layers > 1 ? x.W.layers[1].qkv - w.qkv : 0;
   const WLayout::TmpSet& t = x.W.set[0];
   a.t0 = SeqTmp{t.dzA, t.dzAm, t.dzB, t.dzBm, t.dhid, t.dqkv};

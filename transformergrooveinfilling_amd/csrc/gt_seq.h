@@ -83,6 +83,9 @@ __device__ __forceinline__ float seq_dmul(const SeqDropK& k, const uint32_t key,
   if (!k.thr) return 1.0f;
   return ((gt_fmix32((idx * 0x9E3779B1u) ^ key) >> 8) >= k.thr) ? k.scale : 0.0f;
 }
+__device__ __forceinline__ bool seq_dkeep(const SeqDropK& k, const uint32_t key, const uint32_t idx) {   // k.thr != 0: is element idx kept
+  return (gt_fmix32((idx * 0x9E3779B1u) ^ key) >> 8) >= k.thr;
+}
 
 // ---- sums over the 16 lanes of a token row (lanes 16 r .. 16 r + 15 of a wave = one DPP row): quad butterfly, then the mirrored
 // half-row and row -- the same operand pairs as an xor-1/2/4/8 butterfly (bit-identical to it), without the LDS crossbar.
@@ -384,6 +387,30 @@ __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda
   const int l16 = lane & 15, lg = lane >> 4, ntile = N >> 4, nk = K >> 4;
   if (wave >= ntile) return;                             // wave-uniform
   const float* ap = sA + l16 * lda + 4 * lg;
+  if constexpr (MAXT > 2 && NK * MAXT <= 8) {
+    // short contraction, many tiles (d_model 32: FFN1 / FFN2 dgrad, 4 tiles of 2 k-steps per wave): ALL the wave's fragments are requested
+    // before the first MFMA -- 8 x 16 bytes per lane -- so the stage pays one L2 round trip instead of one per tile (with a prefetch depth
+    // of one tile the 8 MFMAs + epilogue of a tile cover a third of the next fragment's latency)
+    SeqB<NK> ball[MAXT];
+    float4 biall[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wave + i * GT_SEQ_WAVES, tc = t < ntile ? t : wave;     // (clamped: no branch around a load)
+      if (i == 0 && have_pre) ball[0] = pre;
+      else seq_b_load<NK, FULL>(ball[i], Wp, nk, tc, 0, nk, lane);
+      biall[i] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * tc + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wave + i * GT_SEQ_WAVES;
+      if (t < ntile) {
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        seq_b_mma<NK, FULL, HALF>(acc0, acc1, ball[i], ap, lda, nk);
+        epi(16 * t, acc0, acc1, biall[i]);
+      }
+    }
+    return;
+  }
   SeqB<NK> b[2];
   float4 bi[2];
   GT_SUBSTAMP(0);
@@ -927,11 +954,11 @@ __device__ __forceinline__ void seq_attn_bwd_store(float* dq, const int ldq, con
 }
 
 // ---- head_dim 2 (the reference's ClosedHH YAML: d_model 32, 16 heads) on the vector ALU.  Zero-padded to a 16-wide MFMA contraction such a head does
-// 2 .. 8 useful multiplications per 16 and the stage is one latency chain per round of heads (ClosedHH YAML: 17 k cycles forward, 31 k
-// backward per layer, more than every matmul of the layer together).  Here ONE THREAD owns a (query row, head) pair: 32 scores, the
-// softmax and the head's ctx columns in registers, operands straight from the LDS qkv tile as 8- / 16-byte reads (a wave's lanes differ
-// in the head: consecutive addresses; in the row: broadcast).  rows x H <= the workgroup's threads.  Same P / dropout index layout as the
-// MFMA form (P[head][query][key], index = head base + 32 query + key).  (Written for head_dim 2 / 4 / 8; only 2 is instantiated: at 8 the compiler keeps 256 registers live and spills, and the
+// 2 .. 8 useful multiplications per 16 and the stage is one latency chain per round of heads.  Here a (query row, head) pair's 32 scores,
+// the softmax and the head's ctx columns live in the registers of one or two threads, operands straight from the LDS qkv tile as 8- /
+// 16-byte reads (a wave's lanes differ in the head: consecutive addresses; in the row: broadcast).  Same P / dropout index layout as the
+// MFMA form (P[head][query][key], index = head base + 32 query + key).  SPLIT kernels only (16 query / key rows per workgroup).
+// (Written for head_dim 2 / 4 / 8; only 2 is instantiated: at 8 the compiler keeps 256 registers live and spills, and the
 // testing YAML's head_dim-8 attention stays on the zero-padded MFMA form with every other head_dim below 16.)
 template <int HD> struct SeqHv { float v[HD]; };
 template <int HD>
@@ -951,120 +978,204 @@ __device__ __forceinline__ float seq_hv_dot(const SeqHv<HD>& a, const SeqHv<HD>&
   for (int c = 0; c < HD; ++c) t += a.v[c] * b.v[c];
   return t;
 }
+// the value of the neighbouring lane (lane ^ 1): one quad-permute DPP move
+__device__ __forceinline__ float seq_lane_swap1(const float v) {
+#ifdef GT_EMU
+  return __shfl_xor(v, 1);
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+#endif
+}
+__device__ __forceinline__ uint32_t seq_lane_swap1u(const uint32_t v) { return __builtin_bit_cast(uint32_t, seq_lane_swap1(__builtin_bit_cast(float, v))); }
+// Forward: TWO threads per (query row, head) -- neighbouring lanes, 16 keys each (16 rows x 16 heads of a SPLIT workgroup are 256 pairs:
+// every thread of the workgroup busy, two waves per SIMD to hide each other's LDS and exp latency; one thread per pair with 32 keys
+// left half of the SIMDs' issue slots empty: 18 k cycles per layer at the ClosedHH YAML shape).  The pair meets three times through a DPP
+// move: row maximum, row sum, the ctx partial sums.  Lane `part` takes keys 0..15 in order, its neighbour 20..31, 16..19: the rotation
+// puts the pair's 8-byte reads of one instruction 20 rows = 32 banks apart in the [32][3 d + 8] tile of d_model 32 (16 rows apart is the
+// same bank).  2 x nrow x H <= the workgroup's threads.
 template <int HD>
 __device__ __forceinline__ void seq_attn_fwd_small(const float* sQ, const int ldq, const int d, const int H, const float scale, float* Pseq,
                                                    const uint32_t pidx_seq, float* sCtx, const int ldc, const SeqDropK& dk, const uint32_t key,
-                                                   const int row0, const int nrow, const int tid) {
-  if (tid >= nrow * H) return;
-  const int h = tid % H, i = row0 + tid / H;
-  const float* kp = sQ + d + h * HD;
-  const float* vp = sQ + 2 * d + h * HD;
+                                                   uint32_t* amask, const int row0, const int nrow, const int tid) {
+  if (tid >= 2 * nrow * H) return;
+  const int part = tid & 1, pr = tid >> 1, h = pr % H, i = row0 + pr / H;
+  const int j0 = part ? 20 : 0, wrap = part ? 16 : 0;         // key of step jj: j0 + jj, minus wrap from jj = 12 on
+  const float* ka = sQ + d + h * HD + j0 * ldq;
+  const float* kb = ka - wrap * ldq;
   const SeqHv<HD> q = seq_hv_ld<HD>(sQ + i * ldq + h * HD);
-  float sc[32], mx = -INFINITY;
+  float sc[16], mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    sc[j] = seq_hv_dot<HD>(q, seq_hv_ld<HD>(kp + j * ldq)) * scale; mx = fmaxf(mx, sc[j]);
-    if ((j & 3) == 3) { GT_SCHED_FENCE() }                     // (four keys' reads in flight; all 32 hoisted ahead would be 256 registers)
+  for (int jj = 0; jj < 16; ++jj) {
+    sc[jj] = seq_hv_dot<HD>(q, seq_hv_ld<HD>((jj < 12 ? ka : kb) + jj * ldq)) * scale; mx = fmaxf(mx, sc[jj]);
+    if ((jj & 3) == 3) { GT_SCHED_FENCE() }                    // (four keys' reads in flight)
   }
+  mx = fmaxf(mx, seq_lane_swap1(mx));
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    sc[j] = expf(sc[j] - mx); sum += sc[j];
-    if ((j & 3) == 3) { GT_SCHED_FENCE() }                     // (32 interleaved exp expansions are 150 registers of temporaries)
+  for (int jj = 0; jj < 16; ++jj) {
+    sc[jj] = expf(sc[jj] - mx); sum += sc[jj];
+    if ((jj & 3) == 3) { GT_SCHED_FENCE() }                    // (16 interleaved exp expansions are 80 registers of temporaries)
   }
+  sum += seq_lane_swap1(sum);                                  // (a + b in both lanes: identical)
   const float inv = 1.0f / sum;
   float* Prow = Pseq + (size_t)h * 1024 + i * 32;
   const uint32_t pidx = pidx_seq + (uint32_t)(h * 1024 + i * 32);
   SeqHv<HD> o;
+  uint32_t mb = 0u;
 #pragma unroll
   for (int c = 0; c < HD; ++c) o.v[c] = 0.f;
 #pragma unroll
-  for (int j = 0; j < 32; j += 4) {
+  for (int jj = 0; jj < 16; jj += 4) {
+    const int j = j0 + jj - (jj < 12 ? 0 : wrap);
+    const float* vp = (jj < 12 ? ka : kb) + d + jj * ldq;
     float4 pv;
-    pv.x = sc[j] * inv; pv.y = sc[j + 1] * inv; pv.z = sc[j + 2] * inv; pv.w = sc[j + 3] * inv;
+    pv.x = sc[jj] * inv; pv.y = sc[jj + 1] * inv; pv.z = sc[jj + 2] * inv; pv.w = sc[jj + 3] * inv;
     *reinterpret_cast<float4*>(Prow + j) = pv;
-    const float m0 = pv.x * seq_dmul(dk, key, pidx + j), m1 = pv.y * seq_dmul(dk, key, pidx + j + 1);
-    const float m2 = pv.z * seq_dmul(dk, key, pidx + j + 2), m3 = pv.w * seq_dmul(dk, key, pidx + j + 3);
-    const SeqHv<HD> v0 = seq_hv_ld<HD>(vp + j * ldq), v1 = seq_hv_ld<HD>(vp + (j + 1) * ldq);
-    const SeqHv<HD> v2 = seq_hv_ld<HD>(vp + (j + 2) * ldq), v3 = seq_hv_ld<HD>(vp + (j + 3) * ldq);
+    float m0 = pv.x, m1 = pv.y, m2 = pv.z, m3 = pv.w;
+    if (dk.thr) {                                                // (uniform) the keep decisions also go to the mask word: bit = step here
+      const bool k0 = seq_dkeep(dk, key, pidx + j), k1 = seq_dkeep(dk, key, pidx + j + 1);
+      const bool k2 = seq_dkeep(dk, key, pidx + j + 2), k3 = seq_dkeep(dk, key, pidx + j + 3);
+      mb |= (k0 ? 1u << jj : 0u) | (k1 ? 2u << jj : 0u) | (k2 ? 4u << jj : 0u) | (k3 ? 8u << jj : 0u);
+      m0 = k0 ? m0 * dk.scale : 0.f; m1 = k1 ? m1 * dk.scale : 0.f; m2 = k2 ? m2 * dk.scale : 0.f; m3 = k3 ? m3 * dk.scale : 0.f;
+    }
+    const SeqHv<HD> v0 = seq_hv_ld<HD>(vp), v1 = seq_hv_ld<HD>(vp + ldq), v2 = seq_hv_ld<HD>(vp + 2 * ldq), v3 = seq_hv_ld<HD>(vp + 3 * ldq);
 #pragma unroll
     for (int c = 0; c < HD; ++c) o.v[c] += m0 * v0.v[c] + m1 * v1.v[c] + m2 * v2.v[c] + m3 * v3.v[c];
     GT_SCHED_FENCE()
   }
 #pragma unroll
-  for (int c = 0; c < HD; ++c) sCtx[i * ldc + h * HD + c] = o.v[c];
-}
-// Backward, the same ownership in two passes with a workgroup barrier between them (and one after: the results replace q / k / v in
-// place).  Pass A, thread = (query row i of all 32, head): dP, the row sum rd -> srd[head][i], dS, dq_i.  Pass B, thread = (key row j of
-// the rows [krow0, krow0 + nkrow), head), j fastest so that the P column reads of a wave are 64 / 128 contiguous bytes: dv_j, dk_j over
-// all 32 queries.  32 x H and nkrow x H <= the workgroup's threads; srd: H x 32 floats of LDS.
-template <int HD>
-__device__ __forceinline__ void seq_attn_bwd_small(float* sQ, const int ldq, const int d, const int H, const float scale, const float* Pseq,
-                                                   const uint32_t pidx_seq, const float* sDO, const int lddo, const SeqDropK& dk,
-                                                   const uint32_t key, float* srd, const int krow0, const int nkrow, const int tid) {
-  SeqHv<HD> dq, dkk, dvv;
+  for (int c = 0; c < HD; ++c) o.v[c] += seq_lane_swap1(o.v[c]);
+  if (part == 0) {
 #pragma unroll
-  for (int c = 0; c < HD; ++c) { dq.v[c] = 0.f; dkk.v[c] = 0.f; dvv.v[c] = 0.f; }
-  const bool ta = tid < 32 * H, tb = tid < nkrow * H;
-  const int ha = tid % H, ia = tid / H;                        // pass A: (query row, head), head fastest
-  const int jb = krow0 + tid % nkrow, hb = tid / nkrow;        // pass B: (key row, head), key row fastest
-  if (ta) {
-    const float* kp = sQ + d + ha * HD;
-    const float* vp = sQ + 2 * d + ha * HD;
-    const float* Prow = Pseq + (size_t)ha * 1024 + ia * 32;
-    const uint32_t pidx = pidx_seq + (uint32_t)(ha * 1024 + ia * 32);
-    const SeqHv<HD> dO = seq_hv_ld<HD>(sDO + ia * lddo + ha * HD);
-    float p[32], ds[32];
+    for (int c = 0; c < HD; ++c) sCtx[i * ldc + h * HD + c] = o.v[c];
+  }
+  // the row's 32 keep bits (bit = key) -> amask[head][query]: the backward reads them instead of hashing 32 + 16 indices per thread again
+  // (three quarter-rate integer multiplications each: the hash was half of the attention backward's cycles at the ClosedHH YAML shape)
+  if (dk.thr) {
+    uint32_t w = part ? ((((mb << 4) | (mb >> 12)) & 0xFFFFu) << 16) : mb;      // lane 1: step jj is key 16 + (jj + 4) % 16
+    w |= seq_lane_swap1u(w);
+    if (part == 0) amask[h * 32 + i] = w;
+  }
+}
+// Backward, two passes with a workgroup barrier between them (and one after: the results replace q / k / v in place; the barriers are
+// the caller's).  Pass A, thread = (query row i of all 32, head): dP, the row sum rd -> srd[head][i], dS, dq_i; its P row and keep bits
+// (SeqPRow) are REQUESTED by seq_attn_bwd_small_load, which the caller places at the start of the phase, ahead of the state tiles: P
+// was written a forward phase ago by another XCD and takes the longest round trip of the launch.  Pass B, TWO threads per (key row j of
+// the rows [krow0, krow0 + nkrow), head) -- neighbouring lanes, 16 queries each, summed through a DPP move: dv_j, dk_j over all 32
+// queries; its P column and keep bits come from LDS (pass A's row image of P -- 64 KB: the FFN tile's place, idle here -- and the mask
+// words behind the row sums): no global load between the two passes.  32 x H and 2 x nkrow x H <= the workgroup's threads; srd:
+// 2 x H x 32 words of LDS.  The dropout mask of P comes from the forward's keep bits (amask[head][query], bit = key): no hash here.
+struct SeqPRow { f32x4 p[8]; uint32_t mw; };
+// 16 heads (d_model 32).  A thread's P row is 128 contiguous bytes, 4 KB from its neighbour lane's: read row-wise a wave instruction
+// touches 64 lines for 1 KB of use (measured: the 64 KB of a sequence's P took 7.8 k cycles to arrive).  So the wave's 64 rows -- 16 heads x
+// 4 queries, sixteen 512-byte runs -- are requested run-wise: instruction u brings heads 2 u and 2 u + 1, lane = (head & 1, query & 3,
+// 16-byte slot); seq_attn_bwd_small_a turns them into rows through 8 KB of wave-private LDS.
+__device__ __forceinline__ SeqPRow seq_attn_bwd_small_load(const float* Pseq, const uint32_t* amask, const int tid) {
+  SeqPRow r;
+  const int lane = tid & 63, w = tid >> 6;
+  const float* src = Pseq + (size_t)(lane >> 5) * 1024 + (4 * w + ((lane >> 3) & 3)) * 32 + (lane & 7) * 4;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) r.p[u] = *reinterpret_cast<const f32x4*>(src + (size_t)u * 2048);
+  r.mw = amask[(tid & 15) * 32 + (tid >> 4)];
+  return r;
+}
+template <int HD> struct SeqAttnSmallG { SeqHv<HD> dq, dkk, dvv; };
+template <int HD>
+__device__ __forceinline__ void seq_attn_bwd_small_a(SeqAttnSmallG<HD>& G, const float* sQ, const int ldq, const int d, const int H, const float scale,
+                                                     const SeqPRow& pr, float* sImg, const float* sDO, const int lddo, const SeqDropK& dk, float* srd,
+                                                     const int tid) {
+#pragma unroll
+  for (int c = 0; c < HD; ++c) { G.dq.v[c] = 0.f; G.dkk.v[c] = 0.f; G.dvv.v[c] = 0.f; }
+  if (tid >= 32 * H) return;
+  const int ha = tid % H, ia = tid / H;                        // (query row, head), head fastest
+  const float msc = dk.thr ? dk.scale : 1.0f;
+  const float* kp = sQ + d + ha * HD;
+  const float* vp = sQ + 2 * d + ha * HD;
+  const uint32_t mw = pr.mw | (dk.thr ? 0u : 0xFFFFFFFFu);
+  const SeqHv<HD> dO = seq_hv_ld<HD>(sDO + ia * lddo + ha * HD);
+  float p[32], ds[32];
+  {
+    // run-wise granules -> rows, through the wave's 8 KB of sImg: row (head h, query 4 w + il) lives at row slot 4 h + (il ^ (h >> 3)), its
+    // 16-byte slot s at s ^ (h & 7): the 16 heads of one il -- a wave's lanes differ in the head first -- read 16 different (half, slot)
+    // places of the 256-byte bank row.  LDS is in order within a wave: no barrier.
+    const int lane = tid & 63;
+    float* img = sImg + (tid >> 6) * 2048;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int h = 2 * u + (lane >> 5), il = (lane >> 3) & 3;
+      *reinterpret_cast<f32x4*>(img + (4 * h + (il ^ (h >> 3))) * 32 + 4 * ((lane & 7) ^ (h & 7))) = pr.p[u];
+    }
+    GT_WAVE_SYNC();
+    const int il = lane >> 4;
+    const float* row = img + (4 * ha + (il ^ (ha >> 3))) * 32;
 #pragma unroll
     for (int j = 0; j < 32; j += 4) {
-      const float4 pv = *reinterpret_cast<const float4*>(Prow + j);
-      p[j] = pv.x; p[j + 1] = pv.y; p[j + 2] = pv.z; p[j + 3] = pv.w;
-    }
-    float rd = 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      ds[j] = seq_hv_dot<HD>(dO, seq_hv_ld<HD>(vp + j * ldq)) * seq_dmul(dk, key, pidx + j);      // dP (under the probabilities' dropout mask)
-      rd += ds[j] * p[j];
-      if ((j & 3) == 3) { GT_SCHED_FENCE() }
-    }
-    srd[ha * 32 + ia] = rd;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const float g = p[j] * (ds[j] - rd) * scale;
-      const SeqHv<HD> kj = seq_hv_ld<HD>(kp + j * ldq);
-#pragma unroll
-      for (int c = 0; c < HD; ++c) dq.v[c] += g * kj.v[c];
-      if ((j & 3) == 3) { GT_SCHED_FENCE() }
+      const float4 t = *reinterpret_cast<const float4*>(row + 4 * ((j >> 2) ^ (ha & 7)));
+      p[j] = t.x; p[j + 1] = t.y; p[j + 2] = t.z; p[j + 3] = t.w;
     }
   }
-  GT_BARRIER();
-  if (tb) {
-    const float* qp = sQ + hb * HD;
-    const float* dop = sDO + hb * HD;
-    const float* Pcol = Pseq + (size_t)hb * 1024 + jb;
-    const uint32_t pidx = pidx_seq + (uint32_t)(hb * 1024 + jb);
-    const SeqHv<HD> v = seq_hv_ld<HD>(sQ + jb * ldq + 2 * d + hb * HD);
-    float p[32];
+  float rd = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) p[i] = Pcol[i * 32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const float mk = seq_dmul(dk, key, pidx + (uint32_t)(i * 32));
-      const SeqHv<HD> dO = seq_hv_ld<HD>(dop + i * lddo), qi = seq_hv_ld<HD>(qp + i * ldq);
-      const float pm = p[i] * mk, g = p[i] * (seq_hv_dot<HD>(dO, v) * mk - srd[hb * 32 + i]) * scale;
-#pragma unroll
-      for (int c = 0; c < HD; ++c) { dvv.v[c] += pm * dO.v[c]; dkk.v[c] += g * qi.v[c]; }
-      if ((i & 1) == 1) { GT_SCHED_FENCE() }
-    }
+  for (int j = 0; j < 32; ++j) {
+    ds[j] = seq_hv_dot<HD>(dO, seq_hv_ld<HD>(vp + j * ldq)) * (((mw >> j) & 1u) ? msc : 0.f);   // dP (under the probabilities' dropout mask; a select, no branch)
+    rd += ds[j] * p[j];
+    if ((j & 3) == 3) { GT_SCHED_FENCE() }
   }
-  GT_BARRIER();                                                 // every read of q / k / v is done: dq / dk / dv go over them
-  if (ta) {
+  srd[ha * 32 + ia] = rd;
+  reinterpret_cast<uint32_t*>(srd)[H * 32 + ha * 32 + ia] = mw;   // pass B's keep bits (behind the row sums)
 #pragma unroll
-    for (int c = 0; c < HD; ++c) sQ[ia * ldq + ha * HD + c] = dq.v[c];
+  for (int j = 0; j < 32; ++j) {
+    const float g = p[j] * (ds[j] - rd) * scale;
+    const SeqHv<HD> kj = seq_hv_ld<HD>(kp + j * ldq);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) G.dq.v[c] += g * kj.v[c];
+    if ((j & 3) == 3) { GT_SCHED_FENCE() }
   }
-  if (tb) {
+}
+template <int HD>
+__device__ __forceinline__ void seq_attn_bwd_small_b(SeqAttnSmallG<HD>& G, const float* sQ, const int ldq, const int d, const int H, const float scale,
+                                                     const float* sImg, const float* sDO, const int lddo, const SeqDropK& dk,
+                                                     const float* srd, const int krow0, const int nkrow, const int tid) {
+  if (tid >= 2 * nkrow * H) return;
+  const int pb = tid & 1, jb = krow0 + (tid >> 1) % nkrow, hb = (tid >> 1) / nkrow;        // (query half, key row, head)
+  const float msc = dk.thr ? dk.scale : 1.0f;
+  const int i0 = 16 * pb;                                      // this lane's queries: i0 .. i0 + 15
+  const float* qp = sQ + hb * HD + i0 * ldq;
+  const float* dop = sDO + hb * HD + i0 * lddo;
+  const float* rdp = srd + hb * 32 + i0;
+  const uint32_t* mwp = reinterpret_cast<const uint32_t*>(srd) + H * 32 + hb * 32 + i0;
+  // P(hb, i, jb) from pass A's LDS image (seq_attn_bwd_small_a: wave i / 4, row slot 4 h + ((i & 3) ^ (h >> 3)), 16-byte slot ^ (h & 7))
+  const float* pim = sImg + (4 * pb) * 2048 + (4 * hb) * 32 + 4 * ((jb >> 2) ^ (hb & 7)) + (jb & 3);
+  const int hx = hb >> 3;
+  const SeqHv<HD> v = seq_hv_ld<HD>(sQ + jb * ldq + 2 * d + hb * HD);
+  const uint32_t allk = dk.thr ? 0u : 1u;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) { sQ[jb * ldq + d + hb * HD + c] = dkk.v[c]; sQ[jb * ldq + 2 * d + hb * HD + c] = dvv.v[c]; }
+  for (int i = 0; i < 16; ++i) {
+    const float pi = pim[(i >> 2) * 2048 + ((i & 3) ^ hx) * 32];
+    const float mk = (((mwp[i] >> jb) | allk) & 1u) ? msc : 0.f;
+    const SeqHv<HD> dO = seq_hv_ld<HD>(dop + i * lddo), qi = seq_hv_ld<HD>(qp + i * ldq);
+    const float pm = pi * mk, g = pi * (seq_hv_dot<HD>(dO, v) * mk - rdp[i]) * scale;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { G.dvv.v[c] += pm * dO.v[c]; G.dkk.v[c] += g * qi.v[c]; }
+    if ((i & 3) == 3) { GT_SCHED_FENCE() }
+  }
+#pragma unroll
+  for (int c = 0; c < HD; ++c) { G.dvv.v[c] += seq_lane_swap1(G.dvv.v[c]); G.dkk.v[c] += seq_lane_swap1(G.dkk.v[c]); }
+}
+// every read of q / k / v is done (caller's barrier): dq / dk / dv go over them
+template <int HD>
+__device__ __forceinline__ void seq_attn_bwd_small_store(const SeqAttnSmallG<HD>& G, float* sQ, const int ldq, const int d, const int H,
+                                                         const int krow0, const int nkrow, const int tid) {
+  if (tid < 32 * H) {
+    const int ha = tid % H, ia = tid / H;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) sQ[ia * ldq + ha * HD + c] = G.dq.v[c];
+  }
+  if (tid < 2 * nkrow * H) {                                    // lane 0 of the pair stores dk_j, lane 1 dv_j
+    const int pb = tid & 1, jb = krow0 + (tid >> 1) % nkrow, hb = (tid >> 1) / nkrow;
+    float* dst = sQ + jb * ldq + (pb ? 2 * d : d) + hb * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dst[c] = pb ? G.dvv.v[c] : G.dkk.v[c];
   }
 }
 #ifndef GT_SEQ_VATTN
@@ -1248,13 +1359,13 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     const SeqB<NK> bopre = SeqB<NK>();
 #endif
     bool vattn = false;
-    if constexpr (PAD && SPLIT && GT_SEQ_VATTN) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
-      vattn = a.hd == 2 && 32 * a.H <= GT_SEQ_NT;              // (the backward's bound too: both directions take the same form)
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
+      vattn = a.hd == 2 && a.H == 16;                         // (d_model 32; the backward's P staging is written for 16 heads)
       if (vattn) {
         const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
         float* Pseq = wl + a.w0.P + (size_t)(b * a.H) * 1024;
         const uint32_t pseq = (uint32_t)(b * a.H * 1024);
-        seq_attn_fwd_small<2>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sC, SX, dk, key, rb, NROW, tid);
+        seq_attn_fwd_small<2>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sC, SX, dk, key, reinterpret_cast<uint32_t*>(wl + a.w0.amask) + b * a.H * 32, rb, NROW, tid);
       }
     }
     if (!vattn) {
@@ -1750,6 +1861,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   // from LDS; dq / dk / dv replace q / k / v of the head in place -- every wave of the round has finished reading before anyone
   // stores: third barrier), own rows of dqkv -> global (operand of the in-proj weight gradient), in-proj dgrad (K = 3 d: split over
   // the waves) -> partial tiles; ends with a barrier
+  SeqPRow prow = SeqPRow();                                  // head_dim-2 attention: this thread's P row, requested at the start of the phase
   auto attn_inproj = [&](const int l) {
     const float* kb = ws + a.pack_b + (int64_t)l * a.kstride;
     float* wl = ws + (int64_t)l * a.wstride;
@@ -1762,13 +1874,18 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
 #endif
     SeqB<8> bqpre = SeqB<8>();
     bool vattn = false;
-    if constexpr (PAD && SPLIT && GT_SEQ_VATTN) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
-      vattn = a.hd == 2 && 32 * a.H <= GT_SEQ_NT;
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
+      vattn = a.hd == 2 && a.H == 16;
       if (vattn) {                                              // (sR is free here: H x 32 row sums)
-        const uint32_t key = seq_key(dk, GT_SITE_LAYER0 + 8 * l + GT_SITE_ATTN);
-        const float* Pseq = wl + a.w0.P + (size_t)(b * a.H) * 1024;
-        const uint32_t pseq = (uint32_t)(b * a.H * 1024);
-        seq_attn_bwd_small<2>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sZ, SX, dk, key, sR, rb, NROW, tid);
+        static_assert(G::FFN >= 16 * 1024 && G::RES >= 2 * 16 * 32 && !ALIAS, "head_dim-2 attention backward: P image in the FFN tile, row sums + keep bits in sR");
+        SeqAttnSmallG<2> G;
+        seq_attn_bwd_small_a<2>(G, sQ, SQ, d, a.H, ascale, prow, sH, sZ, SX, dk, sR, tid);
+        GT_BARRIER();
+        GT_STAMP(400 + 4 * a.phase + 1);
+        seq_attn_bwd_small_b<2>(G, sQ, SQ, d, a.H, ascale, sH, sZ, SX, dk, sR, rb, NROW, tid);
+        GT_BARRIER();
+        GT_STAMP(400 + 4 * a.phase + 2);
+        seq_attn_bwd_small_store<2>(G, sQ, SQ, d, a.H, rb, NROW, tid);
 #ifndef GT_SEQ_NO_PRE4
         if (preq) bqpre = seq_splitk_first(kb, 3 * d, d, wave, lane);
 #endif
@@ -1843,10 +1960,16 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     const int l = a.L - a.phase;
     GT_STAMP(160 + 2 * a.phase);
     const int64_t hand = (int64_t)a.B * 32 * d;                                                             // floats per hand-over buffer
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) {
+      if (a.hd == 2 && a.H == 16)
+        prow = seq_attn_bwd_small_load(ws + (int64_t)l * a.wstride + a.w0.P + (size_t)(b * a.H) * 1024,
+                                       reinterpret_cast<const uint32_t*>(ws + (int64_t)l * a.wstride + a.w0.amask) + b * a.H * 32, tid);
+    }
     load_rows(sZ, SX, ws + a.dctx + ((a.phase - 1) & 1) * hand + r0 * d, d, 0, 32);                         // dctx of the whole sequence
     load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                   // its saved q / k / v
     load_rows(sDZ, SX, ws + (int64_t)l * a.tstride + a.t0.dzB + r0 * d, d, rb, NROW);                        // dz1 of layer l, own rows
     GT_BARRIER();
+    GT_STAMP(400 + 4 * a.phase);
     attn_inproj(l);
     if (l > 0) {
       chain(l - 1, false);

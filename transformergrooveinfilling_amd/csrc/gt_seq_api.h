@@ -5,7 +5,7 @@
 
 #define GT_SEQ_FMAX 512
 struct SeqLayerP { int64_t in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
-struct SeqLayerW { int64_t qkv, P, ctx, xhat1, rstd1, x1, hact, xhat2, rstd2, xout; };
+struct SeqLayerW { int64_t qkv, P, ctx, xhat1, rstd1, x1, hact, xhat2, rstd2, xout, amask; };
 struct SeqTmp { int64_t dzA, dzAm, dzB, dzBm, dhid, dqkv; };
 struct SeqArgs {
   const float* prm; float* ws; const float* pe; const float* xin; float* hvo;
