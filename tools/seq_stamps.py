@@ -77,8 +77,10 @@ if os.environ.get("GT_SEQ_SPLIT") == "1":
             b = 102 + 10 * k
             print("   load state + attention bwd %d  in-proj dgrad %d" % (st[b + 5] - st[160 + 2 * ph], st[b + 6] - st[b + 5]), end="")
             q = 400 + 4 * ph
-            if st[q] > st[160 + 2 * ph]:       # head_dim-2 attention: state tiles in LDS, pass A (dS, dq), pass B (dk, dv), store
+            if st[q] > st[160 + 2 * ph] and st[q + 1] > st[q]:   # head_dim-2 attention: state tiles in LDS, pass A (dS, dq), pass B (dk, dv), store
                 print("  [state %d  pass A %d  pass B %d  store %d]" % (st[q] - st[160 + 2 * ph], st[q + 1] - st[q], st[q + 2] - st[q + 1], st[b + 5] - st[q + 2]), end="")
+            elif st[q] > st[160 + 2 * ph]:
+                print("  [state %d  attention bwd %d]" % (st[q] - st[160 + 2 * ph], st[b + 5] - st[q]), end="")
             if ph < L:
                 c = 102 + 10 * ph
                 print("  norm2 bwd %d  FFN2 dgrad %d  FFN1 dgrad %d  norm1 bwd %d  out-proj dgrad %d" %

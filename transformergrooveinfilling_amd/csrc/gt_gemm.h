@@ -959,12 +959,15 @@ static inline int gemm_row_bm(int M, int N) { return M < GT_ROW_BM32_MIN ? 16 : 
 static inline bool gemm32row_ok(const GemmArgs& g, bool bkm);
 template <bool BKM, int EPI>
 static inline void gemm32row_launch(const GemmArgs& g, hipStream_t s);
+#ifndef GT_ROW32_BM64_MIN_WG
+#define GT_ROW32_BM64_MIN_WG 256   /* d_model 256: 64-row tiles from this many workgroups of them, 32-row tiles below */
+#endif
 #ifndef GT_ROW32_MIN_M
 #define GT_ROW32_MIN_M 8192     /* the ring-body row tiles (gt_gemm32.h) from this many tokens: 256 / 128 workgroups of 32 / 64 rows */
 #endif
 // rows per workgroup of the row-fused launch of g (the LayerNorm-backward partials table has one row per workgroup)
 static inline int gemm_row_rows(const GemmArgs& g, bool bkm) {
-  if (g.M >= GT_ROW32_MIN_M && gemm32row_ok(g, bkm)) return (g.N == 512 || g.M / 64 >= 256) ? 64 : 32;
+  if (g.M >= GT_ROW32_MIN_M && gemm32row_ok(g, bkm)) return (g.N == 512 || g.M / 64 >= GT_ROW32_BM64_MIN_WG) ? 64 : 32;
   return gemm_row_bm(g.M, g.N);
 }
 template <bool AKM, bool BKM, int EPI>

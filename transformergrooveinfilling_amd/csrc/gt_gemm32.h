@@ -524,7 +524,7 @@ static inline void gemm32row_launch(const GemmArgs& g, hipStream_t s) {
   gt_prof_tag(gemm_label<BKM, EPI>(), 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + 3.0 * g.M * g.N));
   // 64-row tiles once they fill the chip (one workgroup per CU at d_model 512: 132 KB of LDS); 32-row tiles below that at 256
   if (g.N == 512) gt_launch(gemm32row_kernel<512, 2, BKM, EPI>, dim3(g.M / 64), dim3(512), s, g);
-  else if (g.M / 64 >= 256) gt_launch(gemm32row_kernel<256, 2, BKM, EPI>, dim3(g.M / 64), dim3(512), s, g);
+  else if (g.M / 64 >= GT_ROW32_BM64_MIN_WG) gt_launch(gemm32row_kernel<256, 2, BKM, EPI>, dim3(g.M / 64), dim3(512), s, g);
   else gt_launch(gemm32row_kernel<256, 1, BKM, EPI>, dim3(g.M / 32), dim3(512), s, g);
 }
 

@@ -802,12 +802,28 @@ __device__ __forceinline__ void seq_attn_fwd(const SeqAttn& a, float* ctx, const
     for (int r = 0; r < 4; ++r) { if (!PAD || 16 * ct + l16 < hdr) orow[r * ldc + 16 * ct] = o[ct][r]; }
 }
 
+// The P values a wave's two backward roles read (its query tile's rows as 16-byte runs, its key tile's columns), for a caller that
+// requests them ahead of the attention backward: P was written a forward phase ago through another L2 and is the coldest operand of the
+// stage (SPLIT phases: requested before the state tiles, seq_attn_p_load).
+struct SeqPPre { float4 pv[2]; float pc[8]; };
+__device__ __forceinline__ SeqPPre seq_attn_p_load(const float* P, const int w, const int lane) {
+  SeqPPre r;
+  const int l16 = lane & 15, g = lane >> 4, i = 16 * w + l16;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) r.pv[tj] = *reinterpret_cast<const float4*>(P + (unsigned)(i * 32 + 16 * tj + 4 * g));
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.pc[4 * ti + q] = P[(unsigned)((16 * ti + 4 * g + q) * 32 + i)];
+  return r;
+}
 // Backward, two roles per wave with a workgroup barrier between them (gt_attn.h): role 1 (query tile w) -> dq in registers and
 // the row sums rd -> srd (32 floats of LDS per head); role 2 (key tile w) -> dk, dv in registers; after another barrier
 // seq_attn_bwd_store writes dq / dk / dv over q / k / v of the head (the dqkv tile IS the qkv tile).
 template <int HD, bool PAD>
 __device__ __forceinline__ void seq_attn_bwd1(const SeqAttn& a, const float* dctx, const int lddc, const SeqDropK& dk, const uint32_t key,
-                                              const int w, const int lane, float* srd, f32x4 (&dq_out)[HD / 16]) {
+                                              const int w, const int lane, float* srd, f32x4 (&dq_out)[HD / 16],
+                                              const bool have_p = false, const SeqPPre& pp = SeqPPre()) {
   constexpr int NQ = HD / 16;
   const int hdr = PAD ? a.hd : HD;
   const int l16 = lane & 15, g = lane >> 4;
@@ -831,7 +847,7 @@ __device__ __forceinline__ void seq_attn_bwd1(const SeqAttn& a, const float* dct
       for (int c = 0; c < 4; ++c) kb[ct][tj][c] = seq_ld1<PAD>(kcol + (16 * tj + c) * a.ldq + 16 * ct, 16 * ct + l16, hdr);
   float4 pv[2];
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj) pv[tj] = *reinterpret_cast<const float4*>(a.P + (unsigned)(i * 32 + 16 * tj + 4 * g));
+  for (int tj = 0; tj < 2; ++tj) { if (have_p) pv[tj] = pp.pv[tj]; else pv[tj] = *reinterpret_cast<const float4*>(a.P + (unsigned)(i * 32 + 16 * tj + 4 * g)); }
   f32x4 dt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};           // dPd^T tiles [tj]
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -869,7 +885,8 @@ __device__ __forceinline__ void seq_attn_bwd1(const SeqAttn& a, const float* dct
 }
 template <int HD, bool PAD>
 __device__ __forceinline__ void seq_attn_bwd2(const SeqAttn& a, const float* dctx, const int lddc, const SeqDropK& dk, const uint32_t key,
-                                              const int w, const int lane, const float* srd, f32x4 (&dk_out)[HD / 16], f32x4 (&dv_out)[HD / 16]) {
+                                              const int w, const int lane, const float* srd, f32x4 (&dk_out)[HD / 16], f32x4 (&dv_out)[HD / 16],
+                                              const bool have_p = false, const SeqPPre& pp = SeqPPre()) {
   constexpr int NQ = HD / 16;
   const int hdr = PAD ? a.hd : HD;
   const int l16 = lane & 15, g = lane >> 4;
@@ -901,7 +918,7 @@ __device__ __forceinline__ void seq_attn_bwd2(const SeqAttn& a, const float* dct
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 16 * ti + 4 * g + r;
-      pvv[ti][r] = a.P[(unsigned)(i * 32 + j)];
+      pvv[ti][r] = have_p ? pp.pc[4 * ti + r] : a.P[(unsigned)(i * 32 + j)];
       rdv[ti][r] = srd[i];
     }
   f32x4 dd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};           // dPd tiles [ti]
@@ -1178,6 +1195,9 @@ __device__ __forceinline__ void seq_attn_bwd_small_store(const SeqAttnSmallG<HD>
     for (int c = 0; c < HD; ++c) dst[c] = pb ? G.dvv.v[c] : G.dkk.v[c];
   }
 }
+#ifndef GT_SEQ_PPRE
+#define GT_SEQ_PPRE 0           /* 1: SPLIT backward phases request the MFMA attention backward's P values ahead of the state tiles (measured: slower, tools/rejected/README.md) */
+#endif
 #ifndef GT_SEQ_VATTN
 #define GT_SEQ_VATTN 1          /* 0: head_dim < 16 stays on the zero-padded MFMA form */
 #endif
@@ -1862,6 +1882,8 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   // stores: third barrier), own rows of dqkv -> global (operand of the in-proj weight gradient), in-proj dgrad (K = 3 d: split over
   // the waves) -> partial tiles; ends with a barrier
   SeqPRow prow = SeqPRow();                                  // head_dim-2 attention: this thread's P row, requested at the start of the phase
+  SeqPPre ppre = SeqPPre();                                  // MFMA attention: the wave's P values of the first round of heads, likewise
+  bool have_ppre = false;
   auto attn_inproj = [&](const int l) {
     const float* kb = ws + a.pack_b + (int64_t)l * a.kstride;
     float* wl = ws + (int64_t)l * a.wstride;
@@ -1900,9 +1922,10 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
         at.q = sQ + h * a.hd; at.k = at.q + d; at.v = at.q + 2 * d; at.ldq = SQ; at.hd = a.hd; at.scale = ascale;
         at.pidx = (uint32_t)((b * a.H + h) * 1024); at.P = wl + a.w0.P + (size_t)(b * a.H + h) * 1024;
         f32x4 dq_out[HD / 16], dk_out[HD / 16], dv_out[HD / 16];
-        if (active) seq_attn_bwd1<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dq_out);
+        const bool hp = have_ppre && h4 == 0;                          // (the first round's P values were requested at the start of the phase)
+        if (active) seq_attn_bwd1<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dq_out, hp, ppre);
         GT_BARRIER();
-        if (active) seq_attn_bwd2<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dk_out, dv_out);
+        if (active) seq_attn_bwd2<HD, PAD>(at, sZ + h * a.hd, SX, dk, key, wave & 1, lane, srd + 32 * (wave >> 1), dk_out, dv_out, hp, ppre);
 #ifndef GT_SEQ_NO_PRE4
         // the in-proj dgrad's first chunk: in flight across the two barriers, the dq / dk / dv store and the dqkv tile's way to global
         if (preq && h4 + GT_SEQ_WAVES / 2 >= a.H) bqpre = seq_splitk_first(kb, 3 * d, d, wave, lane);
@@ -1960,6 +1983,12 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     const int l = a.L - a.phase;
     GT_STAMP(160 + 2 * a.phase);
     const int64_t hand = (int64_t)a.B * 32 * d;                                                             // floats per hand-over buffer
+    bool vpre = false;
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) vpre = a.hd == 2 && a.H == 16;
+    if (GT_SEQ_PPRE && !vpre && (wave >> 1) < a.H) {
+      ppre = seq_attn_p_load(ws + (int64_t)l * a.wstride + a.w0.P + (size_t)(b * a.H + (wave >> 1)) * 1024, wave & 1, lane);
+      have_ppre = true;
+    }
     if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) {
       if (a.hd == 2 && a.H == 16)
         prow = seq_attn_bwd_small_load(ws + (int64_t)l * a.wstride + a.w0.P + (size_t)(b * a.H) * 1024,
