@@ -161,10 +161,11 @@ def test_sequence_resident_kernels(cfg, B, p):
 
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(128, 4, 512, 2), 1, 0.24), (cfg_dict(128, 16, 48, 3), 2, 0.1), (cfg_dict(128, 2, 32, 1), 1, 0.0),
                                      (cfg_dict(32, 16, 512, 2), 2, 0.24), (cfg_dict(32, 2, 32, 1), 1, 0.1), (cfg_dict(32, 1, 16, 2), 3, 0.0),
-                                     # head_dim 2 in SPLIT mode (d_model 32 / 128 only) runs its attention on the vector ALU, one thread per
+                                     # head_dim 2 in SPLIT mode (d_model 32, 16 heads) runs its attention on the vector ALU, two threads per
                                      # (row, head): the ClosedHH YAML shape above and its F 256 sibling; d_model 128 with 64 heads of 2
                                      # (32 x 64 pairs > 512 threads) falls back to the zero-padded MFMA form -- there also through QUAD
-                                     (cfg_dict(32, 16, 256, 1), 3, 0.1), (cfg_dict(128, 64, 32, 1), 1, 0.1)])
+                                     (cfg_dict(32, 16, 256, 1), 3, 0.1), (cfg_dict(128, 64, 32, 1), 1, 0.1),
+                                     (cfg_dict(32, 16, 64, 1), 1, 0.0)])     # head_dim 2 without dropout: the saved keep bits are read and overruled
 def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
     """d_model 128 / 32, SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels.
     At d_model 128 "split" also means: weight gradients as rider workgroups of the backward phases + the tail launch (gt_seq_wg.h)"""

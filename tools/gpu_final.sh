@@ -22,7 +22,7 @@ python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp.json 2>/dev/nul
 GT_DP_GRAPH=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_graph.json 2>/dev/null
 GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_overlap.json 2>/dev/null
 GT_DP_GRAPH=1 GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_overlap_graph.json 2>/dev/null
-for i in 0 1; do GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py $i > $O/seq_stamps_$i.txt 2>&1; done
+for i in 0 1; do GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py $i > $O/seq_stamps_$i.txt 2>&1; done     # (the shipped path of these shapes: SPLIT)
 GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py 2 > $O/seq_stamps_c2.txt 2>&1
 python tools/wg_unit_bench.py 64 > $O/wg_unit_bench.txt 2>&1
 for i in 0 1 4 6 9; do python tools/class_profile.py $i > $O/class_profile_$i.txt 2>&1; done

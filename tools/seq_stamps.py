@@ -30,23 +30,24 @@ off, cnt = eng.lib.ws_find(s.cfg, "stamps")
 st = s.ws[off:off + cnt].cpu().numpy().view(np.int64)
 L = dims["num_encoder_layers"]
 print(name, "(shader-clock cycles, workgroup 0; 1000 cycles = 0.42 us at 2.4 GHz)")
-fl = ["in-proj", "attention", "out-proj(+ctx copy)", "norm1", "FFN1", "FFN2 split-K", "norm2"]
-print(" forward: input tile load %d, input layer %d, total %d" % (st[1] - st[0], st[2] - st[1], st[2 + 10 * L] - st[0]))
-for l in range(L):
-    b = 2 + 10 * l
-    d = [int(st[b + i + 1] - st[b + i]) for i in range(7)]
-    print("  layer %d: " % l + "  ".join("%s %d" % (n, c) for n, c in zip(fl, d)) + "   = %d" % sum(d))
-print("  final norm + output layer %d" % (st[2 + 10 * L] - st[2 + 10 * (L - 1) + 7]))
-bl = ["norm2 bwd", "FFN2 dgrad", "FFN1 dgrad split-K", "norm1 bwd", "out-proj dgrad", "attention bwd", "in-proj dgrad split-K"]
-print(" backward: output-layer dgrad + final norm %d, total %d" % (st[101] - st[100], st[102 + 10 * L] - st[100]))
-prev = st[101]
-for k in range(L):
-    b = 102 + 10 * k
-    t = [prev] + [int(st[b + i]) for i in range(7)]
-    d = [int(t[i + 1] - t[i]) for i in range(7)]
-    prev = st[b + 6]
-    print("  layer %d: " % (L - 1 - k) + "  ".join("%s %d" % (n, c) for n, c in zip(bl, d)) + "   = %d" % sum(d))
-print("  input-layer epilogue %d" % (st[102 + 10 * L] - prev))
+if os.environ.get("GT_SEQ_SPLIT") != "1":       # one workgroup per sequence: one launch forward, one backward
+    fl = ["in-proj", "attention", "out-proj(+ctx copy)", "norm1", "FFN1", "FFN2 split-K", "norm2"]
+    print(" forward: input tile load %d, input layer %d, total %d" % (st[1] - st[0], st[2] - st[1], st[2 + 10 * L] - st[0]))
+    for l in range(L):
+        b = 2 + 10 * l
+        d = [int(st[b + i + 1] - st[b + i]) for i in range(7)]
+        print("  layer %d: " % l + "  ".join("%s %d" % (n, c) for n, c in zip(fl, d)) + "   = %d" % sum(d))
+    print("  final norm + output layer %d" % (st[2 + 10 * L] - st[2 + 10 * (L - 1) + 7]))
+    bl = ["norm2 bwd", "FFN2 dgrad", "FFN1 dgrad split-K", "norm1 bwd", "out-proj dgrad", "attention bwd", "in-proj dgrad split-K"]
+    print(" backward: output-layer dgrad + final norm %d, total %d" % (st[101] - st[100], st[102 + 10 * L] - st[100]))
+    prev = st[101]
+    for k in range(L):
+        b = 102 + 10 * k
+        t = [prev] + [int(st[b + i]) for i in range(7)]
+        d = [int(t[i + 1] - t[i]) for i in range(7)]
+        prev = st[b + 6]
+        print("  layer %d: " % (L - 1 - k) + "  ".join("%s %d" % (n, c) for n, c in zip(bl, d)) + "   = %d" % sum(d))
+    print("  input-layer epilogue %d" % (st[102 + 10 * L] - prev))
 
 sub = st[200:216]
 if sub[0]:

@@ -177,7 +177,6 @@ extern "C" int gt_param_layout(const gt_config* cfg, int64_t* offsets, int64_t* 
 // ------------------------------------------------------------------------------------ workspace layout
 struct LayerW {
   int64_t qkv, P, ctx, xhat1, rstd1, x1;            // self-attention block
-  int64_t amask;                                    // dropout keep bits of P, one word per (sequence, head, query): head_dim-2 attention of gt_seq.h
   int64_t qx, kvx, Px, ctxx, xhatx, rstdx, x2;      // decoder cross-attention block
   int64_t hact, xhat2, rstd2, xout;                 // FFN block (xhat2/rstd2 = the layer's LAST norm)
 };
@@ -188,6 +187,7 @@ struct WLayout {
   int64_t pack_f = -1, pack_b = -1, pack_stride = 0;   // fragment-ordered weight copies of the sequence-resident kernels (gt_seq.h)
   int64_t seq_dctx = -1;                               // hand-over buffer of their two-workgroups-per-sequence (SPLIT) backward phases
   int64_t seq_xchg = -1, seq_xchg_n = 0;               // pair-exchange region of their four-workgroups-per-sequence (QUAD) forward
+  int64_t seq_amask = -1, seq_amask_stride = 0;        // dropout keep bits of P, one word per (layer, sequence, head, query): their head_dim-2 attention
   // bf16 shadows (precision = 1, bf16_shadows()): fp32 tensor offset -> offset (in floats) of its bf16 copy, for the activations whose
   // producers write one; w16 / w16t: the encoder layers' four matrices and their transposes, [in_w | out_w | w1 | w2] per layer
   std::vector<std::pair<int64_t, int64_t>> sh;
@@ -243,17 +243,21 @@ static bool bf16_shadows(const gt_config& c) {
   return on && attn_mfma && wgrad_deferred(c) && c.precision == 1 && c.n_enc_layers > 0 && (c.d_model == 256 || c.d_model == 512) && c.dim_ff % 128 == 0 &&
          M % 128 == 0 && (hd == 16 || hd == 32 || hd == 64 || hd == 128) && (M / 128) * (nmin / 128) >= GT_T128H_MIN;
 }
+#ifndef GT_WS_SKEW
+#define GT_WS_SKEW 0
+#endif
 static WLayout ws_layout(const gt_config& c) {
   WLayout W;
   int64_t cur = 0;
-  auto add = [&](int64_t n) { int64_t o = cur; cur += (n + 63) / 64 * 64; return o; };
+  static const int64_t skew = [] { const char* e = getenv("GT_WS_SKEW"); return e ? (int64_t)atoll(e) / 64 * 64 : (int64_t)GT_WS_SKEW; }();   // floats between consecutive buffers
+  auto add = [&](int64_t n) { int64_t o = cur; cur += (n + 63) / 64 * 64 + skew; return o; };
   const int64_t M = (int64_t)c.batch * 32, d = c.d_model, F = c.dim_ff, BH = (int64_t)c.batch * c.n_heads;
   W.x0 = add(M * d); W.a0 = add(M * d);
   const int nl = c.n_enc_layers + c.n_dec_layers;
   W.layers.resize(nl);
   for (int l = 0; l < nl; ++l) {
     LayerW& w = W.layers[l];
-    w.qkv = add(M * 3 * d); w.P = add(BH * 1024); w.ctx = add(M * d); w.amask = add(BH * 32);
+    w.qkv = add(M * 3 * d); w.P = add(BH * 1024); w.ctx = add(M * d);
     w.xhat1 = add(M * d); w.rstd1 = add(M); w.x1 = add(M * d);
     if (l >= c.n_enc_layers) {
       w.qx = add(M * d); w.kvx = add(M * 2 * d); w.Px = add(BH * 1024); w.ctxx = add(M * d);
@@ -293,6 +297,7 @@ static WLayout ws_layout(const gt_config& c) {
     W.pack_f = add(W.pack_stride * c.n_enc_layers); W.pack_b = add(W.pack_stride * c.n_enc_layers);
     W.seq_dctx = add(2 * M * d);
     if (d == 128) { W.seq_xchg_n = gt_seq_xchg_floats(c.batch); W.seq_xchg = add(W.seq_xchg_n); }
+    if (d == 32 && c.n_heads == 16) { W.seq_amask_stride = BH * 32; W.seq_amask = add(W.seq_amask_stride * c.n_enc_layers); }   // (behind everything else: no other offset moves)
   }
   if (bf16_shadows(c)) {
     auto sh = [&](int64_t off, int64_t n) { W.sh.emplace_back(off, add((n + 1) / 2)); };
@@ -368,6 +373,7 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   else if (n == "dec_final") set(W.dec_final, M * d); else if (n == "dlogits") set(W.dlogits, M * GT_TGT);
   else if (n == "dmem") set(W.dmem, M * d); else if (n == "dctx") set(W.dctx, M * d);
   else if (n == "seq_xchg") set(W.seq_xchg, W.seq_xchg_n);
+  else if (n == "amask" && W.seq_amask >= 0) set(W.seq_amask, W.seq_amask_stride * c.n_enc_layers);
   else if (n == "pack_f" && W.pack_f >= 0) set(W.pack_f, W.pack_stride * c.n_enc_layers);
   else if (n == "pack_b" && W.pack_b >= 0) set(W.pack_b, W.pack_stride * c.n_enc_layers);
 #ifdef GT_SEQ_STAMPS
@@ -384,7 +390,6 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
     if (layer < 0 || layer >= (int)W.layers.size()) return gt_fail("gt_ws_find: layer %d out of range", layer);
     const LayerW& w = W.layers[layer];
     if (n == "qkv") set(w.qkv, M * 3 * d); else if (n == "P") set(w.P, BH * 1024); else if (n == "ctx") set(w.ctx, M * d);
-    else if (n == "amask") set(w.amask, BH * 32);
     else if (n == "xhat1") set(w.xhat1, M * d); else if (n == "rstd1") set(w.rstd1, M); else if (n == "x1") set(w.x1, M * d);
     else if (n == "qx") set(w.qx, M * d); else if (n == "kvx") set(w.kvx, M * 2 * d); else if (n == "Px") set(w.Px, BH * 1024);
     else if (n == "ctxx") set(w.ctxx, M * d); else if (n == "xhatx") set(w.xhatx, M * d); else if (n == "x2") set(w.x2, M * d);
@@ -925,7 +930,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.p0 = SeqLayerP{p.sa.in_w, p.sa.in_b, p.sa.out_w, p.sa.out_b, p.w1, p.b1, p.w2, p.b2, p.n1w, p.n1b, p.n2w, p.n2b};
   a.pstride = x.c.n_enc_layers > 1 ? x.P.enc[1].sa.in_w - p.sa.in_w : x.P.encn_w - p.sa.in_w;   // (one layer: its span -- the update kernel's range test)
   const LayerW& w = x.W.layers[0];
-  a.w0 = SeqLayerW{w.qkv, w.P, w.ctx, w.xhat1, w.rstd1, w.x1, w.hact, w.xhat2, w.rstd2, w.xout, w.amask};
+  a.w0 = SeqLayerW{w.qkv, w.P, w.ctx, w.xhat1, w.rstd1, w.x1, w.hact, w.xhat2, w.rstd2, w.xout};
   a.wstride = x.c.n_enc_layers > 1 ? x.W.layers[1].qkv - w.qkv : 0;
   const WLayout::TmpSet& t = x.W.set[0];
   a.t0 = SeqTmp{t.dzA, t.dzAm, t.dzB, t.dzBm, t.dhid, t.dqkv};
@@ -935,7 +940,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.dlogits = x.W.dlogits; a.da0 = x.W.dctx; a.ln_part = x.W.ln_part; a.ln_part_stride = x.W.ln_part_stride;
   a.stamps = x.W.stamps;
   a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
-  a.dctx = x.W.seq_dctx; a.xchg = x.W.seq_xchg; a.phase = 0;
+  a.dctx = x.W.seq_dctx; a.xchg = x.W.seq_xchg; a.amask = x.W.seq_amask; a.amask_stride = x.W.seq_amask_stride; a.phase = 0;
   a.loss_y = nullptr; a.loss_penalty = 0.f; a.loss_stats = nullptr; a.loss_part = nullptr; a.loss_ticket = nullptr;
   a.grd = nullptr; a.nseq = 0; a.wg_accumulate = 0; a.ride_last_k = x.M; a.out_early = 0; a.tail_phase = 0; a.tail_ksplit = 1; a.ln_nwg = 0; a.bump = nullptr;
   return a;

@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
         float* Pseq = wl + a.w0.P + (size_t)(b * a.H) * 1024;
         const uint32_t pseq = (uint32_t)(b * a.H * 1024);
-        seq_attn_fwd_small<2>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sC, SX, dk, key, reinterpret_cast<uint32_t*>(wl + a.w0.amask) + b * a.H * 32, rb, NROW, tid);
+        seq_attn_fwd_small<2>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sC, SX, dk, key, reinterpret_cast<uint32_t*>(ws + a.amask + (int64_t)l * a.amask_stride) + b * a.H * 32, rb, NROW, tid);
       }
     }
     if (!vattn) {
@@ -1992,7 +1992,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) {
       if (a.hd == 2 && a.H == 16)
         prow = seq_attn_bwd_small_load(ws + (int64_t)l * a.wstride + a.w0.P + (size_t)(b * a.H) * 1024,
-                                       reinterpret_cast<const uint32_t*>(ws + (int64_t)l * a.wstride + a.w0.amask) + b * a.H * 32, tid);
+                                       reinterpret_cast<const uint32_t*>(ws + a.amask + (int64_t)l * a.amask_stride) + b * a.H * 32, tid);
     }
     load_rows(sZ, SX, ws + a.dctx + ((a.phase - 1) & 1) * hand + r0 * d, d, 0, 32);                         // dctx of the whole sequence
     load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                   // its saved q / k / v

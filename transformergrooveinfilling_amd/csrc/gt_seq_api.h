@@ -5,7 +5,7 @@
 
 #define GT_SEQ_FMAX 512
 struct SeqLayerP { int64_t in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
-struct SeqLayerW { int64_t qkv, P, ctx, xhat1, rstd1, x1, hact, xhat2, rstd2, xout, amask; };
+struct SeqLayerW { int64_t qkv, P, ctx, xhat1, rstd1, x1, hact, xhat2, rstd2, xout; };
 struct SeqTmp { int64_t dzA, dzAm, dzB, dzBm, dhid, dqkv; };
 struct SeqArgs {
   const float* prm; float* ws; const float* pe; const float* xin; float* hvo;
@@ -22,6 +22,7 @@ struct SeqArgs {
   int64_t dctx;                                              // SPLIT kernels: two [M][d] hand-over buffers of the backward phases (phase p writes
                                                              // buffer p & 1 and reads the other: a fast workgroup must not overwrite rows its
                                                              // partner has yet to read)
+  int64_t amask, amask_stride;                               // head_dim-2 attention: keep bits of P, [layer][sequence][head][query] words (-1: absent)
   int64_t xchg;                                              // QUAD forward: the pair-exchange region (8 header granules, then one 16 KB slot per
                                                              // workgroup; zero between launches -- gt_workspace_init); -1: none
   int quad_pro;                                              // QUAD forward: input layer + in-proj(0) ran as a prologue launch (phase -1)
