@@ -211,7 +211,8 @@ def test_small_models_on_the_one_kernel_per_op_path(cfg, B, p):
 
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(128, 4, 512, 3), 64, 0.24), (cfg_dict(128, 16, 48, 2), 7, 0.1), (cfg_dict(128, 2, 32, 1), 3, 0.0),
                                      (cfg_dict(128, 8, 128, 4, embedding_size_src=27), 33, 0.2), (YAML_HH, 16, 0.24), (C1, 32, 0.18),
-                                     (cfg_dict(32, 2, 256, 2, embedding_size_src=27), 5, 0.1), (cfg_dict(32, 1, 16, 1), 2, 0.0)])
+                                     (cfg_dict(32, 2, 256, 2, embedding_size_src=27), 5, 0.1), (cfg_dict(32, 1, 16, 1), 2, 0.0),
+                                     (cfg_dict(32, 16, 64, 1), 2, 0.0)])      # head_dim 2 without dropout (saved keep bits read and overruled)
 def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
     parity.check_step("hip", cfg, B, p, seq="split")
     parity.check_step("hip", cfg, B, p, seq="whole")
