@@ -17,7 +17,9 @@ ENCDEC = cfg_dict(32, 4, 16, 2, 2)
                                      (cfg_dict(128, 4, 48, 1), 1, 0.0),     # row-tile 128
                                      (cfg_dict(256, 2, 16, 1), 1, 0.0),     # row-tile 256, head_dim 128
                                      (cfg_dict(32, 2, 16, 1, 1), 2, 0.2),   # enc-dec, head_dim 16: causal + cross attention on MFMA
-                                     (cfg_dict(64, 2, 16, 1, 1), 1, 0.0)])  # enc-dec, head_dim 32
+                                     (cfg_dict(64, 2, 16, 1, 1), 1, 0.0),   # enc-dec, head_dim 32
+                                     (cfg_dict(256, 2, 16, 1), 2, 0.15),    # head_dim 128 under dropout: four wave pairs per (sequence, head), column tiles split
+                                     (cfg_dict(128, 2, 16, 1, 1), 1, 0.1)]) # enc-dec, head_dim 64: the same split with causal + cross attention
 def test_step_parity(cfg, B, p):
     parity.check_step("emu", cfg, B, p)
 

@@ -724,6 +724,19 @@ static int attn_mfma_hd(const Ctx& x) {
   if (hd == 16 || hd == 32 || hd == 64 || hd == 128) return hd;
   return hd < 16 ? -16 : 0;                         // -16: the 16-wide kernels with zero-padded operands (head_dim 1..15)
 }
+// Attention backward with fewer (sequence, head) pairs than CUs and head_dim 64 / 128 (the reference's d_model-256 YAMLs: 2 heads of 128,
+// batch 32 = 64 pairs): the LDS-staged kernel with four wave pairs per (sequence, head) -- each repeats the dP contraction of its tile from
+// LDS and takes a quarter of the head's column tiles (gt_attn.h, CS).  10.5 -> 10.0 us per launch at 64 pairs: the stage is a latency
+// floor (launch, cold operands, three barriers), not a parallelism problem -- the same split on the register-fragment kernels, forward
+// and backward, was SLOWER (5.8 -> 8.4 / 10.5 -> 16.1 us: every wave repeats the contraction's loads; tools/rejected/README.md).
+#ifndef GT_ATTN_CS_MAX_PAIRS
+#define GT_ATTN_CS_MAX_PAIRS 256
+#endif
+static bool attn_col_split(const Ctx& x, int pairs) {
+  static const int on = [] { const char* e = getenv("GT_ATTN_CS"); return (e && e[0] == '0') ? 0 : 1; }();
+  const int hd = attn_mfma_hd(x);
+  return on && (hd == 64 || hd == 128) && pairs < GT_ATTN_CS_MAX_PAIRS;
+}
 static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, float* P, float* ctx,
                           int causal, int site) {
   AttnArgs a;
@@ -760,9 +773,14 @@ static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k,
   // head_dim 64 with the chip full: the LDS-staged form (every operand byte requested once, 16 bytes at a time)
   static const int lds_min = [] { const char* e = getenv("GT_ATTN_BWD_LDS_MIN"); return e ? atoi(e) : GT_ATTN_BWD_LDS_MIN; }();
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (attn_mfma_hd(x) == 64 && (int)grid.x >= lds_min && ((ldq | ldkv | lddq | lddkv | x.d) & 3) == 0 && al16(q) && al16(k) && al16(v) &&
-      al16(dctx) && al16(dq) && al16(dk) && al16(dv)) {
+  const bool lds_ok = ((ldq | ldkv | lddq | lddkv | x.d) & 3) == 0 && al16(q) && al16(k) && al16(v) && al16(dctx) && al16(dq) && al16(dk) && al16(dv);
+  if (attn_mfma_hd(x) == 64 && (int)grid.x >= lds_min && lds_ok) {
     gt_launch(attn_bwd_lds_kernel<64>, grid, dim3(128), x.s, a);
+    return;
+  }
+  if (attn_col_split(x, (int)grid.x) && lds_ok) {     // few pairs, wide heads: LDS-staged operands, four wave pairs per pair
+    if (attn_mfma_hd(x) == 128) gt_launch(attn_bwd_lds_kernel<128, 4>, grid, dim3(512), x.s, a);
+    else gt_launch(attn_bwd_lds_kernel<64, 4>, grid, dim3(512), x.s, a);
     return;
   }
   switch (attn_mfma_hd(x)) {

@@ -315,10 +315,11 @@ __device__ __forceinline__ AttnOps attn_ops_global(const AttnArgs& a, const int 
   const int hc = (bh % a.H) * hdr;
   return AttnOps{a.q + row0 * a.ldq + hc, a.k + row0 * a.ldk + hc, a.v + row0 * a.ldv + hc, a.dctx + row0 * a.lddc + hc, a.ldq, a.ldk, a.ldv, a.lddc};
 }
-template <int HD, bool PAD>
+template <int HD, bool PAD, int CS = 1>
 __device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const AttnOps& op, const int bh, const int w, const int lane, float* srd,
-                                                    f32x4 (&dq_out)[HD / 16]) {
-  constexpr int NQ = HD / 16;
+                                                    f32x4 (&dq_out)[HD / 16 / CS], const int cs = 0) {
+  constexpr int NQ = HD / 16, NC = NQ / CS;                  // (CS: column split of attn_bwd_lds_kernel -- dP is every wave pair's, the dq column tiles are split)
+  const int ct0 = cs * NC;
   const int hdr = PAD ? a.hd : HD;
   const float* const zp = gt_zero_ptr();
   const int l16 = lane & 15, g = lane >> 4;
@@ -338,13 +339,13 @@ __device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const Att
       v1[q] = attn_ld4<PAD>(vrow + (size_t)16 * op.ldv + 16 * q, 16 * q + 4 * g, hdr, zp);
     }
     const float* __restrict__ kcol = op.k + (size_t)(4 * g) * op.ldk + l16;
-    float kb[NQ][2][4];
+    float kb[NC][2][4];
 #pragma unroll
-    for (int ct = 0; ct < NQ; ++ct)
+    for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) kb[ct][tj][c] = attn_ld1<PAD>(kcol + (size_t)(16 * tj + c) * op.ldk + 16 * ct, 16 * ct + l16, hdr, zp);
+        for (int c = 0; c < 4; ++c) kb[ct][tj][c] = attn_ld1<PAD>(kcol + (size_t)(16 * tj + c) * op.ldk + 16 * (ct0 + ct), 16 * (ct0 + ct) + l16, hdr, zp);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       dt[0] = GT_MFMA16(v0[q].x, df[q].x, dt[0]); dt[1] = GT_MFMA16(v1[q].x, df[q].x, dt[1]);
@@ -365,15 +366,15 @@ __device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const Att
       }
     }
     rd += __shfl_xor(rd, 16); rd += __shfl_xor(rd, 32);
-    if (g == 0) srd[i] = rd;
+    if (g == 0 && (CS == 1 || cs == 0)) srd[i] = rd;
     float ds[2][4];
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[tj][r] = p[tj][r] * (dp[tj][r] - rd) * a.scale;
-    f32x4 o[NQ];
+    f32x4 o[NC];
 #pragma unroll
-    for (int ct = 0; ct < NQ; ++ct) {
+    for (int ct = 0; ct < NC; ++ct) {
       o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
@@ -383,14 +384,15 @@ __device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const Att
     // the dq stores wait until role 2 has issued its loads (dq may share a buffer with k / v: packed dqkv next to qkv is not
     // the case here, but the compiler cannot know) -- they are written at the very end of the kernel
 #pragma unroll
-    for (int ct = 0; ct < NQ; ++ct) dq_out[ct] = o[ct];
+    for (int ct = 0; ct < NC; ++ct) dq_out[ct] = o[ct];
   }
 }
 // (dv / dk of key tile w are returned in registers: the caller stores them -- and role 1's dq -- see attn_bwd_store_direct)
-template <int HD, bool PAD>
+template <int HD, bool PAD, int CS = 1>
 __device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const AttnOps& op, const int bh, const int w, const int lane, const float* srd,
-                                                    f32x4 (&ov)[HD / 16], f32x4 (&ok)[HD / 16]) {
-  constexpr int NQ = HD / 16;
+                                                    f32x4 (&ov)[HD / 16 / CS], f32x4 (&ok)[HD / 16 / CS], const int cs = 0) {
+  constexpr int NQ = HD / 16, NC = NQ / CS;
+  const int ct0 = cs * NC;
   const int hdr = PAD ? a.hd : HD;
   const float* const zp = gt_zero_ptr();
   const int l16 = lane & 15, g = lane >> 4;
@@ -410,15 +412,15 @@ __device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const Att
     }
     const float* __restrict__ docol = op.dctx + (size_t)(4 * g) * op.lddc + l16;
     const float* __restrict__ qcol = op.q + (size_t)(4 * g) * op.ldq + l16;
-    float db[NQ][2][4], qb[NQ][2][4];
+    float db[NC][2][4], qb[NC][2][4];
 #pragma unroll
-    for (int ct = 0; ct < NQ; ++ct)
+    for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          db[ct][ti][c] = attn_ld1<PAD>(docol + (size_t)(16 * ti + c) * op.lddc + 16 * ct, 16 * ct + l16, hdr, zp);
-          qb[ct][ti][c] = attn_ld1<PAD>(qcol + (size_t)(16 * ti + c) * op.ldq + 16 * ct, 16 * ct + l16, hdr, zp);
+          db[ct][ti][c] = attn_ld1<PAD>(docol + (size_t)(16 * ti + c) * op.lddc + 16 * (ct0 + ct), 16 * (ct0 + ct) + l16, hdr, zp);
+          qb[ct][ti][c] = attn_ld1<PAD>(qcol + (size_t)(16 * ti + c) * op.ldq + 16 * (ct0 + ct), 16 * (ct0 + ct) + l16, hdr, zp);
         }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -440,7 +442,7 @@ __device__ __forceinline__ void attn_bwd_mfma_role2(const AttnArgs& a, const Att
         ds[ti][r] = pv * (dd[ti][r] * mk - srd[i]) * a.scale;
       }
 #pragma unroll
-    for (int ct = 0; ct < NQ; ++ct) {
+    for (int ct = 0; ct < NC; ++ct) {
       ov[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
@@ -506,17 +508,20 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
 // times, the column-major fragments 4 bytes at a time: L2 absorbs that, but at d_model 512 it held the kernel to 3.2 TB/s), the
 // fragments then come from LDS (row stride HD + 4: the 16 rows of a fragment read fall in different banks), and dq / dk / dv leave
 // through the same LDS tiles as full 256-byte row segments.
-template <int HD>
-__global__ __launch_bounds__(128) void attn_bwd_lds_kernel(AttnArgs a) {
-  constexpr int LD = HD + 4, Q4 = HD / 4, PER = 32 * Q4 / 128;
+// CS > 1 (few (sequence, head) pairs, wide heads): 2 CS waves per pair -- every wave pair repeats the dP contraction of its query / key tile
+// from LDS and takes 1 / CS of the head's column tiles (role bodies above); the staging loads and the row stores spread over all of them.
+template <int HD, int CS = 1>
+__global__ __launch_bounds__(128 * CS) void attn_bwd_lds_kernel(AttnArgs a) {
+  constexpr int NT = 128 * CS, LD = HD + 4, Q4 = HD / 4, PER = 32 * Q4 / NT, NC = HD / 16 / CS;
+  static_assert(32 * Q4 % NT == 0, "staging passes");
   __shared__ __attribute__((aligned(16))) float sm[4 * 32 * LD];
   __shared__ float srd[32];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, bh = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = wave & 1, cs = wave >> 1, bh = blockIdx.x;
   const AttnOps og = attn_ops_global(a, bh, HD);
   float4 rq[PER], rk[PER], rv[PER], rd[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const int e = tid + 128 * u, r = e / Q4, c = (e % Q4) * 4;
+    const int e = tid + NT * u, r = e / Q4, c = (e % Q4) * 4;
     rq[u] = *reinterpret_cast<const float4*>(og.q + (size_t)r * og.ldq + c);
     rk[u] = *reinterpret_cast<const float4*>(og.k + (size_t)r * og.ldk + c);
     rv[u] = *reinterpret_cast<const float4*>(og.v + (size_t)r * og.ldv + c);
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(128) void attn_bwd_lds_kernel(AttnArgs a) {
   }
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const int e = tid + 128 * u, o = (e / Q4) * LD + (e % Q4) * 4;
+    const int e = tid + NT * u, o = (e / Q4) * LD + (e % Q4) * 4;
     *reinterpret_cast<float4*>(sm + o) = rq[u];
     *reinterpret_cast<float4*>(sm + 32 * LD + o) = rk[u];
     *reinterpret_cast<float4*>(sm + 64 * LD + o) = rv[u];
@@ -532,16 +537,16 @@ __global__ __launch_bounds__(128) void attn_bwd_lds_kernel(AttnArgs a) {
   }
   __syncthreads();
   const AttnOps op{sm, sm + 32 * LD, sm + 64 * LD, sm + 96 * LD, LD, LD, LD, LD};
-  f32x4 dq_out[HD / 16], ov[HD / 16], ok[HD / 16];
-  attn_bwd_mfma_role1<HD, false>(a, op, bh, w, lane, srd, dq_out);
+  f32x4 dq_out[NC], ov[NC], ok[NC];
+  attn_bwd_mfma_role1<HD, false, CS>(a, op, bh, w, lane, srd, dq_out, cs);
   __syncthreads();
-  attn_bwd_mfma_role2<HD, false>(a, op, bh, w, lane, srd, ov, ok);
+  attn_bwd_mfma_role2<HD, false, CS>(a, op, bh, w, lane, srd, ov, ok, cs);
   __syncthreads();                                               // every fragment read of q / k / v is done: the tiles take dq / dk / dv
   {
     const int l16 = lane & 15, g = lane >> 4;
-    float* o = sm + (16 * w + 4 * g) * LD + l16;
+    float* o = sm + (16 * w + 4 * g) * LD + 16 * cs * NC + l16;
 #pragma unroll
-    for (int ct = 0; ct < HD / 16; ++ct)
+    for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         o[r * LD + 16 * ct] = dq_out[ct][r];
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(128) void attn_bwd_lds_kernel(AttnArgs a) {
   const int hc = (bh % a.H) * HD;
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    const int e = tid + 128 * u, r = e / Q4, c = (e % Q4) * 4, o = r * LD + c;
+    const int e = tid + NT * u, r = e / Q4, c = (e % Q4) * 4, o = r * LD + c;
     if (a.dq != nullptr) {                                  // (nullptr: dq / dk / dv live in bf16 only)
       *reinterpret_cast<float4*>(a.dq + (row0 + r) * a.lddq + hc + c) = *reinterpret_cast<const float4*>(sm + o);
       *reinterpret_cast<float4*>(a.dk + (row0 + r) * a.lddk + hc + c) = *reinterpret_cast<const float4*>(sm + 32 * LD + o);
