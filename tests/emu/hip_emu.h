@@ -326,6 +326,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
       for (unsigned x = 0; x < grid.x; ++x) pending.push_back(dim3(x, y, z));
+  int stalled = 0;                                   // passes in a row that completed no workgroup
   while (!pending.empty()) {
     again.clear();
     for (const dim3& blk : pending) {
@@ -334,7 +335,10 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
       run_block();
       if (retry_) again.push_back(blk);           // waited for a workgroup that has not run yet: once more after the others
     }
-    if (again.size() == pending.size()) { fprintf(stderr, "hip_emu: every remaining workgroup waits for another one (%zu blocks)\n", again.size()); abort(); }
+    // (a launch with k meetings per workgroup pair can pass k - 1 times without a completion: each pass takes every pair one meeting further)
+    if (again.size() == pending.size()) {
+      if (++stalled > 4) { fprintf(stderr, "hip_emu: every remaining workgroup waits for another one (%zu blocks)\n", again.size()); abort(); }
+    } else stalled = 0;
     pending.swap(again);
   }
   dyn_smem_ = nullptr;

@@ -30,7 +30,7 @@ EPI = {0: None, 1: "gemm_wgrad", 2: "gemm_fwd_input", 3: "gemm_fwd_ffn1", 4: "ge
 PLAIN = [("seq_tail_kernel", "seq_tail"), ("seq_update_pack_kernel", "optimizer"), ("wgrad_group_kernel", "gemm_wgrad"), ("wgrad_reduce", "gemm_wgrad_reduce"), ("attn_fwd", "attn_fwd"), ("attn_bwd", "attn_bwd"),
          ("attn_decode", "attn_decode"), ("ln_bwd", "ln_bwd"), ("ln_fwd", "ln_fwd"), ("heads_loss", "heads_loss"), ("loss_kernel", "loss"),
          ("sgd_kernel", "optimizer"), ("adam_kernel", "optimizer"), ("ln_param_reduce", "ln_param_reduce"),
-         ("encoder_small", "encoder_small"), ("seq_fwd_kernel", "seq_fwd"), ("seq_bwd_kernel", "seq_bwd"),
+         ("encoder_small", "encoder_small"), ("seq_fwd_kernel", "seq_fwd"), ("seq_fb_kernel", "seq_fwd"), ("seq_bwd_kernel", "seq_bwd"),
          ("seq_pack_kernel", "seq_pack"), ("wgrad32_group_kernel", "gemm_wgrad"), ("voice_metrics", "voice_metrics"),
          ("gather_batch", "gather_batch")]
 

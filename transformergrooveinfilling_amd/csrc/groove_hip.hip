@@ -296,7 +296,7 @@ static WLayout ws_layout(const gt_config& c) {
     W.pack_stride = (int64_t)4 * d * d + (int64_t)2 * d * F;
     W.pack_f = add(W.pack_stride * c.n_enc_layers); W.pack_b = add(W.pack_stride * c.n_enc_layers);
     W.seq_dctx = add(2 * M * d);
-    if (d == 128) { W.seq_xchg_n = gt_seq_xchg_floats(c.batch); W.seq_xchg = add(W.seq_xchg_n); }
+    if (d == 128) { W.seq_xchg_n = 2 * gt_seq_xchg_floats(c.batch); W.seq_xchg = add(W.seq_xchg_n); }    // (two regions: the forward's, and backward phase 0's when fused behind it)
     if (d == 32 && c.n_heads == 16) { W.seq_amask_stride = BH * 32; W.seq_amask = add(W.seq_amask_stride * c.n_enc_layers); }   // (behind everything else: no other offset moves)
   }
   if (bf16_shadows(c)) {
@@ -925,17 +925,27 @@ static bool use_seq(const gt_config& c) {
 // gt_train_step hands its loss over to the sequence-resident forward (one launch less): set around its gt_forward call
 struct SeqLoss { const float* y; float penalty; float* stats; unsigned* ticket; };
 static thread_local SeqLoss g_seq_loss = {nullptr, 0.f, nullptr, nullptr};
+// flops of backward phase 0 of the SPLIT / QUAD schedule: the dgrads of the output layer and of the last layer's FFN2, FFN1, out-proj
+static double seq_b0_flops(const Ctx& x) { return 2.0 * x.M * (27.0 * x.d + 2.0 * x.d * x.F + (double)x.d * x.d); }
+static thread_local bool g_seq_b0_fused = false;     // the forward of this fused step already ran backward phase 0 (seq_fb_kernel): gt_train_step's backward skips it
 // gt_train_step with GT_STEP_PACKS_CURRENT: the fragment-ordered weight copies in ws are the previous fused update's (seq_update_pack_kernel)
 static thread_local bool g_seq_packs_current = false;
 // launches of one gt_train_step on the sequence-resident path (0: another path -- dozens to hundreds): pack, forward (phases), backward
 // (phases), LayerNorm-parameter reduce, grouped weight gradients (one or two tile classes), optimizer.  Hosts use it to choose
 // between replaying a captured graph and plain launches: below ~25 nodes the graph's per-node cost exceeds what it saves.
+// the fused train step's last forward launch goes on into backward phase 0 (seq_fb_kernel): QUAD schedule, riders, head_dim 32
+static bool seq_fuse_b0(const gt_config& c) {
+  static const int fuse_env = [] { const char* e = getenv("GT_SEQ_FUSE_B0"); return (e && e[0] == '0') ? 0 : 1; }();
+  static const int quad_bwd0 = [] { const char* e = getenv("GT_SEQ_QUAD_BWD0"); return (e && e[0] == '0') ? 0 : 1; }();
+  return fuse_env && quad_bwd0 && seq_split(c) && seq_quad(c) && seq_ride(c) && c.d_model / c.n_heads == 32;
+}
 extern "C" int gt_step_launches(const gt_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (!use_seq(*cfg)) return 0;
   // (with GT_STEP_PACKS_CURRENT one less: no packing launch)
   if (!seq_split(*cfg)) return 7;
-  return 2 * cfg->n_enc_layers + 1 + (seq_ride(*cfg) ? 3 : 5);   // pack, L forward + L + 1 backward phases, [grouped weight gradients x 2,] reduce / tail, update
+  // pack, L forward + L + 1 backward phases (QUAD at head_dim 32: the last forward launch runs backward phase 0 too), [grouped weight gradients x 2,] reduce / tail, update
+  return 2 * cfg->n_enc_layers + 1 + (seq_ride(*cfg) ? 3 : 5) - (seq_fuse_b0(*cfg) ? 1 : 0);
 }
 static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hvo) {
   SeqArgs a;
@@ -958,7 +968,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.dlogits = x.W.dlogits; a.da0 = x.W.dctx; a.ln_part = x.W.ln_part; a.ln_part_stride = x.W.ln_part_stride;
   a.stamps = x.W.stamps;
   a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
-  a.dctx = x.W.seq_dctx; a.xchg = x.W.seq_xchg; a.amask = x.W.seq_amask; a.amask_stride = x.W.seq_amask_stride; a.phase = 0;
+  a.dctx = x.W.seq_dctx; a.xchg = x.W.seq_xchg; a.xchg_b = x.W.seq_xchg >= 0 ? x.W.seq_xchg + gt_seq_xchg_floats(x.c.batch) : -1; a.fuse_b0 = 0; a.amask = x.W.seq_amask; a.amask_stride = x.W.seq_amask_stride; a.phase = 0;
   a.loss_y = nullptr; a.loss_penalty = 0.f; a.loss_stats = nullptr; a.loss_part = nullptr; a.loss_ticket = nullptr;
   a.grd = nullptr; a.nseq = 0; a.wg_accumulate = 0; a.ride_last_k = x.M; a.out_early = 0; a.tail_phase = 0; a.tail_ksplit = 1; a.ln_nwg = 0; a.bump = nullptr;
   return a;
@@ -976,19 +986,29 @@ static int seq_forward(const Ctx& x, const float* pe, const float* src, float* h
     gt_prof_tag("seq_pack", 0.0, 12.0 * x.c.n_enc_layers * x.W.pack_stride);
     gt_seq_launch_pack(a, (unsigned)((frags + 3) / 4), x.s);
   }
-  gt_prof_tag("seq_fwd", fl, 4.0 * x.M * (x.c.src_dim + x.c.n_enc_layers * (9.0 * x.d + x.F) + 27.0));
   const int hc = x.hd < 16 ? 0 : x.hd;             // head-dim class (one instantiation each: the attention bodies' registers differ 4x)
+  // fused train step on the QUAD schedule: the last phase's launch goes on into backward phase 0 (seq_fb_kernel; GT_SEQ_FUSE_B0=0: off)
+  const bool fuse_b0 = seq_fuse_b0(x.c) && a.loss_y != nullptr;
+  // (its dgrad products -- output layer, FFN2, FFN1, out-proj of the last layer -- are counted where they run)
+  gt_prof_tag("seq_fwd", fl + (fuse_b0 ? seq_b0_flops(x) : 0.0), 4.0 * x.M * (x.c.src_dim + x.c.n_enc_layers * (9.0 * x.d + x.F) + 27.0));
   if (seq_split(x.c)) {
     const bool quad = seq_quad(x.c);                           // four workgroups per sequence: column partners share the FFN
     // GT_SEQ_QUAD_PRO=1: input layer + in-proj(0) as a prologue launch of their own instead of four times over inside phase 0 --
     // measured neutral at the headline shape (0.2076 vs 0.2073 ms: one more launch for 17 k fewer cycles of phase 0), so off
     static const int quad_pro = [] { const char* e = getenv("GT_SEQ_QUAD_PRO"); return (e && e[0] == '1') ? 1 : 0; }();
     a.quad_pro = quad ? quad_pro : 0;
+    g_seq_b0_fused = false;
     for (int p = a.quad_pro ? -1 : 0; p < x.c.n_enc_layers; ++p) {   // one launch per encoder layer (gt_seq.h, SPLIT) [+ QUAD's prologue]
       SeqArgs ap = a;
       ap.phase = p;
       if (p > (a.quad_pro ? -1 : 0)) gt_prof_tag("seq_fwd", 0.0, 0.0);          // (flops and bytes of the whole forward are on the first phase's tag)
-      gt_seq_launch_fwd(ap, x.d, hc, true, (quad ? 4 : 2) * x.c.batch, x.s, quad);
+      if (fuse_b0 && p == x.c.n_enc_layers - 1) {
+        ap.fuse_b0 = 1;
+        gt_seq_launch_fb(ap, 4 * x.c.batch, x.s);
+        g_seq_b0_fused = true;
+      } else {
+        gt_seq_launch_fwd(ap, x.d, hc, true, (quad ? 4 : 2) * x.c.batch, x.s, quad);
+      }
     }
     return 0;
   }
@@ -1319,6 +1339,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
         if (last_pct == 100) a.ride_last_k = M;
         fl += 2.0 * M * ((L - 1) * 3.0 * d * d + L * ((double)d * d + 2.0 * d * x.F))
               - 2.0 * (M - a.ride_last_k) * (per_layer + (L > 1 ? win : 0)) * 2048.0;
+        if (g_seq_b0_fused) fl -= seq_b0_flops(x);                  // (phase 0 ran, and was counted, in the forward's last launch)
         gt_prof_tag("seq_bwd", fl, 4.0 * M * (L * (14.0 * d + 2.0 * x.F) + 27.0) + 4.0 * M * L * (8.0 * d + 2.0 * x.F));   // + the riders' operands, once
         // bucketed backward (data-parallel overlap): phase 1 = the launches up to the cut of grad_split, phase 2 = the rest + tail
         const int pcut = L - split_.split_layer + 1;                 // last backward phase of the first half (split_.nb == 2)
@@ -1326,10 +1347,13 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
         a.ln_nwg = nwg;
         static const int quad_bwd0 = [] { const char* e = getenv("GT_SEQ_QUAD_BWD0"); return (e && e[0] == '0') ? 0 : 1; }();
         const bool quad0 = quad_bwd0 && seq_quad(*cfg);
+        const bool b0_done = g_seq_b0_fused && quad0;                // (phase 0 ran inside the forward's last launch)
+        g_seq_b0_fused = false;
         for (int p = p_lo; p <= p_hi; ++p) {
+          if (p == 0 && b0_done) continue;
           SeqArgs ap = a;
           ap.phase = p;
-          if (p > p_lo) gt_prof_tag("seq_bwd", 0.0, 0.0);
+          if (p > p_lo && !(b0_done && p == 1)) gt_prof_tag("seq_bwd", 0.0, 0.0);
           // phase 0 has no riders: four workgroups per sequence there (column partners, gt_seq.h QUAD) while they fit the chip
           if (p == 0 && quad0) gt_seq_launch_bwd(ap, d, hc, true, 2 * a.nseq, x.s, true);
           else gt_seq_launch_bwd(ap, d, hc, true, a.nseq + (p == 0 ? 0 : R), x.s);

@@ -32,3 +32,4 @@ void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsign
   else { GT_SEQ_DISPATCH(seq_bwd_kernel, d_model, hc, grid, block, s, a) }
 }
 void gt_seq_launch_tail(const SeqArgs& a, unsigned nblocks, hipStream_t s) { gt_launch(seq_tail_kernel, dim3(nblocks), dim3(GT_SEQ_NT), s, a); }
+void gt_seq_launch_fb(const SeqArgs& a, unsigned nblocks, hipStream_t s) { gt_launch(seq_fb_kernel<32>, dim3(nblocks), dim3(GT_SEQ_NT), s, a); }

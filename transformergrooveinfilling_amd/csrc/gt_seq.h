@@ -1239,8 +1239,11 @@ template <int DP> struct SeqGeo {
 // computed by both; saved activations are written by one of the two.  The last phase's output layer + loss run on partner 0 only.
 // Both partners must be resident at once to meet: they are adjacent blocks of a grid that fits the chip (one workgroup per CU by LDS);
 // the spin is bounded (seq_xchg_get).
+// (The body is a device function over ONE LDS buffer -- lds, SeqFwdLds<DP>::N floats -- so that a kernel can run it and then the
+//  backward's body on the same storage.  Returns false when this workgroup is done with the launch.)
+template <int DP> struct SeqFwdLds { static constexpr int N = 3 * SeqGeo<DP>::TILE + SeqGeo<DP>::RES + SeqGeo<DP>::UNI; };
 template <int DP, int HDC, bool EXACT, bool SPLIT, bool QUAD = false>
-__global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
+__device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds) {
   static_assert(!QUAD || (SPLIT && EXACT && DP == 128), "QUAD: the SPLIT kernels of d_model 128");
   using G = SeqGeo<DP>;
   constexpr int SX = G::SX, SH = G::SH, SQ = G::SQ, SRS = G::SRS, CW = G::CW, NK = G::NK;
@@ -1248,7 +1251,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
   constexpr bool PAD = SeqHd<HDC>::PAD;
   constexpr bool HALF = SPLIT;
   constexpr int NH = HALF ? 1 : 2, NROW = HALF ? 16 : 32;    // 16-row halves a matmul epilogue sees / rows this workgroup owns
-  __shared__ __attribute__((aligned(16))) float sX[G::TILE], sX1[G::TILE], sC[G::TILE], sR[G::RES], sU[G::UNI];
+  float* const sX = lds; float* const sX1 = sX + G::TILE; float* const sC = sX1 + G::TILE; float* const sR = sC + G::TILE; float* const sU = sR + G::RES;
   float* const sQ = sU;                                      // qkv tile: in-proj -> attention
   float* const sH = sU;                                      // FFN tile: FFN1 -> FFN2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
@@ -1366,6 +1369,9 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     float* wl = ws + (int64_t)l * a.wstride;
     const int site0 = GT_SITE_LAYER0 + 8 * l;
     const int sb = 2 + 10 * l;                               // stamp base of this layer
+    // (QUAD, last layer of a launch that goes on into backward phase 0: each partner reads back ITS OWN saves there -- the LayerNorm
+    //  statistics that otherwise one of the two writes are written by both, identical values)
+    const bool fzl = QUAD && a.fuse_b0 != 0 && l + 1 == a.L;
     // ---- attention: operands from the LDS qkv tile, P to global, ctx to the LDS tile.  Whole: wave pair p takes head h4 + p and the
     // pair's two waves the two query tiles; SPLIT: wave w takes head h8 + w, query tile = the own half.  The qkv tile goes to global
     // here (saved for the backward) -- line-shaped, see seq_tile_out.
@@ -1424,7 +1430,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         SeqVec<CW>::ld(z, &sR[row * SRS + c0]); SeqVec<CW>::ld(bi, bo + c0); SeqVec<CW>::ld(xr, &sX[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, sv1 ? wl + a.w0.x1 + r0 * d : nullptr, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb);
+      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, (sv1 || fzl) ? wl + a.w0.x1 + r0 * d : nullptr, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 4);
@@ -1476,8 +1482,9 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       GT_STAMP(300 + 4 * l);
       unsigned long long* const xq = reinterpret_cast<unsigned long long*>(ws + a.xchg) + 8;       // (granule 0..7: the region's header)
       const bool last = l + 1 == a.L;                               // last layer: partner 1 only sends (partner 0 runs the output layer alone)
-      if (!last || cpart == 1) seq_xchg_put(xq + (size_t)vb * GT_XCHG_WG_GRANULES, acc0, tid);
-      if (last && cpart == 1) return true;                          // (workgroup-uniform)
+      const bool fz = a.fuse_b0 != 0;                               // (the launch goes on into backward phase 0: partner 1 needs the sum too)
+      if (!last || cpart == 1 || fz) seq_xchg_put(xq + (size_t)vb * GT_XCHG_WG_GRANULES, acc0, tid);
+      if (last && cpart == 1 && !fz) return true;                   // (workgroup-uniform)
       *reinterpret_cast<float4*>(&sR[(16 * cpart + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
       GT_STAMP(301 + 4 * l);
       const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg));
@@ -1507,7 +1514,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         SeqVec<CW>::ld(bi, b2 + c0); SeqVec<CW>::ld(xr, &sX1[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, sv0 ? wl + a.w0.xout + r0 * d : nullptr, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid, rb);
+      }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, (sv0 || fzl) ? wl + a.w0.xout + r0 * d : nullptr, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 7);
@@ -1555,7 +1562,8 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     bce = gt_wave_sum(bce); mv = gt_wave_sum(mv); mo = gt_wave_sum(mo); ok = gt_wave_sum(ok);
     if (lane == 0) { red[wave * 4 + 0] = bce; red[wave * 4 + 1] = mv; red[wave * 4 + 2] = mo; red[wave * 4 + 3] = ok; }
     GT_BARRIER();
-    if (tid == 0) {
+    if (tid == 0 && cpart != 0) red[32] = 0.0f;                // (QUAD, fused with backward phase 0: partner 1 computed dlogits for itself; the statistics are partner 0's)
+    if (tid == 0 && cpart == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float t = red[q];
@@ -1611,7 +1619,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
         input_layer(OwnRows{});
         in_proj(0, OwnRows{});
         seq_tile_out_cols(ws + a.w0.qkv + r0 * 3 * d, 3 * d, sQ, SQ, cpart * (3 * d / 2), 3 * d / 2, tid, rb, NROW);
-        return;
+        return false;
       }
     }
     const bool pro = QUAD && a.quad_pro != 0;
@@ -1638,7 +1646,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
       GT_BARRIER();
     }
     GT_STAMP(2 + 10 * l + 1);
-    if (layer_rest(l, l == 0 && !pro)) return;
+    if (layer_rest(l, l == 0 && !pro)) return false;
     if (l + 1 < a.L) {
       in_proj(l + 1, OwnRows{});
       float* const gq = ws + (int64_t)(l + 1) * a.wstride + a.w0.qkv + r0 * 3 * d;
@@ -1650,6 +1658,12 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
     GT_WGSTAMP(1);
     GT_STAMP(61 + 2 * (l + 1));
   }
+  return true;
+}
+template <int DP, int HDC, bool EXACT, bool SPLIT, bool QUAD = false>
+__global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[SeqFwdLds<DP>::N];
+  (void)seq_fwd_body<DP, HDC, EXACT, SPLIT, QUAD>(a, lds);
 }
 
 // ================================================================================================================ backward
@@ -1665,8 +1679,13 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_fwd_kernel(SeqArgs a) {
 // the forward: the column partners of a row half split the FFN2 dgrad by columns of dhid and the FFN1 dgrad by its contraction (one
 // pair exchange of the [16][128] partial results), split the out-proj dgrad's columns (dctx goes to the hand-over buffer anyway), and
 // compute the output-layer dgrad and the LayerNorm backward passes twice; partner 0 writes what both computed.  Phase 0 only.
+template <int DP> struct SeqBwdLds {
+  using G = SeqGeo<DP>;
+  static constexpr int U = DP > 64 ? G::UNI : G::QKV + G::FFN, P = 2 * GT_SEQ_WAVES * DP;
+  static constexpr int N = 3 * G::TILE + G::RES + U + P + 32 * GT_SEQ_WAVES / 2;
+};
 template <int DP, int HDC, bool EXACT, bool SPLIT, bool QUAD = false>
-__global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
+__device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds) {
   static_assert(!QUAD || (SPLIT && EXACT && DP == 128), "QUAD: the SPLIT kernels of d_model 128");
   using G = SeqGeo<DP>;
   constexpr int SX = G::SX, SH = G::SH, SQ = G::SQ, SRS = G::SRS, CW = G::CW, NK = G::NK;
@@ -1680,8 +1699,8 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
   // sQ and sH share storage -- the FFN tile is dead once the FFN1 dgrad has read it, the qkv tile is loaded after that, and the
   // next layer's FFN tile is requested only after the in-proj dgrad has read dqkv.
   constexpr bool ALIAS = DP > 64;
-  __shared__ __attribute__((aligned(16))) float sZ[G::TILE], sDZ[G::TILE], sC[G::TILE], sR[G::RES], sU[ALIAS ? G::UNI : G::QKV + G::FFN],
-      sP[2 * GT_SEQ_WAVES * DP], srd[32 * GT_SEQ_WAVES / 2];
+  float* const sZ = lds; float* const sDZ = sZ + G::TILE; float* const sC = sDZ + G::TILE; float* const sR = sC + G::TILE;
+  float* const sU = sR + G::RES; float* const sP = sU + SeqBwdLds<DP>::U; float* const srd = sP + SeqBwdLds<DP>::P;
   float* const sQ = sU;
   float* const sH = ALIAS ? sU : sU + G::QKV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
@@ -1695,7 +1714,7 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     // rider workgroups (gt_seq_wg.h): the blocks behind the sequence workgroups compute the weight gradients whose operands the
     // earlier phases left in the workspace -- same kernel, same LDS footprint, hence always on a CU no sequence workgroup occupies
     if (a.grd != nullptr && (int)blockIdx.x >= a.nseq) {
-      static_assert(sizeof(sU) >= GT_WG_LDS * sizeof(float) && sizeof(sP) >= 8 * 64 * sizeof(float), "rider LDS");
+      static_assert(SeqBwdLds<DP>::U >= GT_WG_LDS && SeqBwdLds<DP>::P >= 8 * 64, "rider LDS");
       seq_wg_riders(a, a.phase, (int)blockIdx.x - a.nseq, (int)gridDim.x - a.nseq, sU, sP, tid);
       return;
     }
@@ -1826,10 +1845,12 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
       seq_tile_out_cols(tl + a.t0.dhid + r0 * F, F, sH, SH, fc0, fcn, tid, rb, NROW);
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
       seq_mm_krange<true>(acc0, acc1, sH + rb * SH + l16 * SH + 4 * lg, SH, kb_w1, nkf, wave, kq0, kq0 + (nkf >> 1), lane, pre1, b1pre);
-      unsigned long long* const xq = reinterpret_cast<unsigned long long*>(ws + a.xchg) + 8;
+      // (fused behind the last forward phase: a region of its own -- the forward's exchange of this launch may still be in flight at the partner)
+      const int64_t xoff = a.fuse_b0 ? a.xchg_b : a.xchg;
+      unsigned long long* const xq = reinterpret_cast<unsigned long long*>(ws + xoff) + 8;
       seq_xchg_put(xq + (size_t)vb * GT_XCHG_WG_GRANULES, acc0, tid);
       *reinterpret_cast<float4*>(&sR[(16 * cpart + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
-      const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg));
+      const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg));       // (one error word: the forward region's header)
       *reinterpret_cast<float4*>(&sR[(16 * (1 - cpart) + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(oth[0], oth[1], oth[2], oth[3]);
     } else {
       seq_tile_out(tl + a.t0.dhid + r0 * F, sH, SH, F, tid, rb, NROW);
@@ -2008,4 +2029,26 @@ __global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
     }
     GT_STAMP(161 + 2 * a.phase);
   }
+}
+template <int DP, int HDC, bool EXACT, bool SPLIT, bool QUAD = false>
+__global__ __launch_bounds__(GT_SEQ_NT) void seq_bwd_kernel(SeqArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[SeqBwdLds<DP>::N];
+  seq_bwd_body<DP, HDC, EXACT, SPLIT, QUAD>(a, lds);
+}
+// QUAD, fused train step: the LAST forward phase and backward phase 0 in one launch (a.fuse_b0).  From the loss down to the out-proj
+// dgrad of the last layer the backward is row-local -- the same rows, the same (row half, column partner) workgroup as the forward phase
+// that ends in the loss -- so the launch boundary between them bought nothing but its cost (kernel duration minus first-workgroup-start ..
+// last-workgroup-end: 4 us) and phase 0's reload of what this workgroup had just written.  Both partners run the whole forward phase here
+// (the last layer's pair exchange in both directions, the output layer and dlogits twice, the statistics once), then the backward body on
+// the same LDS buffer: it reads its operands from global memory as ever -- this workgroup's own stores of a moment ago, ordered by the
+// barrier below (workgroup scope: one CU, one L1).
+template <int HDC>
+__global__ __launch_bounds__(GT_SEQ_NT) void seq_fb_kernel(SeqArgs a) {
+  constexpr int N = SeqBwdLds<128>::N > SeqFwdLds<128>::N ? SeqBwdLds<128>::N : SeqFwdLds<128>::N;
+  __shared__ __attribute__((aligned(16))) float lds[N];
+  if (!seq_fwd_body<128, HDC, true, true, true>(a, lds)) return;
+  __syncthreads();
+  SeqArgs b = a;
+  b.phase = 0;
+  seq_bwd_body<128, 32, true, true, true>(b, lds);
 }

@@ -25,6 +25,7 @@ struct SeqArgs {
   int64_t amask, amask_stride;                               // head_dim-2 attention: keep bits of P, [layer][sequence][head][query] words (-1: absent)
   int64_t xchg;                                              // QUAD forward: the pair-exchange region (8 header granules, then one 16 KB slot per
                                                              // workgroup; zero between launches -- gt_workspace_init); -1: none
+  int64_t xchg_b; int fuse_b0;                               // QUAD, fused step: the last forward launch goes on into backward phase 0 (seq_fb_kernel), whose pair exchange uses the region at xchg_b
   int quad_pro;                                              // QUAD forward: input layer + in-proj(0) ran as a prologue launch (phase -1)
   int phase;                                                 // SPLIT kernels: which phase this launch runs
   // fused loss (gt_train_step): the launch that runs the output layer also computes the loss terms, d loss / d logits and the
@@ -51,5 +52,7 @@ void gt_seq_launch_update_pack(const SeqArgs& a, int algo, float* params, float*
 void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s, bool quad = false);
 // floats of the QUAD forward's pair-exchange region for a batch: 8 header granules + 4 x batch slots of 4 x 512 8-byte granules
 static inline int64_t gt_seq_xchg_floats(int batch) { return 16 + (int64_t)4 * batch * 4 * 512 * 2; }
+// the last forward phase + backward phase 0 of the QUAD schedule in ONE launch (a.fuse_b0 = 1; head-dim class 32 only)
+void gt_seq_launch_fb(const SeqArgs& a, unsigned nblocks, hipStream_t s);
 void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s, bool quad = false);
 void gt_seq_launch_tail(const SeqArgs& a, unsigned nblocks, hipStream_t s);
