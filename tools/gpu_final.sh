@@ -11,6 +11,7 @@ for i in 0 1 2 3; do GT_SEQ=0 python tools/shape_bench.py --only $i --steps 200 
 GT_SEQ_SPLIT=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_SPLIT=0 (one workgroup per sequence) /' >> $O/shapes.txt
 GT_SEQ_QUAD=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_QUAD=0 (two workgroups per sequence in every phase: round 3) /' >> $O/shapes.txt
 GT_SEQ_QUAD_BWD0=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_QUAD_BWD0=0 (four workgroups per sequence in the forward only) /' >> $O/shapes.txt
+GT_SEQ_FUSE_B0=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_FUSE_B0=0 (backward phase 0 as a launch of its own) /' >> $O/shapes.txt
 for l in 0 1 2; do GT_BF16_SHADOWS=$l python tools/shape_bench.py --only 11 --steps 30 --warmup 5 2>/dev/null | tail -1 | sed "s/^/GT_BF16_SHADOWS=$l /" >> $O/shapes.txt; done
 GT_SEQ_RIDE=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_SEQ_RIDE=0 (grouped weight gradients at the end) /' >> $O/shapes.txt
 GT_PACK_FOLD=0 python tools/shape_bench.py --only 2 --steps 200 2>/dev/null | tail -1 | sed 's/^/GT_PACK_FOLD=0 (packing launch at the head of every step) /' >> $O/shapes.txt
