@@ -1537,6 +1537,7 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
                            const float* hvo, const float* d_hvo, float* ws, const gt_step_state* state, int train, int accumulate,
                            gt_stream_t stream) {
   if (!hvo || !d_hvo) return gt_fail("gt_backward: hvo / d_hvo must not be NULL");
+  g_seq_b0_fused = false;                           // (only gt_train_step's own forward may have run backward phase 0 already)
   return backward_impl(cfg, params, grads, xin, tgt_in, hvo, d_hvo, ws, state, train, accumulate, stream);
 }
 
@@ -1624,9 +1625,10 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   }
   // whole step: the last launch of backward (the LayerNorm partials reduce -- every model has LayerNorms) also advances the
   // step counters, and the optimizer is told so: one launch less than update + step_inc
-  if (backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, skip_update == 2 ? 1 : 0,
-                    skip_update == 0 ? state : nullptr, true))
-    return -1;
+  const int brc = backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, skip_update == 2 ? 1 : 0,
+                                skip_update == 0 ? state : nullptr, true);
+  g_seq_b0_fused = false;                           // (consumed by that call; cleared here too in case it left early)
+  if (brc) return -1;
   if (!skip_update) {
     PLayout P = param_layout(*cfg);
     if (use_seq(*cfg)) {
