@@ -124,6 +124,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-dp-tune", action="store_true", help="world > 1: keep the default data-parallel recipe instead of timing the four")
     ap.add_argument("--force-dp", action="store_true",
                     help="1 GPU only: run the data-parallel step sequence (graph, RCCL all-reduce in a 1-rank group, update) to "
                          "measure its non-communication overhead")
@@ -243,19 +244,34 @@ def run_rank(args):
         sync()
         dt = time.perf_counter() - t0
         ev = e0.elapsed_time(e1) * 1e-3 if not emu else dt
+        # a pair exchange of the four-workgroups-per-sequence schedule that timed out inside the block (its updates were skipped on the
+        # device, the engine has fallen back to two workgroups per sequence): the block does not count -- on any rank
+        bad = 1.0 if eng.check_exchange(eng.slot(batch), "a timed block of bench.py") else 0.0
         if world > 1:
-            t = torch.tensor([dt, ev], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt, ev, bad], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, ev = float(t[0].item()), float(t[1].item())
-        return dt, ev
+            dt, ev, bad = float(t[0].item()), float(t[1].item()), float(t[2].item())
+        return dt, ev, bad
 
     for _ in range(args.warmup):
         eng.train_step()
+    # world > 1: the first run on real ranks picks its own data-parallel recipe -- {one all-reduce, two overlapped buckets} x {eager
+    # sequence, one hipGraph per step}, ~30 steps each, the maximum over ranks decides (StepEngine.autotune_dp) -- unless the environment
+    # forces one (GT_DP_OVERLAP / GT_DP_GRAPH) or --no-dp-tune is given.  Untimed; parameters and step state are restored.
+    dp_tune = None
+    if (world > 1 or (args.force_dp and os.environ.get("GT_DP_TUNE") == "1")) and not args.no_dp_tune \
+            and "GT_DP_OVERLAP" not in os.environ and "GT_DP_GRAPH" not in os.environ:
+        dp_tune = eng.autotune_dp(steps=2 if emu else 30, warmup=1 if emu else 5)
+        for _ in range(2 if emu else 5):
+            eng.train_step()
+    eng.check_exchange(eng.slot(batch), "the warm-up of bench.py")
     # EXACTLY --steps steps per block, as the contract says; at least BLOCKS blocks, and more of the same until MIN_TIMED_S seconds of
     # timed steps have run (every rank takes the same decision: the block times are already the maximum over ranks)
     blocks = []
     while len(blocks) < (1 if emu else BLOCKS) or (not emu and sum(b[0] for b in blocks) < MIN_TIMED_S and len(blocks) < MAX_BLOCKS):
         blocks.append(timed_block(eng.train_step, args.steps))
+    discarded = sum(1 for b in blocks if b[2])
+    blocks = [b for b in blocks if not b[2]] or [timed_block(eng.train_step, args.steps)]
     walls = sorted(b[0] for b in blocks)
     dt = walls[len(walls) // 2]                                          # the median block
     ev = sorted(b[1] for b in blocks)[len(blocks) // 2]
@@ -302,7 +318,11 @@ def run_rank(args):
                             "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if not emu else None,
                             "overlap_allreduce": bool(eng.overlap_allreduce) if (world > 1 or args.force_dp) else None,
                             "grad_buckets": len(eng.lib.grad_buckets(eng.slot(batch).cfg)),
-                            "grad_bytes": 4 * eng.total},
+                            "grad_bytes": 4 * eng.total,
+                            "dp_graph": bool(eng.dp_graph and not eng.dp_graph_failed) if (world > 1 or args.force_dp) else None,
+                            "dp_tune": dp_tune},
+            # QUAD pair exchanges that timed out (0 on a GPU this process has to itself); blocks in which one did are not in `value`
+            "exchange_timeouts": eng.exchange_timeouts, "blocks_discarded": discarded,
             "step_roofline": {"f_train_mflop_per_seq": ftrain / 1e6, "achieved_tflops": seq_s * ftrain / 1e12,
                               "frac_of_fp32_mfma_peak": seq_s * ftrain / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world)},
             "final_loss": loss,

@@ -220,6 +220,17 @@ int gt_set_seq_split(int on);
  * condition (env GT_SEQ_QUAD=0/1).  Results agree with the SPLIT mode to fp32 rounding (the FFN2 contraction is summed as two halves);
  * bitwise repeatable run to run.  Needs gt_workspace_init on the workspace. */
 int gt_set_seq_quad(int on);
+/* The pair exchange polls with a bound: a partner workgroup that never arrives (the two were not resident at the same time: another
+ * stream's kernel, a CU mask, another process holds CUs) makes the waiting workgroup give up, raise the error word at the head of the
+ * "seq_xchg" workspace region (gt_ws_find) and go on with garbage partials.  Fail-safe (round 5): with the word set -- it stays set until
+ * the host zeroes the region with gt_workspace_init -- the fused update (gt_train_step, gt_optimizer_step_ws) leaves parameters and
+ * optimizer moments untouched and only clears the consumed gradients; the same when gradient element n_floats - 1 (padding behind the
+ * 27-float output bias; a data-parallel host writes its error flag there before the all-reduce) is non-zero, so every rank skips
+ * together.  gt_set_xchg_spin_max: polls before giving up (<= 0: the default, 2^22 = seconds; tests lower it). */
+int gt_set_xchg_spin_max(int polls);
+/* Test aid: nblocks workgroups that each pin 96 KB of LDS (no sequence workgroup fits beside one) for `usec` microseconds -- a second
+ * stream holding CUs while a four-workgroups-per-sequence launch is in flight. */
+int gt_debug_occupy_cus(int nblocks, int usec, gt_stream_t stream);
 /* gt_config.precision = 1 (BASELINE configs[4]) at d_model 256 / 512 with every Linear of a layer on the big-tile kernel: bf16 copies of
  * the GEMM operands.  The producers of every activation / gradient a Linear, dgrad or weight gradient of an encoder layer consumes write
  * it in bf16 (8 tensors per layer), a per-step kernel writes bf16 copies of the layers' weights and of their transposes, and the GEMMs

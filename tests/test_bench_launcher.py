@@ -32,6 +32,11 @@ def test_bare_shell_launch_of_two_ranks():
     assert d["world"] == 2 and d["dist_world_size"] == 2 and d["backend"] == "gloo"
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["final_loss"] == out["final_loss"]
+    # the first run on real ranks picks its own data-parallel recipe: the table of the recipes timed (host memory: the eager ones) and
+    # the one kept are part of the record; no pair exchange timed out, no block was thrown away
+    t = d["dp_tune"]
+    assert t["chosen"] in t["modes"] and set(t["modes"]) <= {"plain_eager", "buckets_eager"} and all(v and v > 0 for v in t["modes"].values())
+    assert out["exchange_timeouts"] == 0 and out["blocks_discarded"] == 0
 
 
 def test_single_rank_and_two_ranks_compute_the_same_kind_of_step():

@@ -113,6 +113,38 @@ def test_big_tile_kernel_variant():
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GT_EMU_LIB_PATH=so), capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    # the same library (operand shadows from 1 tile) with the 64x64 rule lowered: both operands bf16 on gemm64h_kernel, bf16-only storage
+    out = _emu_subprocess("assert parity.check_bf16_shadows('emu', cfg_dict(256, 4, 128, 2), 4, 0.2) == 31\n"
+                          "parity.check_step_bf16('emu', cfg_dict(256, 8, 256, 1), 4, 0.0)\n"
+                          "harness.emu_lib().cdll.gt_set_operand_shadows(1)\n"
+                          "parity.check_step_bf16('emu', cfg_dict(256, 4, 128, 1), 4, 0.2)\n",
+                          dict(GT_EMU_LIB_PATH=so, GT_T64R_MIN="1", GT_TRACE_GEMM64="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    assert any(ln.startswith("[gemm64] bf16-source") for ln in out.stderr.splitlines())
+
+
+def _emu_subprocess(code, env):
+    import os
+    import subprocess
+    import sys
+    from harness import ROOT
+    head = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import parity, harness\nfrom harness import cfg_dict\n") % (ROOT, os.path.join(ROOT, "tests"))
+    return subprocess.run([sys.executable, "-c", head + code + "print('ok')\n"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
+
+
+# ---- 64x64 tiles on the ring body (gt_gemm64.h, round 5): problems of 192 .. 2047 tiles otherwise -- the tile rule is lowered through
+# the environment (GT_T64R_MIN=1, read once per process: a subprocess) and GT_TRACE_GEMM64=1 proves which launches took the kernel
+def test_tile64_ring_kernel():
+    out = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 4, 128, 2), 2, 0.2)\n"          # M = 64: NT (QKV, out-proj, FFN, K 256 / 128), NN dgrads (K 768), all four epilogues
+                          "parity.check_step('emu', cfg_dict(128, 2, 256, 1, 1), 2, 0.0)\n"        # encoder-decoder: the accumulate epilogue (cross-attention dmem)
+                          "parity.check_step_bf16('emu', cfg_dict(256, 4, 128, 1), 2, 0.2)\n"      # fp32 sources rounded at fragment assembly (32x32x16 bf16 MFMA)
+                          "parity.check_train_step('emu', cfg_dict(256, 2, 128, 1), 2, 0.1, seq=False)\n",
+                          dict(GT_T64R_MIN="1", GT_TRACE_GEMM64="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    tr = [ln for ln in out.stderr.splitlines() if ln.startswith("[gemm64]")]
+    for want in ("NT epi 0 prec 0", "NN epi 0 prec 0", "NT epi 3 prec 0", "NN epi 5 prec 0", "NN epi 6 prec 0", "NT epi 0 prec 1", "K 768"):
+        assert any(want in ln for ln in tr), (want, tr[:5])
 
 
 def test_gather_and_voice_metrics_kernels():

@@ -1,0 +1,157 @@
+"""The four-workgroups-per-sequence (QUAD) pair exchange must fail SAFE (ADVICE r04 / VERDICT r04 #4): a timed-out exchange raises an
+error word; from then on the fused update applies nothing, the host notices (asynchronous poll on the step path, synchronising check on
+the logging / evaluation paths), zeroes the region and falls back to two workgroups per sequence.  Here on host memory with the
+emulator build of the kernels (the GPU suite drives a real time-out: tests/test_hip_api.py)."""
+import os
+import socket
+import sys
+import warnings
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIMS = dict(d_model=128, n_heads=4, dim_feedforward=64, num_encoder_layers=2, num_decoder_layers=0, dropout=0.0, embedding_size_src=16)
+
+
+def _engine(B, world=1, seed=3, **kw):
+    from harness import emu_lib
+    from transformergrooveinfilling_amd import layout
+    from transformergrooveinfilling_amd.engine import StepEngine
+    lib = emu_lib()
+    lib.cdll.gt_set_seq_quad(-1)
+    eng = StepEngine(batch_size=B, optimizer=kw.pop("optimizer", "sgd"), learning_rate=0.05, hit_loss_penalty=0.47, seed=seed, device="cpu",
+                     world_size=world, lib=lib, **DIMS)
+    eng.load_named(layout.init_params(DIMS, seed=5))
+    return eng
+
+
+def _raise_word(eng, s):
+    w = eng._xchg_word(s)
+    assert w is not None                       # d_model 128: the workspace has the exchange region
+    w.fill_(1)
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_timed_out_exchange_skips_the_update_and_recovers(optimizer):
+    from transformergrooveinfilling_amd import layout
+    eng = _engine(2, optimizer=optimizer)
+    try:
+        x, y = layout.synthetic_batch(2, 16, seed=9)
+        x, y = torch.from_numpy(x), torch.from_numpy(y)
+        eng.train_step(x, y)
+        assert not eng.check_exchange(eng.slot(2))
+        before = eng.params.clone()
+        m0 = None if eng.m is None else eng.m.clone()
+        _raise_word(eng, eng.slot(2))
+        eng.train_step(x, y)                   # forward / backward ran, the update must not have been applied
+        assert torch.equal(eng.params, before)
+        assert float(eng.grads.abs().max()) == 0.0          # (consumed gradients cleared all the same)
+        if m0 is not None:
+            assert torch.equal(eng.m, m0)
+        eng.train_step(x, y)                   # the word is sticky: still nothing
+        assert torch.equal(eng.params, before)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            st = eng.mean_stats(eng.slot(2))   # the logging path: finds it, recovers, reports NaN for the garbage step
+        assert torch.isnan(st).all() and eng.exchange_timeouts == 1
+        assert any("pair exchange" in str(w.message) for w in rec)
+        assert int(eng._xchg_word(eng.slot(2)).item()) == 0
+        eng.train_step(x, y)                   # two workgroups per sequence from here on: trains again
+        assert not torch.equal(eng.params, before)
+        ref = _engine(2, optimizer=optimizer)  # (a fresh engine, QUAD schedule: the same numbers to fp32 rounding)
+        ref.params.copy_(before)
+        if optimizer == "sgd":             # (Adam would need step 1's moments in the fresh engine: the skip itself is checked above)
+            ref.set_state(step=eng.state_struct().step - 1, opt_step=eng.state_struct().opt_step - 1)
+            ref.train_step(x, y)
+            assert (ref.params - eng.params).abs().max() < 1e-6
+        assert torch.isfinite(eng.mean_stats(eng.slot(2))).all()
+    finally:
+        eng.lib.cdll.gt_set_seq_quad(-1)
+
+
+def test_strict_mode_raises():
+    from transformergrooveinfilling_amd import layout
+    eng = _engine(2)
+    eng.xchg_strict = True
+    x, y = layout.synthetic_batch(2, 16, seed=9)
+    eng.train_step(torch.from_numpy(x), torch.from_numpy(y))
+    _raise_word(eng, eng.slot(2))
+    with pytest.raises(RuntimeError, match="pair exchange"):
+        eng.mean_stats(eng.slot(2))
+    eng.lib.call("gt_workspace_init", __import__("ctypes").byref(eng.slot(2).cfg), __import__("ctypes").c_void_p(eng.slot(2).ws.data_ptr()), None)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GT_DP_OVERLAP="1")
+    from transformergrooveinfilling_amd import layout, parallel
+    parallel.init_distributed("gloo")
+    eng = _engine(2, world=world, seed=3 | (rank << 32))
+    x, y = layout.synthetic_batch(4, 16, seed=9)
+    sl = slice(2 * rank, 2 * rank + 2)
+    x, y = torch.from_numpy(x[sl]), torch.from_numpy(y[sl])
+    eng.train_step(x, y)
+    before = eng.params.clone()
+    if rank == 1:
+        _raise_word(eng, eng.slot(2))          # ONE rank's exchange times out ...
+    eng.train_step(x, y)
+    skipped = torch.equal(eng.params, before)  # ... EVERY rank must skip (the flag rides the gradient all-reduce in the guard element)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        st = eng.mean_stats(eng.slot(2))       # ... and every rank learns of it at the next log point
+    nan = bool(torch.isnan(st).all())
+    eng.train_step(x, y)
+    torch.save({"skipped": skipped, "nan": nan, "params": eng.params.clone(), "timeouts": eng.exchange_timeouts, "before": before}, out % rank)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_skip_together(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "r%d.pt")
+    mp.start_processes(_dp_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    assert a["skipped"] and b["skipped"] and a["nan"] and b["nan"]
+    assert a["timeouts"] == 1 and b["timeouts"] == 1
+    assert torch.equal(a["params"], b["params"]) and not torch.equal(a["params"], a["before"])      # replicas identical, training resumed
+
+
+def _tune_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from transformergrooveinfilling_amd import layout, parallel
+    parallel.init_distributed("gloo")
+    eng = _engine(2, world=world, seed=3 | (rank << 32))
+    x, y = layout.synthetic_batch(4, 16, seed=9)
+    sl = slice(2 * rank, 2 * rank + 2)
+    eng.x.copy_(torch.from_numpy(x[sl])); eng.y.copy_(torch.from_numpy(y[sl]))
+    p0, st0 = eng.params.clone(), eng.state.clone()
+    tune = eng.autotune_dp(steps=2, warmup=1)
+    same = torch.equal(eng.params, p0) and torch.equal(eng.state, st0)            # the run that follows is the run that would have been
+    eng.train_step()
+    torch.save({"tune": tune, "same": same, "params": eng.params.clone(), "overlap": eng.overlap_allreduce}, out % rank)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_data_parallel_autotune_agrees_across_ranks(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "t%d.pt")
+    mp.start_processes(_tune_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    assert a["same"] and b["same"]
+    assert a["tune"]["chosen"] == b["tune"]["chosen"] and a["tune"]["modes"] == b["tune"]["modes"]      # (max over ranks: one table)
+    assert set(a["tune"]["modes"]) == {"plain_eager", "buckets_eager"}                                  # host memory: no hipGraph recipes
+    assert a["overlap"] == b["overlap"] == (a["tune"]["chosen"] == "buckets_eager")
+    assert torch.equal(a["params"], b["params"])
+    from transformergrooveinfilling_amd import layout
+    ref = _engine(4)
+    x, y = layout.synthetic_batch(4, 16, seed=9)
+    ref.train_step(torch.from_numpy(x), torch.from_numpy(y))
+    assert (ref.params - a["params"]).abs().max() < 1e-6

@@ -342,3 +342,79 @@ def test_predict_walks_large_sets_in_chunks():
         assert torch.equal(whole, parts)
         assert torch.equal(whole, eng.predict(x).cpu())
         assert eng.predict_chunk(70) == PREDICT_CHUNK and eng.predict_chunk(4096) == 4096
+
+
+def test_quad_pair_exchange_fails_safe_under_contention_and_on_timeout():
+    """VERDICT r04 #4d / ADVICE r04: a four-workgroups-per-sequence (QUAD) step while another stream holds CUs with an LDS-heavy kernel
+    must give the right numbers; and when an exchange does time out (forced: a polling bound of ONE) the step must not be applied --
+    parameters untouched, the engine notices without synchronising on the step path, falls back to two workgroups per sequence and
+    trains on -- never silent garbage."""
+    import ctypes
+    import warnings
+    from transformergrooveinfilling_amd import engine as E
+    from transformergrooveinfilling_amd.engine import StepEngine
+    dims = dict(d_model=128, n_heads=4, dim_feedforward=512, num_encoder_layers=2, num_decoder_layers=0, dropout=0.24, embedding_size_src=16)
+    B = 64                                                      # 4 x 64 = 256 workgroups: the whole chip
+    x, y = ng.synthetic_batch(B, 16, seed=4)
+
+    def make():
+        e = StepEngine(batch_size=B, optimizer="sgd", learning_rate=0.05, hit_loss_penalty=0.5, seed=3, **dims)
+        e.load_named(ng.init_params(dims, seed=1))
+        e.x.copy_(torch.from_numpy(x)); e.y.copy_(torch.from_numpy(y))
+        return e
+
+    lib = make().lib
+    try:
+        lib.cdll.gt_set_seq_quad(-1)
+        ref = make()
+        for _ in range(3):
+            ref.train_step()
+        torch.cuda.synchronize()
+        # (1) 96 CUs held for 30 ms by another stream while three QUAD steps are enqueued: partners are adjacent blocks, dispatched
+        #     together, so the exchange only ever waits for a dispatch slot -- same numbers, bit for bit, no time-out
+        eng = make()
+        side = torch.cuda.Stream()
+        lib.call("gt_debug_occupy_cus", 96, 30000, ctypes.c_void_p(side.cuda_stream))
+        for _ in range(3):
+            eng.train_step()
+        torch.cuda.synchronize()
+        assert not eng.check_exchange(eng.slot(B)) and eng.exchange_timeouts == 0
+        assert torch.equal(eng.params, ref.params)
+        # (2) a polling bound of one: exchanges give up at once.  The update is skipped on the device ...
+        lib.cdll.gt_set_xchg_spin_max(1)
+        before = eng.params.clone()
+        eng.train_step()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.params, before) and float(eng.grads.abs().max()) == 0.0
+        # ... the step path notices by itself (asynchronous 4-byte copy every XCHG_POLL_EVERY steps, looked at one poll later) ...
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            for _ in range(3 * E.XCHG_POLL_EVERY):
+                eng.train_step()
+                if eng.exchange_timeouts:
+                    break
+            torch.cuda.synchronize()
+        assert eng.exchange_timeouts == 1 and any("pair exchange" in str(w.message) for w in rec)
+        assert torch.equal(eng.params, before)                  # every step in between was a skipped one
+        # ... and from there on it trains on two workgroups per sequence, with the numbers of an undisturbed engine (fp32 rounding)
+        lib.cdll.gt_set_xchg_spin_max(0)
+        st = eng.state_struct()
+        eng.set_state(step=ref.state_struct().step, opt_step=ref.state_struct().opt_step)
+        ref.train_step(); eng.train_step()
+        torch.cuda.synchronize()
+        assert not eng.check_exchange(eng.slot(B))
+        assert (eng.params - ref.params).abs().max() < 2e-6 * ref.params.abs().max()
+        # evaluation forward and predict through a raised word: noticed at once, repeated on the fallback schedule
+        lib.cdll.gt_set_seq_quad(-1)
+        e2 = make()
+        want = e2.predict(torch.from_numpy(x)).clone()
+        s2 = e2.slot(B)
+        lib.cdll.gt_set_xchg_spin_max(1)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            got = e2.predict(torch.from_numpy(x))
+        lib.cdll.gt_set_xchg_spin_max(0)
+        assert e2.exchange_timeouts >= 1 and torch.equal(got[..., :9], want[..., :9]) and (got - want).abs().max() < 1e-5
+    finally:
+        lib.cdll.gt_set_xchg_spin_max(0)
+        lib.cdll.gt_set_seq_quad(-1)

@@ -32,7 +32,8 @@ def test_step_parity(cfg, B, p):
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(32, 4, 16, 1), 256, 0.1), (cfg_dict(64, 4, 64, 1), 256, 0.2), (cfg_dict(128, 4, 512, 1), 256, 0.24),
                                      (cfg_dict(256, 2, 512, 1), 256, 0.3), (cfg_dict(512, 8, 512, 1), 256, 0.15),
                                      (cfg_dict(256, 2, 512, 1, 1), 256, 0.1), (cfg_dict(512, 8, 512, 1), 512, 0.1),
-                                     (cfg_dict(256, 2, 512, 1), 512, 0.2)])
+                                     (cfg_dict(256, 2, 512, 1), 512, 0.2),
+                                     (cfg_dict(512, 8, 512, 1), 64, 0.15)])      # a GPU's share of configs[3]: 2048 tokens, 64x64 ring tiles (gt_gemm64.h: 256 / 768 tiles)
 def test_step_parity_large_batches(cfg, B, p):
     """M = 8192 / 16384 tokens: the 32- and 64-row LayerNorm-row tiles of every padded width, 128x128 GEMM tiles and the
     64x64 / 128x128-tile weight-gradient groups (mixed with 32x32-tile problems in one backward) -- tile choices the
@@ -155,7 +156,8 @@ def test_step_parity_bf16_operands(cfg, B, p):
 
 
 @pytest.mark.parametrize("cfg,B,p", [(cfg_dict(512, 8, 512, 1, embedding_size_src=27), 256, 0.24), (cfg_dict(128, 4, 512, 1), 256, 0.24),
-                                     (cfg_dict(256, 2, 512, 1, 1), 256, 0.1)])
+                                     (cfg_dict(256, 2, 512, 1, 1), 256, 0.1),
+                                     (cfg_dict(512, 8, 512, 1, embedding_size_src=27), 64, 0.24)])     # a GPU's share of configs[4]: both operands bf16 on 64x64 tiles (gemm64h_kernel)
 def test_step_parity_bf16_operands_large_batches(cfg, B, p):
     """8192 tokens: 128x128 / 64x64 bf16 tiles and the 64- and 128-tile weight-gradient groups"""
     parity.check_step_bf16("hip", cfg, B, p)
@@ -170,6 +172,7 @@ def test_bf16_shadows_of_the_gemm_operands():
     c5 = dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=2, num_decoder_layers=0, embedding_size_src=27)
     assert parity.check_bf16_shadows("hip", c5, 192, 0.3) == 31
     assert parity.check_bf16_shadows("hip", dict(c5, n_heads=16, num_encoder_layers=1), 192, 0.0) == 15
+    assert parity.check_bf16_shadows("hip", c5, 64, 0.3) == 31          # 2048 tokens: the same through the 64x64-tile kernels (gt_gemm64.h)
     lib = _lib.get_lib()
     try:
         for level in (2, 1):                        # 2 (the default): operand-only tensors in bf16 ALONE; 1: beside their fp32 tensors

@@ -40,6 +40,33 @@ static void run32(const char* tag, GemmArgs g, int reps) {
          100.0 * tf / 157.3);
 }
 
+template <bool BKM, int EPI, int PREC>
+static void run64(const char* tag, GemmArgs g, int reps) {
+  dim3 grid(g.N / 64, g.M / 64);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) gemm64_kernel<BKM, EPI, PREC><<<grid, 256>>>(g);
+  hipEventRecord(a);
+  for (int i = 0; i < reps; ++i) gemm64_kernel<BKM, EPI, PREC><<<grid, 256>>>(g);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double us = 1e3 * ms / reps, tf = 2.0 * g.M * g.N * g.K / us / 1e6;
+  printf("%-44s grid %5d x %3d  LDS %6d B  %8.1f us  %6.1f TFLOP/s  (%.1f %% of 157.3)\n", tag, grid.y, grid.x, (int)(Gemm64Cfg::SMEM * 4), us, tf,
+         100.0 * tf / 157.3);
+}
+template <int WHICH>
+static void runh(const char* tag, GemmArgs g, int reps) {
+  dim3 grid = WHICH == 64 ? dim3(g.N / 64, g.M / 64) : dim3(g.N / 128, g.M / 128);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < reps + 3; ++i) {
+    if (i == 3) hipEventRecord(a);
+    if (WHICH == 64) gemm64h_kernel<EPI_STORE><<<grid, 256>>>(g); else gemm32h_kernel<EPI_STORE><<<grid, 256>>>(g);
+  }
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double us = 1e3 * ms / reps, tf = 2.0 * g.M * g.N * g.K / us / 1e6;
+  printf("%-44s grid %5d x %3d  %8.1f us  %6.1f TFLOP/s\n", tag, grid.y, grid.x, us, tf);
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 3 ? atoi(argv[1]) : 16384, N = argc > 3 ? atoi(argv[2]) : 1536, K = argc > 3 ? atoi(argv[3]) : 512;
   float *A, *B, *C, *bias;
@@ -60,6 +87,18 @@ int main(int argc, char** argv) {
   // bring the chip to its loaded clock first: the first kernels of a process otherwise read 5-10 % low
   for (int i = 0; i < 200; ++i) gemm_kernel<2, 2, 4, 4, 32, false, false, EPI_STORE><<<dim3((N + 127) / 128, (M + 127) / 128), 256>>>(g);
   hipDeviceSynchronize();
+  if (gemm64_ok(g, EPI_STORE)) {
+    run64<false, EPI_STORE, 0>("gt_gemm64.h 64x64 32x32x2 ring, NT store", g, reps);
+    run64<false, EPI_RELU_DROP, 0>("gt_gemm64.h 64x64 32x32x2 ring, NT relu", g, reps);
+    run64<false, EPI_STORE, 1>("gt_gemm64.h 64x64 fp32 source -> bf16 MFMA", g, reps);
+    uint16_t *A16, *B16;
+    hipMalloc(&A16, (size_t)M * K * 2); hipMalloc(&B16, (size_t)N * K * 2);
+    hipMemset(A16, 0, (size_t)M * K * 2); hipMemset(B16, 0, (size_t)N * K * 2);
+    GemmArgs gh = g; gh.A16 = A16; gh.B16 = B16; gh.lda16 = gh.ldb16 = K; gh.bf16 = 1;
+    runh<64>("gt_gemm64.h 64x64 bf16 sources", gh, reps);
+    if (gemm32h_ok(gh, EPI_STORE)) runh<128>("gt_gemm32.h 128x128 bf16 sources", gh, reps);
+    runh<64>("gt_gemm64.h 64x64 bf16 sources", gh, reps);
+  }
   if (gemm32_ok(g, EPI_STORE, false)) {
     run32<false, EPI_STORE>("gt_gemm32.h 128x128 32x32x2 ring, NT store", g, reps);
     run32<false, EPI_RELU_DROP>("gt_gemm32.h 128x128 32x32x2 ring, NT relu", g, reps);
@@ -80,6 +119,7 @@ int main(int argc, char** argv) {
   g.ldb = N;   // B[k*ldb + n]: reuse the buffer as a (K x N) matrix (N*K floats)
   printf("NN (dgrad layout: B[k][n])\n");
   if (gemm32_ok(g, EPI_STORE, true)) run32<true, EPI_STORE>("gt_gemm32.h 128x128 32x32x2 ring, NN store", g, reps);
+  if (gemm64_ok(g, EPI_STORE)) run64<true, EPI_STORE, 0>("gt_gemm64.h 64x64 32x32x2 ring, NN store", g, reps);
   run<2, 2, 1, 1, 64, false, true, EPI_STORE>("32x32   <2,2,1,1,BK64>", g, reps);
   run<2, 2, 4, 4, 32, false, true, EPI_STORE>("128x128 <2,2,4,4,BK32>", g, reps);
   run<4, 2, 4, 4, 32, false, true, EPI_STORE>("256x128 <4,2,4,4,BK32> 8 waves", g, reps);

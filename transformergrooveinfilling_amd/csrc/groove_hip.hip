@@ -912,6 +912,10 @@ static bool seq_quad(const gt_config& c) {
   if (g_seq_quad < 0) { const char* e = getenv("GT_SEQ_QUAD"); if (e) g_seq_quad = e[0] != '0'; }
   return g_seq_quad != 0;
 }
+// bound of the pair exchange's polling loop (0 / negative: the compiled default).  A test lowers it to see the time-out path -- error
+// word, skipped update, host recovery -- without waiting seconds.
+static int g_xchg_spin_max = 0;
+extern "C" int gt_set_xchg_spin_max(int polls) { g_xchg_spin_max = polls; return 0; }
 static bool seq_supported(const gt_config& c) {
   const int hd = c.d_model / c.n_heads;
   return c.n_dec_layers == 0 && c.precision == 0 && c.d_model % 16 == 0 && c.d_model <= 128 && c.dim_ff % 16 == 0 &&
@@ -968,7 +972,7 @@ static SeqArgs mk_seq(const Ctx& x, const float* pe, const float* src, float* hv
   a.dlogits = x.W.dlogits; a.da0 = x.W.dctx; a.ln_part = x.W.ln_part; a.ln_part_stride = x.W.ln_part_stride;
   a.stamps = x.W.stamps;
   a.pack_f = x.W.pack_f; a.pack_b = x.W.pack_b; a.kstride = x.W.pack_stride;
-  a.dctx = x.W.seq_dctx; a.xchg = x.W.seq_xchg; a.xchg_b = x.W.seq_xchg >= 0 ? x.W.seq_xchg + gt_seq_xchg_floats(x.c.batch) : -1; a.fuse_b0 = 0; a.amask = x.W.seq_amask; a.amask_stride = x.W.seq_amask_stride; a.phase = 0;
+  a.dctx = x.W.seq_dctx; a.xchg = x.W.seq_xchg; a.xchg_b = x.W.seq_xchg >= 0 ? x.W.seq_xchg + gt_seq_xchg_floats(x.c.batch) : -1; a.fuse_b0 = 0; a.spin_max = g_xchg_spin_max > 0 ? g_xchg_spin_max : GT_XCHG_SPIN_MAX; a.amask = x.W.seq_amask; a.amask_stride = x.W.seq_amask_stride; a.phase = 0;
   a.loss_y = nullptr; a.loss_penalty = 0.f; a.loss_stats = nullptr; a.loss_part = nullptr; a.loss_ticket = nullptr;
   a.grd = nullptr; a.nseq = 0; a.wg_accumulate = 0; a.ride_last_k = x.M; a.out_early = 0; a.tail_phase = 0; a.tail_ksplit = 1; a.ln_nwg = 0; a.bump = nullptr;
   return a;
@@ -1646,6 +1650,26 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
     if (optimizer_step_impl(algo, params, grads, m, v, P.total, state, 1, stream, 1)) return -1;
   }
   return 0;
+}
+
+// ------------------------------------------------------------------------------------ test aid: hold CUs
+// nblocks workgroups that each pin 96 KB of LDS (no 136 KB sequence workgroup fits beside one) and spin for `usec` microseconds of the
+// 100 MHz constant clock: a second stream's kernel (an RCCL collective, an evaluation predict) holding CUs while a four-workgroups-per-
+// sequence launch is in flight (tests/test_hip_api.py: the step must come out right, or the engine must say that it did not).
+__global__ __launch_bounds__(64) void occupy_cus_kernel(int usec, unsigned* sink) {
+  __shared__ unsigned hold[24 * 1024];
+  hold[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+#ifndef GT_EMU
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)usec * 100ull) __builtin_amdgcn_s_sleep(32);
+#endif
+  if (hold[(threadIdx.x + 1) & 63] == 0xFFFFFFFFu && sink) *sink = 1u;      // (keeps the array alive)
+}
+extern "C" int gt_debug_occupy_cus(int nblocks, int usec, gt_stream_t stream) {
+  if (nblocks <= 0 || usec < 0) return gt_fail("gt_debug_occupy_cus: nblocks %d / usec %d", nblocks, usec);
+  gt_launch(occupy_cus_kernel, dim3(nblocks), dim3(64), (hipStream_t)stream, usec, (unsigned*)nullptr);
+  return launch_status("gt_debug_occupy_cus");
 }
 
 // ------------------------------------------------------------------------------------ evaluation metrics / input gather

@@ -40,6 +40,7 @@ void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsign
 void gt_seq_launch_update_pack(const SeqArgs& a, int algo, float* params, float* grads, float* m, float* v, int64_t n, const gt_step_state* st,
                                int step_advanced, hipStream_t s) {
   const int64_t frags = (int64_t)a.L * a.kstride / 256;
-  SeqUpd u{params, grads, m, v, n, st, algo, step_advanced, (int)((frags + 3) / 4)};
+  SeqUpd u{params, grads, m, v, n, st, algo, step_advanced, (int)((frags + 3) / 4),
+           a.xchg >= 0 ? reinterpret_cast<const unsigned*>(a.ws + a.xchg) : nullptr};
   gt_launch(seq_update_pack_kernel, dim3((unsigned)(u.nblk_a + (n / 4 + 255) / 256 + 1)), dim3(256), s, a, u);
 }

@@ -26,6 +26,8 @@
 #pragma once
 #include "gt_common.h"
 #include <type_traits>
+#include <stdio.h>
+#include <stdlib.h>
 
 #ifndef GT_MIDSLAB_STORE
 #define GT_MIDSLAB_STORE 1
@@ -909,6 +911,28 @@ static inline void gemm32h_launch(const GemmArgs& g, hipStream_t s);
                                    the bf16-only storage it comes with pays by itself -- C5 at 64 sequences per GPU 1.282 -> 1.206 ms (the fp32 body at 64
                                    tiles: C4 bs 64 1.65 -> 2.75 ms) */
 #endif
+// 64x64 tiles on the ring body (gt_gemm64.h, round 5): interior problems of GT_T64R_MIN .. GT_T64R_MAX tiles of 64x64 -- too few 128x128
+// tiles to fill 256 CUs evenly, enough 64x64 ones (d_model 512 at 2048 tokens: N = 512 -> 256 tiles, QKV -> 768 = 3 per CU)
+static inline bool gemm64_ok(const GemmArgs& g, int epi);
+template <bool BKM, int EPI>
+static inline void gemm64_launch(const GemmArgs& g, hipStream_t s);
+static inline bool gemm64h_ok(const GemmArgs& g, int epi);
+template <bool BKM, int EPI>
+static inline void gemm64h_launch(const GemmArgs& g, hipStream_t s);
+#ifndef GT_T64R_MIN
+#define GT_T64R_MIN 192
+#endif
+#ifndef GT_T64R_MAX
+#define GT_T64R_MAX 2047        /* 64x64 tiles; from 512 tiles of 128x128 the big tile (half the operand bytes per flop) has two full rounds */
+#endif
+#ifndef GT_T64H_MAX
+#define GT_T64H_MAX 2047
+#endif
+static inline long gt_env_long(const char* name, long dflt) { const char* e = getenv(name); return (e && e[0]) ? atol(e) : dflt; }
+static inline bool gemm64_range(long t64, bool h) {
+  static const long lo = gt_env_long("GT_T64R_MIN", GT_T64R_MIN), hi = gt_env_long("GT_T64R_MAX", GT_T64R_MAX), hih = gt_env_long("GT_T64H_MAX", GT_T64H_MAX);
+  return t64 >= lo && t64 <= (h ? hih : hi);
+}
 // standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
 template <bool AKM, bool BKM, int EPI>
 static inline void gemm_launch(GemmArgs g, hipStream_t s) {
@@ -920,6 +944,9 @@ static inline void gemm_launch(GemmArgs g, hipStream_t s) {
     return;
   }
   if constexpr (!AKM && (EPI == EPI_STORE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_NZ || EPI == EPI_ADD_RELUMASK_DROP)) {
+    const long b64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    if (g.bf16 && gemm64_range(b64, true) && gemm64h_ok(g, EPI)) { gemm64h_launch<BKM, EPI>(g, s); return; }       // both operands as bf16 shadows
+    if (!(g.bf16 && g.A16 && g.B16) && gemm64_range(b64, false) && gemm64_ok(g, EPI)) { gemm64_launch<BKM, EPI>(g, s); return; }
     const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     if (g.bf16 && b128 >= GT_T128H_MIN && gemm32h_ok(g, EPI)) { gemm32h_launch<BKM, EPI>(g, s); return; }     // both operands as bf16 shadows
     if (g.bf16 && b128 >= GT_T128_BIG_MIN && gemm32_ok(g, EPI, BKM)) { gemm32_launch<BKM, EPI>(g, s); return; }
@@ -1005,3 +1032,4 @@ static inline int gemm_launch_row(GemmArgs g, hipStream_t s) {
 }
 
 #include "gt_gemm32.h"
+#include "gt_gemm64.h"

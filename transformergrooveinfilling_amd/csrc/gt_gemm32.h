@@ -42,24 +42,24 @@ static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm) {
   return true;
 }
 
-// The store epilogues of the 128x128 tile (transposed product: lane (r32, h) holds ONE row of C per 32x32 tile and, in registers
+// The store epilogues of a tile of TA x TB 32x32 blocks per wave (128x128: 2 x 2; gt_gemm64.h: 1 x 1) (transposed product: lane (r32, h) holds ONE row of C per 32x32 tile and, in registers
 // 4 q .. 4 q + 3, the four consecutive columns 8 q + 4 h + 0..3): two-phase -- every global input first, then compute + 16-byte stores.
 // g.C16: a bf16 copy of the stored values as well (8-byte stores), for a consumer that takes this output as a GEMM operand.
-template <int EPI>
-__device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
+template <int EPI, int TA = 2, int TB = 2>
+__device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f32x16 (&acc)[TA][TB], const int m0, const int n0, const int wm, const int wn,
                                                       const int r32, const int h) {
   const uint32_t dkey = gt_drop_key(g.drop);
 #pragma unroll
-  for (int tb = 0; tb < 2; ++tb) {
-    f32x4 bia[4], rin[2][4], rin2[2][4];
+  for (int tb = 0; tb < TB; ++tb) {
+    f32x4 bia[4], rin[TA][4], rin2[TA][4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-      const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
+      const int col = n0 + wn * (32 * TB) + tb * 32 + 8 * q4 + 4 * h;
       bia[q4] = f32x4{0.f, 0.f, 0.f, 0.f};
       if ((EPI == EPI_STORE || EPI == EPI_RELU_DROP) && g.bias != nullptr) bia[q4] = *reinterpret_cast<const f32x4*>(g.bias + col);
 #pragma unroll
-      for (int ta = 0; ta < 2; ++ta) {
-        const int row = m0 + wm * 64 + ta * 32 + r32;
+      for (int ta = 0; ta < TA; ++ta) {
+        const int row = m0 + wm * (32 * TA) + ta * 32 + r32;
         rin[ta][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI == EPI_STORE && g.accumulate) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.C + (size_t)row * g.ldc + col);
         if (EPI == EPI_MASK_NZ && g.res16 != nullptr) {      // the mask source (hact) lives in bf16 only: zero / non-zero is all that is asked
@@ -72,10 +72,10 @@ __device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f
     }
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-      const int col = n0 + wn * 64 + tb * 32 + 8 * q4 + 4 * h;
+      const int col = n0 + wn * (32 * TB) + tb * 32 + 8 * q4 + 4 * h;
 #pragma unroll
-      for (int ta = 0; ta < 2; ++ta) {
-        const int row = m0 + wm * 64 + ta * 32 + r32;
+      for (int ta = 0; ta < TA; ++ta) {
+        const int row = m0 + wm * (32 * TA) + ta * 32 + r32;
         f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -112,9 +112,7 @@ __device__ __forceinline__ float seq_row16_sum(float v) {
 // co-resident) raises the region's error word instead of hanging the GPU.
 #define GT_XTAG 0x5EC0DE01u
 #define GT_XCHG_WG_GRANULES (4 * GT_SEQ_NT)          /* 8-byte granules per workgroup slot (16 KB) */
-#ifndef GT_XCHG_SPIN_MAX
-#define GT_XCHG_SPIN_MAX (1 << 22)
-#endif
+// (GT_XCHG_SPIN_MAX, the default bound of the polling loop: gt_seq_api.h)
 #ifdef GT_EMU
 #define GT_XTAG_NOW (GT_XTAG + emu::launch_serial)     /* (the emulator re-runs a waiting workgroup: a per-launch tag instead of the reset) */
 #else
@@ -131,7 +129,7 @@ __device__ __forceinline__ void seq_xchg_put(unsigned long long* slot, const f32
 #endif
   }
 }
-__device__ __forceinline__ f32x4 seq_xchg_get(unsigned long long* slot, const int tid, unsigned* err) {
+__device__ __forceinline__ f32x4 seq_xchg_get(unsigned long long* slot, const int tid, unsigned* err, const int spin_max = GT_XCHG_SPIN_MAX) {
   unsigned long long w[4];
 #ifdef GT_EMU
   bool ok = true;
@@ -147,7 +145,7 @@ __device__ __forceinline__ f32x4 seq_xchg_get(unsigned long long* slot, const in
       ok = ok && (uint32_t)(w[j] >> 32) == GT_XTAG;
     }
     if (__all(ok)) break;                                      // (wave-uniform exit: the lanes of a wave leave together)
-    if (++spins > GT_XCHG_SPIN_MAX) { if ((tid & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    if (++spins > spin_max) { if ((tid & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     __builtin_amdgcn_s_sleep(1);
   }
 #pragma unroll
@@ -252,9 +250,15 @@ __global__ __launch_bounds__(256) void seq_pack_kernel(SeqArgs a) {
 // the parameter buffer, the forward fragment (the block as loaded: lane (l16, lg) = row l16, columns 4 lg ..) and -- transposed through
 // 1 KB of LDS -- the dgrad fragment; the gradient is consumed and zeroed.  Part B: every other parameter (biases, LayerNorms, input /
 // output layer), the flat sweep of sgd_kernel / adam_kernel.  Same arithmetic as those kernels, element for element.
-struct SeqUpd { float* prm; float* g; float* m; float* v; int64_t n; const gt_step_state* st; int algo, step_advanced, nblk_a; };
+// err: the QUAD pair-exchange region's error word (nullptr: no such region).  A timed-out exchange (partner workgroups not co-resident: the
+// launch went on with garbage partials) must never reach the parameters: with the word set the update leaves parameters and moments as
+// they are -- only the consumed gradients are cleared and the weight copies rewritten -- and the word stays set until the host has seen it
+// (StepEngine.check_exchange: zeroes the region, falls back to two workgroups per sequence).
+struct SeqUpd { float* prm; float* g; float* m; float* v; int64_t n; const gt_step_state* st; int algo, step_advanced, nblk_a; const unsigned* err; };
 __device__ __forceinline__ float seq_upd_elem(const SeqUpd& u, const int64_t i, const float w, const float g, const float k, const float b1,
-                                              const float b2, const float step_size, const float inv_sqrt_bc2, const float gs, const float eps) {
+                                              const float b2, const float step_size, const float inv_sqrt_bc2, const float gs, const float eps,
+                                              const bool skip) {
+  if (skip) return w;
   if (u.algo == 0) return w - k * g;
   const float gi = g * gs;
   const float mi = b1 * u.m[i] + (1.0f - b1) * gi;
@@ -273,6 +277,9 @@ __global__ __launch_bounds__(256) void seq_update_pack_kernel(SeqArgs a, SeqUpd 
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
     step_size = u.st->lr / bc1; inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
   }
+  // (the word: written through by an earlier launch of this stream; g[n - 1]: padding behind the 27-float output bias -- zero in a single
+  //  process; a data-parallel host writes its error flag there before the gradient all-reduce, so that EVERY rank skips together)
+  const bool skip = (u.err != nullptr && *u.err != 0u) || u.g[u.n - 1] != 0.f;
   const int d = a.d, F = a.F, d16 = d >> 4, f16 = F >> 4;
   const int nf0 = 3 * d16 * d16, nf1 = d16 * d16, nf2 = f16 * d16, T = nf0 + nf1 + 2 * nf2;
   if ((int)blockIdx.x < u.nblk_a) {
@@ -289,10 +296,10 @@ __global__ __launch_bounds__(256) void seq_update_pack_kernel(SeqArgs a, SeqUpd 
     const int64_t e0 = src + (int64_t)l * a.pstride + (int64_t)(16 * br + l16) * C + 16 * bc + 4 * lg;
     const float4 w = *reinterpret_cast<const float4*>(u.prm + e0), g = *reinterpret_cast<const float4*>(u.g + e0);
     float4 nw;
-    nw.x = seq_upd_elem(u, e0, w.x, g.x, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
-    nw.y = seq_upd_elem(u, e0 + 1, w.y, g.y, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
-    nw.z = seq_upd_elem(u, e0 + 2, w.z, g.z, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
-    nw.w = seq_upd_elem(u, e0 + 3, w.w, g.w, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
+    nw.x = seq_upd_elem(u, e0, w.x, g.x, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps, skip);
+    nw.y = seq_upd_elem(u, e0 + 1, w.y, g.y, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps, skip);
+    nw.z = seq_upd_elem(u, e0 + 2, w.z, g.z, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps, skip);
+    nw.w = seq_upd_elem(u, e0 + 3, w.w, g.w, k, b1, b2, step_size, inv_sqrt_bc2, gs, eps, skip);
     *reinterpret_cast<float4*>(u.prm + e0) = nw;
     *reinterpret_cast<float4*>(u.g + e0) = make_float4(0.f, 0.f, 0.f, 0.f);
     float* pf = a.ws + a.pack_f + (int64_t)l * a.kstride + moff;
@@ -316,8 +323,8 @@ __global__ __launch_bounds__(256) void seq_update_pack_kernel(SeqArgs a, SeqUpd 
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    if (i + e < u.n) {
-      u.prm[i + e] = seq_upd_elem(u, i + e, u.prm[i + e], u.g[i + e], k, b1, b2, step_size, inv_sqrt_bc2, gs, eps);
+    if (i + e < u.n - 1) {                                        // (n - 1: the guard element, neither updated nor cleared)
+      u.prm[i + e] = seq_upd_elem(u, i + e, u.prm[i + e], u.g[i + e], k, b1, b2, step_size, inv_sqrt_bc2, gs, eps, skip);
       u.g[i + e] = 0.f;
     }
   }
@@ -1487,7 +1494,7 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
       if (last && cpart == 1 && !fz) return true;                   // (workgroup-uniform)
       *reinterpret_cast<float4*>(&sR[(16 * cpart + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
       GT_STAMP(301 + 4 * l);
-      const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg));
+      const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg), a.spin_max);
       GT_STAMP(302 + 4 * l);
       *reinterpret_cast<float4*>(&sR[(16 * (1 - cpart) + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(oth[0], oth[1], oth[2], oth[3]);
     } else {
@@ -1850,7 +1857,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
       unsigned long long* const xq = reinterpret_cast<unsigned long long*>(ws + xoff) + 8;
       seq_xchg_put(xq + (size_t)vb * GT_XCHG_WG_GRANULES, acc0, tid);
       *reinterpret_cast<float4*>(&sR[(16 * cpart + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
-      const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg));       // (one error word: the forward region's header)
+      const f32x4 oth = seq_xchg_get(xq + (size_t)(vb ^ 1) * GT_XCHG_WG_GRANULES, tid, reinterpret_cast<unsigned*>(ws + a.xchg), a.spin_max);       // (one error word: the forward region's header)
       *reinterpret_cast<float4*>(&sR[(16 * (1 - cpart) + l16) * SRS + 16 * wave + 4 * lg]) = make_float4(oth[0], oth[1], oth[2], oth[3]);
     } else {
       seq_tile_out(tl + a.t0.dhid + r0 * F, sH, SH, F, tid, rb, NROW);

@@ -4,6 +4,9 @@
 #include "gt_common.h"
 
 #define GT_SEQ_FMAX 512
+#ifndef GT_XCHG_SPIN_MAX
+#define GT_XCHG_SPIN_MAX (1 << 22)      /* polls of the QUAD pair exchange before a workgroup gives its partner up (seconds); gt_set_xchg_spin_max overrides */
+#endif
 struct SeqLayerP { int64_t in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
 struct SeqLayerW { int64_t qkv, P, ctx, xhat1, rstd1, x1, hact, xhat2, rstd2, xout; };
 struct SeqTmp { int64_t dzA, dzAm, dzB, dzBm, dhid, dqkv; };
@@ -26,6 +29,7 @@ struct SeqArgs {
   int64_t xchg;                                              // QUAD forward: the pair-exchange region (8 header granules, then one 16 KB slot per
                                                              // workgroup; zero between launches -- gt_workspace_init); -1: none
   int64_t xchg_b; int fuse_b0;                               // QUAD, fused step: the last forward launch goes on into backward phase 0 (seq_fb_kernel), whose pair exchange uses the region at xchg_b
+  int spin_max;                                              // bound of the pair exchange's polling loop (gt_set_xchg_spin_max; default GT_XCHG_SPIN_MAX)
   int quad_pro;                                              // QUAD forward: input layer + in-proj(0) ran as a prologue launch (phase -1)
   int phase;                                                 // SPLIT kernels: which phase this launch runs
   // fused loss (gt_train_step): the launch that runs the output layer also computes the loss terms, d loss / d logits and the

@@ -28,6 +28,7 @@ PREDICT_WS_BYTES = 32 << 30            # ... the chunk grows (x2) while its work
 PREDICT_WS_KEEP = 4 << 30              # predict() keeps a workspace between calls only up to this size (a per-epoch evaluation must not pin tens of GiB)
 MAX_GRAPHS = 4                         # captured step graphs kept per slot (least recently used dropped first)
 MAX_SLOTS = 6                          # per-batch-size step slots kept (least recently created dropped first; the engine's own batch size stays)
+XCHG_POLL_EVERY = 32                   # train steps between two asynchronous reads of the QUAD pair exchange's error word (see poll_exchange)
 
 
 def _ptr(t):
@@ -57,6 +58,9 @@ class _Slot:
         self.fwd_id = 0                # bumped by every call that overwrites the saved activations (see StepEngine.forward)
         self.pack_epoch = -1           # StepEngine._pepoch at which this workspace's fragment-ordered weight copies were written
         self.xchg_off = None           # workspace offset of the QUAD pair-exchange region's error word (-1: none; looked up lazily)
+        self.xchg_host = None          # pinned int32 the error word is copied into, asynchronously, every XCHG_POLL_EVERY-th train step
+        self.xchg_event = None         # ... the event behind that copy
+        self.xchg_count = 0
 
 
 class _LossSlot:
@@ -124,6 +128,9 @@ class StepEngine:
         # GT_DP_GRAPH=1: the whole data-parallel step (collectives included) as ONE captured hipGraph per step (measured with
         # bench.py --force-dp; off by default: it could not be exercised with more than one rank on the 1-GPU boxes of the build)
         self.dp_graph = os.environ.get("GT_DP_GRAPH", "0") == "1"
+        self.dp_graph_failed = False   # a capture of the one-enqueue step failed once: eager sequence from then on (_dp_whole)
+        self.dp_tune = None            # autotune_dp's table: {mode: ms per step (max over ranks)} and the mode kept
+        self._capturing = False        # inside _replay's warm-up launch / capture: the recipe being recorded must not depend on the moment
         self._slots = {}
         # Fused whole steps on the sequence-resident path end with an update that also writes the next step's fragment-ordered
         # weights into the slot's workspace (GT_STEP_PACKS_CURRENT): valid while nothing else has written the parameters --
@@ -133,6 +140,8 @@ class StepEngine:
         self._loss_slots = {}
         self._train_B = None           # batch size of the most recent train step (its slot is never evicted)
         self._predict_ws = {}          # chunk size -> (cfg, workspace, tgt scratch) of predict()
+        self.exchange_timeouts = 0     # QUAD pair exchanges that timed out (each: updates skipped until noticed, then SPLIT schedule)
+        self.xchg_strict = os.environ.get("GT_XCHG_STRICT", "0") == "1"       # raise instead of recovering
         self.B = int(batch_size) if batch_size else None
         if self.B:
             self.slot(self.B)
@@ -214,7 +223,7 @@ class StepEngine:
         """Are the fragment-ordered weight copies in slot s's workspace those of the current parameters?  (written by the last
         fused update on THIS slot, nothing -- the engine or torch -- has written the parameters since; never under graph replay:
         a captured graph would replay the flag blindly)"""
-        return (self.fold_pack and not self.graph_for(s) and s.pack_epoch == self._pepoch
+        return (self.fold_pack and not self._capturing and not self.graph_for(s) and s.pack_epoch == self._pepoch
                 and self._pver == self.params._version)
 
     def _note_fused_step(self, s):
@@ -273,21 +282,91 @@ class StepEngine:
             side.wait_stream(torch.cuda.current_stream(self.device))
             snap = (self.params.clone(), self.state.clone(), None if self.m is None else (self.m.clone(), self.v.clone()),
                     self.grads.clone())
-            with torch.cuda.stream(side):
-                fn()
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            torch.cuda.synchronize(self.device)
-            self.params.copy_(snap[0]); self.state.copy_(snap[1])
-            if snap[2] is not None:
-                self.m.copy_(snap[2][0]); self.v.copy_(snap[2][1])
-            self.grads.copy_(snap[3])             # zeros for a whole-step graph (gt_train_step's precondition), else what the first half left
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                fn()
+            self._capturing = True                # (no GT_STEP_PACKS_CURRENT in a recorded recipe: a replay would pass it blindly)
+            try:
+                with torch.cuda.stream(side):
+                    fn()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                self.params.copy_(snap[0]); self.state.copy_(snap[1])
+                if snap[2] is not None:
+                    self.m.copy_(snap[2][0]); self.v.copy_(snap[2][1])
+                self.grads.copy_(snap[3])         # zeros for a whole-step graph (gt_train_step's precondition), else what the first half left
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+            finally:
+                self._capturing = False
             s.graphs[key] = g
         g = s.graphs.pop(key)
         s.graphs[key] = g                         # (most recently used last)
         g.replay()
+
+    def _dp_whole(self, s, key, whole):
+        """The data-parallel step as ONE captured hipGraph (collectives included) -- with a way back: a capture that fails (a collective
+        that cannot be recorded on this stack, an allocator call inside the capture) is logged once and the step, like every later one,
+        runs as the eager sequence in this same process.  Every rank issues the same collectives in the same order either way (the
+        warm-up pass and the eager sequence call exactly what the graph records), so ranks need not agree on the outcome."""
+        if not self.dp_graph_failed:
+            try:
+                self._replay(s, key, whole, force=True)
+                self._note_fused_step(s)          # (after the replay: the update inside it wrote the next step's weight copies)
+                return
+            except Exception as e:                # noqa: BLE001 -- whatever the capture raised
+                import warnings
+                self.dp_graph_failed = True
+                s.graphs.pop(key, None)
+                if not self.on_host:
+                    torch.cuda.synchronize(self.device)
+                warnings.warn("data-parallel step: hipGraph capture failed (%s: %s); falling back to the eager sequence" %
+                              (type(e).__name__, e), RuntimeWarning)
+        whole()
+
+    def autotune_dp(self, steps=30, warmup=3, modes=None):
+        """world > 1: time `steps` steps of every data-parallel recipe -- {single all-reduce, two overlapped buckets} x {eager sequence,
+        one hipGraph per step} -- on the engine's static batch, keep the fastest.  Every rank takes the MAX over ranks of each time (one
+        tiny all-reduce per recipe), so all ranks keep the same recipe.  Parameters, optimizer state and step counters are restored:
+        the run that follows is the run that would have been.  -> {"modes": {name: ms}, "chosen": name}"""
+        import time
+        import torch.distributed as dist
+        s = self.slot(self.B)
+        two = len(self.lib.grad_buckets(s.cfg)) == 2
+        cand = [(False, False)] + ([(True, False)] if two else [])
+        if not self.on_host:
+            cand += [(False, True)] + ([(True, True)] if two else [])
+        if modes is not None:
+            cand = [c for c in cand if c in modes]
+        name = lambda c: ("buckets" if c[0] else "plain") + ("_graph" if c[1] else "_eager")
+        snap = (self.params.clone(), self.state.clone(), None if self.m is None else (self.m.clone(), self.v.clone()))
+        sync = (lambda: None) if self.on_host else (lambda: torch.cuda.synchronize(self.device))
+        table = {}
+        for c in cand:
+            self.overlap_allreduce, self.dp_graph = c
+            self.dp_graph_failed = False
+            t = float("inf")
+            try:
+                for _ in range(warmup):
+                    self.train_step()
+                sync(); dist.barrier(); t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.train_step()
+                sync(); t = (time.perf_counter() - t0) / steps * 1e3
+                if c[1] and self.dp_graph_failed:
+                    t = float("inf")               # (it ran, but as the eager sequence)
+            except Exception:                      # noqa: BLE001 -- a recipe that cannot run on this stack is simply not chosen
+                sync()
+            tt = torch.tensor([t if t != float("inf") else 1e30], dtype=torch.float64, device=self.device if not self.on_host else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            table[name(c)] = float(tt)
+            self.params.copy_(snap[0]); self.state.copy_(snap[1]); self.grads.zero_()
+            if snap[2] is not None:
+                self.m.copy_(snap[2][0]); self.v.copy_(snap[2][1])
+            self._pepoch += 1                      # (the parameters were rewritten: every slot's weight copies are stale)
+        best = min(cand, key=lambda c: table[name(c)])
+        self.overlap_allreduce, self.dp_graph = best
+        self.dp_graph_failed = False
+        self.dp_tune = {"modes": {k: (None if v >= 1e29 else round(v, 5)) for k, v in table.items()}, "chosen": name(best), "steps": steps}
+        return self.dp_tune
 
     def _watched_step(self, s, on_grads):
         """One step with the gradients VISIBLE between backward and update: forward + loss + backward (skip_update = 1), on_grads() --
@@ -318,6 +397,7 @@ class StepEngine:
         else:
             import torch.distributed as dist
             buckets = self.lib.grad_buckets(s.cfg) if self.overlap_allreduce else []
+            guard = self._guard_fn(s)
             if self.dp_graph and on_grads is None and not self.on_host:
                 # ONE enqueue per step: forward + backward, the all-reduce(s) and the update captured in one hipGraph -- the collectives are
                 # nodes of the graph (RCCL enqueues on its own stream: fork / join edges), nothing returns to Python between the halves
@@ -325,16 +405,18 @@ class StepEngine:
                     if len(buckets) == 2:
                         (o0, c0), (o1, c1) = buckets
                         self._enqueue_step(s, 2)
+                        guard()
                         w0 = dist.all_reduce(self.grads[o0:o0 + c0], async_op=True)
                         self._enqueue_step(s, 3)
                         w1 = dist.all_reduce(self.grads[o1:o1 + c1], async_op=True)
                         w0.wait(); w1.wait()
                     else:
                         self._enqueue_step(s, 1)
+                        guard()
                         dist.all_reduce(self.grads)
                     self.enqueue_update(slot=s)
-                self._note_fused_step(s)
-                self._replay(s, ("dp_whole", self.algo, self.penalty, len(buckets)), whole, force=True)
+                self._dp_whole(s, ("dp_whole", self.algo, self.penalty, len(buckets)), whole)
+                self.poll_exchange(s)
                 return s.stats
             if len(buckets) == 2:
                 # bucketed overlap: graph A ends as soon as the upper bucket's gradients are final; its
@@ -342,6 +424,7 @@ class StepEngine:
                 # captured graphs.  Sums over ranks; averaged by grad_scale inside the optimizer kernel.
                 (o0, c0), (o1, c1) = buckets
                 self._replay(s, ("bwd_top", self.algo, self.penalty), lambda: self._enqueue_step(s, 2))
+                guard()
                 w0 = dist.all_reduce(self.grads[o0:o0 + c0], async_op=True)
                 if self.graph_for(s) and ("bwd_rest", self.algo, self.penalty) not in s.graphs:
                     w0.wait()                     # first step only: the capture warm-up snapshots and restores the gradient buffer
@@ -350,10 +433,12 @@ class StepEngine:
                 w0.wait(); w1.wait()
             else:
                 self._replay(s, ("fwdbwd", self.algo, self.penalty), lambda: self._enqueue_step(s, 1))
+                guard()
                 dist.all_reduce(self.grads)                  # RCCL sum over xGMI; averaged by grad_scale
             if on_grads is not None:
                 on_grads()                        # (data-parallel: the all-reduced sums; the update averages them by grad_scale)
             self.enqueue_update(slot=s)
+        self.poll_exchange(s)
         return s.stats
 
     def train_step_indexed(self, xs, ys, idx, on_grads=None):
@@ -382,6 +467,7 @@ class StepEngine:
                 s.keep[gkey] = (xs, ys)           # the captured graph holds their raw pointers: keep the tensors alive with it
                 for k in [k for k in s.keep if k not in s.graphs]:
                     del s.keep[k]
+            self.poll_exchange(s)
             return s.stats
         gather()
         return self.train_step(B=s.B)
@@ -416,9 +502,16 @@ class StepEngine:
         s.x.copy_(x)
         if tgt_in is not None:
             s.tgt.copy_(tgt_in)
-        self.lib.call("gt_forward", ctypes.byref(s.cfg), _ptr(self.params), _ptr(self.pe), _ptr(s.x),
-                      None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(s.ws), _ptr(self.state),
-                      int(train), self.stream)
+        def run():
+            self.lib.call("gt_forward", ctypes.byref(s.cfg), _ptr(self.params), _ptr(self.pe), _ptr(s.x),
+                          None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(s.ws), _ptr(self.state),
+                          int(train), self.stream)
+        run()
+        # evaluation forwards are consumed on the host right away: a timed-out pair exchange is noticed here and the forward repeated on
+        # the fallback schedule (a forward has no side effects).  Training forwards of the module API are covered by the device-side
+        # skip of the update (backward_guard) and the next synchronising check.
+        if not train and not self.on_host and self._xchg_word(s) is not None and self.check_exchange(s, "an evaluation forward"):
+            run()
         return s.hvo
 
     def loss(self, s, y, penalty, want_grad=True):
@@ -433,6 +526,11 @@ class StepEngine:
         self.lib.call("gt_backward", ctypes.byref(s.cfg), _ptr(self.params), _ptr(self.grads), _ptr(s.x),
                       None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(d_hvo), _ptr(s.ws), _ptr(self.state),
                       int(train), int(accumulate), self.stream)
+        # module API (loss.backward(); opt.step() -- any torch optimizer): gradients computed through a timed-out pair exchange are
+        # garbage; they are zeroed on the device (no synchronisation) so that the step that follows is a no-op instead of a corruption
+        w = self._xchg_word(s)
+        if w is not None and not self.on_host:
+            self.grads.masked_fill_((w != 0).expand(self.total), 0.0)
 
     def predict_chunk(self, n):
         """Sequences per gt_predict call for a set of n: as many as fit the workspace budget (greedy decoding is launch-bound --
@@ -451,6 +549,20 @@ class StepEngine:
         return chunk
 
     def predict(self, x, use_thres=True, thres=0.5, chunk=None, pd_seed=None):
+        out = self._predict(x, use_thres, thres, chunk, pd_seed)
+        if not self.on_host:
+            bad = False
+            for m, (cfg, ws, _) in list(self._predict_ws.items()):
+                w = self._xchg_word(ws, cfg)
+                if w is not None and int(w.item()) != 0:
+                    self._recover_exchange(ws, cfg, "predict")
+                    bad = True
+            if bad:                                 # (predict has no side effects: repeat on the fallback schedule)
+                out = self._predict(x, use_thres, thres, chunk, pd_seed)
+        self._trim_predict_ws()
+        return out
+
+    def _predict(self, x, use_thres=True, thres=0.5, chunk=None, pd_seed=None):
         """model.predict for ANY batch size (ref:evaluator.py:173 passes the whole evaluation set at once):
         returns a (N,32,27) HVO tensor on the device ([h | v | o], one D2H for the evaluator).  The set is walked in chunks
         of `chunk` sequences (default: predict_chunk) over one cached workspace (sized for a chunk, not for N)."""
@@ -478,33 +590,113 @@ class StepEngine:
                 continue
             self.lib.call("gt_predict", ctypes.byref(cfg), _ptr(self.params), _ptr(self.pe), _ptr(x[i:i + m]), _ptr(out[i:i + m]),
                           ctypes.c_float(thres), int(use_thres), _ptr(tgt), _ptr(ws), self.stream)
-        for m in [k for k, (_, ws, _) in self._predict_ws.items() if 4 * ws.numel() > PREDICT_WS_KEEP]:
-            del self._predict_ws[m]               # (stream-ordered free: the caching allocator keeps the block until the launches ran)
         return out
 
-    def check_exchange(self, s):
-        """The QUAD forward's pair exchange spins with a bound: a partner workgroup that never arrives (the two were not resident at the
-        same time) raises an error word in the exchange region instead of hanging the GPU -- the step's numbers are then garbage.
-        Called where the host synchronises anyway (the logging path): raises if the word is set."""
-        if s.xchg_off is None:
-            try:
-                s.xchg_off = self.lib.ws_find(s.cfg, "seq_xchg")[0]
-            except Exception:
-                s.xchg_off = -1
-        if s.xchg_off >= 0 and int(s.ws[s.xchg_off:s.xchg_off + 1].view(torch.int32).item()) != 0:
-            raise RuntimeError("sequence kernels: a pair exchange of the four-workgroups-per-sequence forward timed out "
-                               "(partner workgroups not co-resident); set GT_SEQ_QUAD=0")
+    def _trim_predict_ws(self):
+        for m in [k for k, (_, ws, _) in self._predict_ws.items() if 4 * ws.numel() > PREDICT_WS_KEEP]:
+            del self._predict_ws[m]               # (stream-ordered free: the caching allocator keeps the block until the launches ran)
+
+    # ---- QUAD pair exchange: what happens when partner workgroups were not co-resident ---------------------------------------
+    # The exchange polls with a bound (csrc/gt_seq.h, seq_xchg_get); a workgroup that gives its partner up raises the error word at the
+    # head of the slot's "seq_xchg" region and goes on with garbage.  Device side, the fused update refuses to apply anything while the
+    # word is set (parameters and moments untouched, gradients cleared) -- and, data-parallel, while the all-reduced guard element is
+    # non-zero, so every rank skips together.  Host side: the word is read (a) asynchronously every XCHG_POLL_EVERY-th train step
+    # (poll_exchange: a 4-byte copy into pinned memory, looked at one poll later -- no synchronisation on the step path), (b) wherever the
+    # host synchronises anyway: mean_stats (the logging path), eval forwards, predict.  On a set word the engine zeroes the region, falls
+    # back to two workgroups per sequence for the rest of the process (gt_set_seq_quad(0): same numbers, no in-launch exchange), drops
+    # the captured graphs and warns -- or raises, with GT_XCHG_STRICT=1.  The steps in between were skipped, never applied.
+    def _xchg_word(self, s_or_ws, cfg=None):
+        """1-element int32 view of the error word of a slot (or of a (cfg, workspace) pair), None when the shape has no such region."""
+        if cfg is None:
+            s = s_or_ws
+            if s.xchg_off is None:
+                try:
+                    s.xchg_off = self.lib.ws_find(s.cfg, "seq_xchg")[0]
+                except Exception:
+                    s.xchg_off = -1
+            return s.ws[s.xchg_off:s.xchg_off + 1].view(torch.int32) if s.xchg_off >= 0 else None
+        try:
+            off = self.lib.ws_find(cfg, "seq_xchg")[0]
+        except Exception:
+            return None
+        return s_or_ws[off:off + 1].view(torch.int32) if off >= 0 else None
+
+    def _guard_fn(self, s):
+        """Data-parallel: before the gradient all-reduce every rank writes its error flag into the guard element (the last float of the
+        gradient buffer: padding behind the 27-float output bias); the update kernel of EVERY rank skips when the sum is non-zero."""
+        w = self._xchg_word(s)
+        if w is None:
+            return lambda: None
+        g = self.grads[self.total - 1:]
+        return lambda: g.copy_(w != 0)
+
+    def _recover_exchange(self, ws, cfg, what):
+        self.exchange_timeouts += 1
+        msg = ("sequence kernels: a pair exchange of the four-workgroups-per-sequence schedule timed out during %s (partner workgroups "
+               "not co-resident: another stream / process holds CUs?)" % what)
+        if self.xchg_strict:
+            raise RuntimeError(msg + "; GT_XCHG_STRICT=1")
+        import warnings
+        warnings.warn(msg + " -- the affected updates were skipped on the device; falling back to two workgroups per sequence "
+                      "(GT_SEQ_QUAD=0) for the rest of this process", RuntimeWarning)
+        self.lib.cdll.gt_set_seq_quad(0)
+        self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)      # (zeroes the region: stale granules, the word)
+        for t in self._slots.values():             # captured graphs hold QUAD launches; the launch count changes with the schedule
+            t.graphs.clear(); t.keep.clear(); t.use_graph = None
+            if t.ws is not ws and self._xchg_word(t) is not None:
+                self.lib.call("gt_workspace_init", ctypes.byref(t.cfg), _ptr(t.ws), self.stream)
+        if not self.on_host:
+            self.grads[self.total - 1:].zero_()
+
+    def poll_exchange(self, s):
+        """Step path, no synchronisation: every XCHG_POLL_EVERY-th call looks at the PREVIOUS asynchronous copy of the error word (complete
+        by now, or left for the next poll) and starts the next one."""
+        s.xchg_count += 1
+        if s.xchg_count % XCHG_POLL_EVERY or self.on_host:
+            return
+        w = self._xchg_word(s)
+        if w is None:
+            return
+        if s.xchg_host is None:
+            s.xchg_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            s.xchg_event = torch.cuda.Event()
+        elif s.xchg_event.query():
+            if int(s.xchg_host[0]) != 0:
+                s.xchg_host.zero_()
+                self._recover_exchange(s.ws, s.cfg, "a train step")
+                return
+        else:
+            return                                  # (the last copy is still in flight: look again next time)
+        s.xchg_host.copy_(w, non_blocking=True)
+        s.xchg_event.record(torch.cuda.current_stream(self.device))
+
+    def check_exchange(self, s, what="a train step"):
+        """Synchronising read of slot s's error word (call where the host waits for the device anyway).  -> True when a time-out was found
+        (and recovered from: the numbers of the launches since the last check are garbage, their updates were skipped)."""
+        w = self._xchg_word(s)
+        if w is None or int(w.item()) == 0:
+            return False
+        self._recover_exchange(s.ws, s.cfg, what)
+        return True
 
     def mean_stats(self, s):
-        self.check_exchange(s)
         """The slot's 8-float stats averaged over the data-parallel ranks (one tiny all-reduce; every rank must call it).
-        Single process: the stats tensor itself."""
+        Single process: the stats tensor itself.  Also the synchronising check of the pair exchange: stats of a step whose exchange timed
+        out come back as NaN (data-parallel: on every rank -- the flag travels with the stats all-reduce, so all ranks fall back together)."""
         if self.world_size == 1 or not self.reduce_stats:
+            if self.check_exchange(s):
+                return torch.full_like(s.stats, float("nan"))
             return s.stats
         import torch.distributed as dist
-        t = s.stats.clone()
+        w = self._xchg_word(s)
+        flag = torch.zeros(1, dtype=torch.float32, device=s.stats.device) if w is None else (w != 0).to(torch.float32)
+        t = torch.cat([s.stats, flag])
         dist.all_reduce(t)
-        return t / self.world_size
+        if float(t[8]) != 0.0:
+            if w is not None:                      # (ranks whose own word is clean fall back too: one schedule everywhere)
+                self._recover_exchange(s.ws, s.cfg, "a train step (some rank)")
+            return torch.full_like(s.stats, float("nan"))
+        return t[:8] / self.world_size
 
     def profile(self, steps):
         """Eager (no graph) pass of `steps` train steps with HIP events around every launch.
