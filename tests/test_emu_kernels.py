@@ -147,6 +147,22 @@ def test_tile64_ring_kernel():
         assert any(want in ln for ln in tr), (want, tr[:5])
 
 
+def test_layernorm_fused_into_the_64_tile_linears():
+    """gt_gemm64.h, EPI_RES_LN / EPI_RES_LNBWD: the N / 64 workgroups of a row block exchange their row partials inside the launch
+    (opt-in, gt_set_ln_exchange(1)): forward (Chan-merged mean / M2) and backward (row sums, dgamma / dbeta partials) against the oracle, NT
+    and NN, fp32 and bf16 fragments, N = 256 and 512; the emulator re-runs workgroups that find a partner's ready word missing."""
+    from harness import emu_lib
+    lib = emu_lib()
+    lib.cdll.gt_set_ln_exchange(1)
+    try:
+        parity.check_step("emu", cfg_dict(256, 4, 128, 2), 2, 0.2)
+        parity.check_step_bf16("emu", cfg_dict(256, 4, 128, 1), 2, 0.2)
+        parity.check_train_step("emu", cfg_dict(256, 2, 128, 1), 2, 0.1, seq=False)
+        parity.check_step("emu", cfg_dict(512, 8, 128, 1), 2, 0.1)
+    finally:
+        lib.cdll.gt_set_ln_exchange(-1)
+
+
 def test_gather_and_voice_metrics_kernels():
     """gt_gather_batch / gt_voice_metrics under the emulator against numpy."""
     import ctypes

@@ -389,7 +389,7 @@ def test_quad_pair_exchange_fails_safe_under_contention_and_on_timeout():
         # ... the step path notices by itself (asynchronous 4-byte copy every XCHG_POLL_EVERY steps, looked at one poll later) ...
         with warnings.catch_warnings(record=True) as rec:
             warnings.simplefilter("always")
-            for _ in range(3 * E.XCHG_POLL_EVERY):
+            for _ in range(40 * E.XCHG_POLL_EVERY):     # (the host runs a hundred steps ahead of the device: the copy it looks at is an old one)
                 eng.train_step()
                 if eng.exchange_timeouts:
                     break
@@ -404,17 +404,17 @@ def test_quad_pair_exchange_fails_safe_under_contention_and_on_timeout():
         torch.cuda.synchronize()
         assert not eng.check_exchange(eng.slot(B))
         assert (eng.params - ref.params).abs().max() < 2e-6 * ref.params.abs().max()
-        # evaluation forward and predict through a raised word: noticed at once, repeated on the fallback schedule
+        # predict through a raised word (its own workspace): noticed when the call ends, repeated on the fallback schedule
         lib.cdll.gt_set_seq_quad(-1)
         e2 = make()
         want = e2.predict(torch.from_numpy(x)).clone()
-        s2 = e2.slot(B)
-        lib.cdll.gt_set_xchg_spin_max(1)
+        cfg2, ws2, _ = e2._predict_ws[B]
+        e2._xchg_word(ws2, cfg2).fill_(1)
         with warnings.catch_warnings(record=True):
             warnings.simplefilter("always")
             got = e2.predict(torch.from_numpy(x))
-        lib.cdll.gt_set_xchg_spin_max(0)
-        assert e2.exchange_timeouts >= 1 and torch.equal(got[..., :9], want[..., :9]) and (got - want).abs().max() < 1e-5
+        assert e2.exchange_timeouts == 1 and int(e2._xchg_word(ws2, cfg2).item()) == 0
+        assert torch.equal(got[..., :9], want[..., :9]) and (got - want).abs().max() < 1e-5
     finally:
         lib.cdll.gt_set_xchg_spin_max(0)
         lib.cdll.gt_set_seq_quad(-1)

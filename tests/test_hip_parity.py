@@ -182,6 +182,49 @@ def test_bf16_shadows_of_the_gemm_operands():
         lib.cdll.gt_set_operand_shadows(-1)
 
 
+def test_layernorm_row_exchange_of_the_64_tile_linears():
+    """opt-in (gt_set_ln_exchange(1)): LayerNorm forward / backward inside the producing Linear / dgrad at 2048 tokens, the 8 workgroups of a
+    row block meeting through the in-launch row exchange (csrc/gt_gemm64.h) -- oracle parity at a GPU's share of configs[3] / [4], a train
+    step, and the time-out path: a polling bound of one raises the error word and the update applies nothing."""
+    import ctypes
+    import torch
+    from transformergrooveinfilling_amd import _lib
+    from transformergrooveinfilling_amd.engine import StepEngine
+    import warnings
+    lib = _lib.get_lib()
+    lib.cdll.gt_set_ln_exchange(1)
+    try:
+        parity.check_step("hip", cfg_dict(512, 8, 512, 1), 64, 0.15)
+        parity.check_step("hip", cfg_dict(256, 2, 512, 2), 64, 0.3)
+        parity.check_step_bf16("hip", cfg_dict(512, 8, 512, 1, embedding_size_src=27), 64, 0.24)
+        parity.check_train_step("hip", cfg_dict(512, 8, 512, 1), 64, 0.1)
+        dims = dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=2, num_decoder_layers=0, dropout=0.1, embedding_size_src=16)
+        eng = StepEngine(batch_size=64, optimizer="adam", learning_rate=0.01, hit_loss_penalty=0.5, seed=3, use_graph=False, **dims)   # (a captured graph would keep the polling bound it was recorded with)
+        from oracle import numpy_groove as ng
+        eng.load_named(ng.init_params(dims, seed=1))
+        x, y = ng.synthetic_batch(64, 16, seed=4)
+        eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))
+        eng.train_step(); eng.train_step()
+        torch.cuda.synchronize()
+        assert not eng.check_exchange(eng.slot(64))
+        before, m0 = eng.params.clone(), eng.m.clone()
+        lib.cdll.gt_set_xchg_spin_max(1)
+        eng.train_step()
+        torch.cuda.synchronize()
+        lib.cdll.gt_set_xchg_spin_max(0)
+        assert torch.equal(eng.params, before) and torch.equal(eng.m, m0) and float(eng.grads.abs().max()) == 0.0
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            assert eng.check_exchange(eng.slot(64))             # noticed, region zeroed, the norm a row pass of its own again
+        eng.train_step()
+        torch.cuda.synchronize()
+        assert not torch.equal(eng.params, before) and not eng.check_exchange(eng.slot(64))
+    finally:
+        lib.cdll.gt_set_xchg_spin_max(0)
+        lib.cdll.gt_set_ln_exchange(-1)
+        lib.cdll.gt_set_seq_quad(-1)
+
+
 def test_train_step_bf16_operands():
     parity.check_train_step_bf16("hip", ENC, 4, 0.2)
     parity.check_train_step_bf16("hip", cfg_dict(128, 4, 512, 2), 8, 0.24)

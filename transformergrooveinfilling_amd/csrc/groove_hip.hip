@@ -99,7 +99,7 @@ static int check_cfg(const gt_config* c) {
   if (c->n_enc_layers <= 0 || c->n_enc_layers > 64 || c->n_dec_layers < 0 || c->n_dec_layers > 64)
     return gt_fail("layer counts out of range (enc %d, dec %d)", c->n_enc_layers, c->n_dec_layers);
   if (!(c->dropout >= 0.f && c->dropout < 1.f)) return gt_fail("dropout %f outside [0,1)", (double)c->dropout);
-  if (c->precision != 0 && c->precision != 1) return gt_fail("precision %d unknown (0 = fp32, 1 = bf16 GEMM operands)", c->precision);
+  if (c->precision < 0 || c->precision > 2) return gt_fail("precision %d unknown (0 = fp32, 1 = bf16 GEMM operands, 2 = ... and bf16 storage of the Linear outputs)", c->precision);
   if ((int64_t)c->batch * 32 * (c->dim_ff > 3 * c->d_model ? c->dim_ff : 3 * c->d_model) >= (1ll << 31))
     return gt_fail("batch %d too large for 32-bit element indices", c->batch);
   // every LayerNorm instance gets one row of the dgamma/dbeta partials table (LnJobs): refuse here, before any launch,
@@ -187,6 +187,7 @@ struct WLayout {
   int64_t pack_f = -1, pack_b = -1, pack_stride = 0;   // fragment-ordered weight copies of the sequence-resident kernels (gt_seq.h)
   int64_t seq_dctx = -1;                               // hand-over buffer of their two-workgroups-per-sequence (SPLIT) backward phases
   int64_t seq_xchg = -1, seq_xchg_n = 0;               // pair-exchange region of their four-workgroups-per-sequence (QUAD) forward
+  int64_t rowx = -1, rowx_n = 0;                       // row exchange of the LayerNorm-fused 64x64-tile Linears (gt_gemm64.h; d_model 256 / 512)
   int64_t seq_amask = -1, seq_amask_stride = 0;        // dropout keep bits of P, one word per (layer, sequence, head, query): their head_dim-2 attention
   // bf16 shadows (precision = 1, bf16_shadows()): fp32 tensor offset -> offset (in floats) of its bf16 copy, for the activations whose
   // producers write one; w16 / w16t: the encoder layers' four matrices and their transposes, [in_w | out_w | w1 | w2] per layer
@@ -232,7 +233,7 @@ static int bf16_shadow_level() {
 static bool bf16_shadows(const gt_config& c);
 static bool bf16_wt(const gt_config& c) {
   static const int on = [] { const char* e = getenv("GT_BF16_WT"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on && c.precision == 1 && c.n_enc_layers > 0 && c.d_model % 32 == 0 && c.dim_ff % 32 == 0 && !bf16_shadows(c);
+  return on && c.precision >= 1 && c.n_enc_layers > 0 && c.d_model % 32 == 0 && c.dim_ff % 32 == 0 && !bf16_shadows(c);
 }
 static bool bf16_shadows(const gt_config& c) {
   const int on = bf16_shadow_level() > 0;
@@ -240,8 +241,22 @@ static bool bf16_shadows(const gt_config& c) {
   const int hd = c.n_heads > 0 ? c.d_model / c.n_heads : 0;
   static const int attn_mfma = [] { const char* e = getenv("GT_ATTN_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();      // (ctx / dqkv shadows)
   const int nmin = c.d_model < c.dim_ff ? c.d_model : c.dim_ff;            // every Linear of a layer on the big-tile kernel (its epilogue writes hact16 / dhid16)
-  return on && attn_mfma && wgrad_deferred(c) && c.precision == 1 && c.n_enc_layers > 0 && (c.d_model == 256 || c.d_model == 512) && c.dim_ff % 128 == 0 &&
+  return on && attn_mfma && wgrad_deferred(c) && c.precision >= 1 && c.n_enc_layers > 0 && (c.d_model == 256 || c.d_model == 512) && c.dim_ff % 128 == 0 &&
          M % 128 == 0 && (hd == 16 || hd == 32 || hd == 64 || hd == 128) && (M / 128) * (nmin / 128) >= GT_T128H_MIN;
+}
+// precision = 2 (round 5): bf16 where the bytes are.  On top of precision 1's operand-only tensors (level 2 of the shadows: ctx, hact, dhid,
+// dqkv, masked dz copies) every Linear OUTPUT of the encoder layers that torch.autocast(bfloat16) would hand on as bf16 is stored in bf16
+// alone: qkv (read by the attention kernels: fp32 arithmetic on bf16-stored q / k / v), the out-proj / linear2 outputs ahead of their
+// LayerNorm, the dgrad outputs ahead of a LayerNorm backward, and dctx (out-proj dgrad -> attention backward).  The residual stream, the
+// LayerNorm statistics / xhat, softmax, loss, master weights and optimizer stay fp32.  Applies where the level-2 shadows apply and the
+// heads are 64 or 128 wide (the LDS-staged attention kernels); elsewhere precision 2 runs as precision 1 (gt_precision_in_force).
+static bool p2(const gt_config& c) {
+  const int hd = c.n_heads > 0 ? c.d_model / c.n_heads : 0;
+  return c.precision == 2 && bf16_shadows(c) && bf16_shadow_level() >= 2 && (hd == 64 || hd == 128);
+}
+extern "C" int gt_precision_in_force(const gt_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  return p2(*cfg) ? 2 : (cfg->precision ? 1 : 0);
 }
 #ifndef GT_WS_SKEW
 #define GT_WS_SKEW 0
@@ -299,6 +314,7 @@ static WLayout ws_layout(const gt_config& c) {
     if (d == 128) { W.seq_xchg_n = 2 * gt_seq_xchg_floats(c.batch); W.seq_xchg = add(W.seq_xchg_n); }    // (two regions: the forward's, and backward phase 0's when fused behind it)
     if (d == 32 && c.n_heads == 16) { W.seq_amask_stride = BH * 32; W.seq_amask = add(W.seq_amask_stride * c.n_enc_layers); }   // (behind everything else: no other offset moves)
   }
+  if (!seq_supported(c) && (d == 256 || d == 512) && M % 64 == 0) { W.rowx_n = gt_rowx_floats(M, (int)d); W.rowx = add(W.rowx_n); }
   if (bf16_shadows(c)) {
     auto sh = [&](int64_t off, int64_t n) { W.sh.emplace_back(off, add((n + 1) / 2)); };
     const bool only = bf16_shadow_level() >= 2;
@@ -342,6 +358,7 @@ extern "C" int gt_workspace_init(const gt_config* cfg, float* ws, gt_stream_t st
   if (!ws) return gt_fail("gt_workspace_init: ws must not be NULL");
   const WLayout W = ws_layout(*cfg);
   if (W.seq_xchg >= 0) (void)hipMemsetAsync(ws + W.seq_xchg, 0, (size_t)W.seq_xchg_n * sizeof(float), (hipStream_t)stream);
+  if (W.rowx >= 0) (void)hipMemsetAsync(ws + W.rowx, 0, (size_t)W.rowx_n * sizeof(float), (hipStream_t)stream);      // (tag 0 never matches: serials start at 1)
   return launch_status("gt_workspace_init");
 }
 // 0: no bf16 operand shadows for this configuration; 1: beside the fp32 tensors; 2: ctx / hact / dhid / dqkv / masked dz copies of the
@@ -373,6 +390,8 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   else if (n == "dec_final") set(W.dec_final, M * d); else if (n == "dlogits") set(W.dlogits, M * GT_TGT);
   else if (n == "dmem") set(W.dmem, M * d); else if (n == "dctx") set(W.dctx, M * d);
   else if (n == "seq_xchg") set(W.seq_xchg, W.seq_xchg_n);
+  else if (n == "rowx") set(W.rowx, W.rowx_n);
+  else if (n == "xchg_err") { if (W.seq_xchg >= 0) set(W.seq_xchg, 1); else if (W.rowx >= 0) set(W.rowx, 1); }      // the error word of whichever in-launch exchange this shape has
   else if (n == "amask" && W.seq_amask >= 0) set(W.seq_amask, W.seq_amask_stride * c.n_enc_layers);
   else if (n == "pack_f" && W.pack_f >= 0) set(W.pack_f, W.pack_stride * c.n_enc_layers);
   else if (n == "pack_b" && W.pack_b >= 0) set(W.pack_b, W.pack_stride * c.n_enc_layers);
@@ -617,6 +636,34 @@ static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, 
 #ifndef GT_ROW_FUSE_BIG_MAX_D
 #define GT_ROW_FUSE_BIG_MAX_D 256
 #endif
+// LayerNorm inside the producing Linear / dgrad on 64x64 tiles with the in-launch row exchange (gt_gemm64.h).  OPT-IN (GT_LN_XCHG=1 /
+// gt_set_ln_exchange(1); -1 = the environment, default off): parity-green, 22 launches fewer per step at d_model 512 -- and not faster.
+// Measured at 2048 tokens (round 5, A/B on one box): C4 bs 64 1.494 ms fused vs 1.494 separate, C5 bf16 bs 64 0.984 vs 0.968: the hand-off
+// (data, drain, ready word, poll, fetch: every hop an agent-scope round trip of ~1-2 us, plus the start skew of the 8 workgroups of a row
+// block) costs what the row pass of its own costs (5.3 us per Linear + LayerNorm launch at fp32, 8 us at bf16 against 5.8-6.2 us).  A
+// first version that polled tagged granules (16 scattered 8-byte loads per lane and round) cost 13 us per launch: 1.811 ms.
+static int g_ln_xchg = -1;
+extern "C" int gt_set_ln_exchange(int on) { g_ln_xchg = on < 0 ? -1 : on != 0; return 0; }
+static int seq_cu_count();
+static int g_xchg_spin_max = 0;
+static bool ln_xchg(const Ctx& x) {
+  if (g_ln_xchg < 0) { const char* e = getenv("GT_LN_XCHG"); g_ln_xchg = (e && e[0] == '1') ? 1 : 0; }
+  return g_ln_xchg != 0 && x.W.rowx >= 0;
+}
+static void ln_xchg_args(const Ctx& x, GemmArgs& g) {
+  g.rowx = reinterpret_cast<unsigned*>(x.ws + x.W.rowx);
+  g.spin_max = g_xchg_spin_max > 0 ? g_xchg_spin_max : GT_XCHG_SPIN_MAX;
+}
+// the fused launch on whichever 64x64 kernel the operands allow (both bf16 shadows -> gemm64h; a bf16-ONLY input needs that one); false: not taken
+template <bool BKM, int EPI>
+static bool ln_xchg_launch(const Ctx& x, const GemmArgs& g, bool in_only16) {
+  if (!gemm64_ln_shape(g, seq_cu_count())) return false;
+  if (g.bf16 && g.A16 && g.B16 && gemm64h_ok(g, EPI)) { gemm64h_launch<false, EPI>(g, x.s); return true; }
+  if (in_only16 || (g.bf16 && g.A16 && g.B16)) return false;
+  if (!gemm64_ok(g, EPI)) return false;
+  gemm64_launch<BKM, EPI>(g, x.s);
+  return true;
+}
 static bool row_fused(const Ctx& x) {
   return !x.c.precision && (x.d <= GT_ROW_FUSE_MAX_D || (x.M >= GT_ROW_FUSE_MIN_M && x.d <= GT_ROW_FUSE_BIG_MAX_D));
 }
@@ -625,6 +672,27 @@ static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float*
 static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, int K, const float* res, const float* xhat,
                        const float* rstd, int64_t gamma_off, float* dz, float* dzm, int site) {
   if (!row_fused(x)) {
+    if (ln_xchg(x) && x.ln && x.ln->n < GT_LN_JOBS_MAX) {
+      // ONE launch: the dgrad on 64x64 tiles, the LayerNorm backward in its epilogue (row sums through the in-launch exchange)
+      const float* wt = wT_of(x, W);                            // (precision 1 without shadows: the NT form over the fp32 transpose)
+      GemmArgs g = wt ? mk_gemm(dY, ldy, wt, K, dz, x.d, x.M, x.d, K) : mk_gemm(dY, ldy, W, x.d, dz, x.d, x.M, x.d, K);
+      if (!wt && ldy == K) { g.A16 = sh_act(x, dY); g.B16 = sh_w(x, W, true); g.lda16 = g.ldb16 = K; }
+      g.as_dgrad = 1;
+      g.res = res; g.ldres = x.d; g.xhat = xhat; g.rstd = rstd; g.gamma = x.prm + gamma_off;
+      g.C2 = (x.drop && !only16(x, dzm)) ? dzm : nullptr;
+      g.C16 = sh_act(x, x.drop ? dzm : dz); g.ldc16 = x.d;
+      g.drop = mk_drop(x, site);
+      float dummy; g.ln_part = &dummy;                          // (eligibility first: a registered job cannot be taken back)
+      ln_xchg_args(x, g);
+      const bool h16 = g.bf16 && g.A16 && g.B16 && gemm64h_ok(g, EPI_RES_LNBWD);
+      const bool f32 = !only16(x, dY) && !(g.bf16 && g.A16 && g.B16) && gemm64_ok(g, EPI_RES_LNBWD);
+      if (gemm64_ln_shape(g, seq_cu_count()) && (h16 || f32)) {
+        g.ln_part = ln_job(x, gamma_off, x.M / 64);
+        if (wt) { if (ln_xchg_launch<false, EPI_RES_LNBWD>(x, g, only16(x, dY))) return 0; }
+        else if (ln_xchg_launch<true, EPI_RES_LNBWD>(x, g, only16(x, dY))) return 0;
+        return gt_fail("dgrad + LayerNorm backward: the fused launch was refused after its job was registered");
+      }
+    }
     dgrad_store(x, dY, ldy, W, x.d, dz, x.d, K, 0);
     ln_bwd(x, dz, res, xhat, rstd, gamma_off, dz, dzm, site);
     return 0;
@@ -691,6 +759,15 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
   if (!row_fused(x)) {
     g.A16 = sh_act(x, in); g.B16 = sh_w(x, x.prm + w_off, false); g.lda16 = g.ldb16 = K;
     if (only16(x, in)) need16(g.A16 && g.B16 && gemm32h_ok(g, EPI_STORE), "Linear (+ LayerNorm) of a bf16-only tensor");
+    if (!second && ln_xchg(x)) {
+      // ONE launch: the Linear on 64x64 tiles, dropout + residual + LayerNorm in its epilogue (row statistics through the in-launch exchange)
+      GemmArgs f = g;
+      f.res = res; f.ldres = x.d; f.gamma = x.prm + gamma_off; f.beta = x.prm + gamma_off + bo;
+      f.aux = xhat; f.aux2 = rstd; f.drop = mk_drop(x, site);
+      f.C16 = sh_act(x, out); f.ldc16 = x.d;
+      ln_xchg_args(x, f);
+      if (ln_xchg_launch<false, EPI_RES_LN>(x, f, only16(x, in))) return 0;
+    }
     gemm_launch<false, false, EPI_STORE>(g, x.s);
     if (second) {
       gt_prof_tag("ln_fwd", 0, 24.0 * x.M * x.d);
@@ -797,7 +874,7 @@ static int make_ctx(Ctx& x, const gt_config* cfg, const float* params, float* gr
                     int train, gt_stream_t stream) {
   if (check_cfg(cfg)) return -1;
   if (!params || !ws) return gt_fail("params / ws must not be NULL");
-  g_bf16 = cfg->precision;
+  g_bf16 = cfg->precision ? 1 : 0;
   x.c = *cfg;
   x.P = param_layout(*cfg);
   x.W = ws_layout(*cfg);
@@ -914,7 +991,6 @@ static bool seq_quad(const gt_config& c) {
 }
 // bound of the pair exchange's polling loop (0 / negative: the compiled default).  A test lowers it to see the time-out path -- error
 // word, skipped update, host recovery -- without waiting seconds.
-static int g_xchg_spin_max = 0;
 extern "C" int gt_set_xchg_spin_max(int polls) { g_xchg_spin_max = polls; return 0; }
 static bool seq_supported(const gt_config& c) {
   const int hd = c.d_model / c.n_heads;
@@ -1548,17 +1624,17 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
 // ------------------------------------------------------------------------------------ optimizer
 // step_advanced: the caller's previous launch already advanced step / opt_step (fused train step, see LnJobs::bump)
 static int optimizer_step_impl(int algo, float* params, float* grads, float* m, float* v, int64_t n, gt_step_state* state,
-                               int zero_grads, gt_stream_t stream, int step_advanced) {
+                               int zero_grads, gt_stream_t stream, int step_advanced, const unsigned* err = nullptr) {
   if (!params || !grads || !state || n <= 0) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 1023) / 1024);
   if (algo == 0) {
     gt_prof_tag("optimizer", 0, 12.0 * n);
-    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, (const gt_step_state*)state, zero_grads);
+    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, (const gt_step_state*)state, zero_grads, err);
   } else if (algo == 1) {
     if (!m || !v) return gt_fail("gt_optimizer_step: adam needs m and v");
     gt_prof_tag("optimizer", 0, 28.0 * n);
-    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state, zero_grads, step_advanced);
+    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state, zero_grads, step_advanced, err);
   } else {
     return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
   }
@@ -1577,7 +1653,11 @@ extern "C" int gt_optimizer_step_ws(const gt_config* cfg, int algo, float* param
                                     gt_step_state* state, int zero_grads, gt_stream_t stream) {
   if (check_cfg(cfg)) return -1;
   PLayout P = param_layout(*cfg);
-  if (!use_seq(*cfg) || !zero_grads || !ws) return optimizer_step_impl(algo, params, grads, m, v, P.total, state, zero_grads, stream, 0);
+  if (!use_seq(*cfg) || !zero_grads || !ws) {
+    const WLayout W0 = ws ? ws_layout(*cfg) : WLayout();
+    const unsigned* err = (ws && W0.rowx >= 0) ? reinterpret_cast<const unsigned*>(ws + W0.rowx) : nullptr;      // (the row exchange's error word)
+    return optimizer_step_impl(algo, params, grads, m, v, P.total, state, zero_grads, stream, 0, err);
+  }
   if (!params || !grads || !state) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
   if (algo != 0 && algo != 1) return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
   if (algo == 1 && (!m || !v)) return gt_fail("gt_optimizer_step: adam needs m and v");
@@ -1647,7 +1727,8 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
       gt_seq_launch_update_pack(a, algo, params, grads, m, v, P.total, state, 1, (hipStream_t)stream);
       return launch_status("gt_train_step");
     }
-    if (optimizer_step_impl(algo, params, grads, m, v, P.total, state, 1, stream, 1)) return -1;
+    if (optimizer_step_impl(algo, params, grads, m, v, P.total, state, 1, stream, 1,
+                            W.rowx >= 0 ? reinterpret_cast<const unsigned*>(ws + W.rowx) : nullptr)) return -1;
   }
   return 0;
 }

@@ -74,6 +74,9 @@ struct GemmArgs {
   uint16_t* C16; int ldc16;
   const uint16_t* res16;     // EPI_MASK_NZ: the mask source as bf16 (row stride ldres), when its fp32 tensor is not stored
   int as_dgrad;              // profiling label only: an NT product that IS a dgrad (B = a transposed weight copy)
+  // gt_gemm64.h, LayerNorm-fused epilogues on 64x64 tiles: the row exchange region of the workspace (header: error word, launch serial,
+  // ticket; then [M][N / 32 parts][2] tagged 8-byte granules) and the bound of its polling loop
+  unsigned* rowx; int spin_max;
 };
 
 template <int ROWS, int COLS, int NT>

@@ -18,6 +18,12 @@
 #pragma once
 // (included at the end of gt_gemm.h, after gt_gemm32.h)
 
+#ifndef GT_G64_DEEP
+#define GT_G64_DEEP 0           /* fp32 MFMA loop: 1 = a three-deep register ring (slab t + 4 requested in the second half of slab t), 0 = the
+                                   two-deep ring of gt_gemm32.h.  Measured (round 5, gemm_bench, M 2048): three-deep 13.6 / 32.5 / 34.6 us against
+                                   12.8 / 31.2 / 33.4 us (N 512 K 512 / N 512 K 1536 / N 1536 K 512): bytes in flight are not what holds the loop at
+                                   1.15 us per 64-wide slab (MFMA issue 0.85 us at 2.4 GHz -- ~0.97 us at the ~2.1 GHz the chip holds under this load) */
+#endif
 struct Gemm64Cfg {
   static constexpr int BM = 64, BN = 64, BK = 64, NT = 256;
   static constexpr int STR = 64 + 4, SZ = 64 * STR;           // floats: [64 rows][BK + 4] or [BK k][64 + 4]
@@ -33,6 +39,11 @@ static inline bool gemm64_ok(const GemmArgs& g, int epi) {
   if ((epi == EPI_MASK_NZ || epi == EPI_ADD_RELUMASK_DROP) && ((g.ldres & 3) || !al16(g.res) || (g.res16 && (reinterpret_cast<uintptr_t>(g.res16) & 7)))) return false;
   if (epi == EPI_ADD_RELUMASK_DROP && ((g.N & 3) || !al16(g.aux_in))) return false;
   if (g.C16 && ((g.ldc16 & 3) || (reinterpret_cast<uintptr_t>(g.C16) & 7))) return false;
+  if (epi == EPI_RES_LN || epi == EPI_RES_LNBWD) {
+    if (!g.rowx || !g.gamma || !al16(g.gamma) || (g.res && ((g.ldres & 3) || !al16(g.res))) || !g.C) return false;
+    if (epi == EPI_RES_LN && (!g.beta || !al16(g.beta) || !g.aux || !al16(g.aux) || !g.aux2 || (g.bias && !al16(g.bias)))) return false;
+    if (epi == EPI_RES_LNBWD && (!g.xhat || !al16(g.xhat) || !g.rstd || !g.ln_part || (g.C2 && !al16(g.C2)))) return false;
+  }
   return true;
 }
 
@@ -48,6 +59,254 @@ __device__ __forceinline__ int gemm64_bid() {
 #define G64_X(mask) GT_SGB(mask, 1)
 #define G64_R(n) GT_SGB(0x100, n)
 
+// ================================================================================================================ LayerNorm epilogues
+// EPI_RES_LN / EPI_RES_LNBWD on 64x64 tiles (round 5).  A LayerNorm needs sums over the WHOLE row (N = d_model columns = N / 64 column
+// tiles of a row block), and at 2048 tokens a row-owning tile makes every workgroup stream the whole weight matrix (23 TF measured) --
+// so until round 5 the norm was a launch of its own behind the Linear / dgrad: 24 launches of 5.8-7.3 us at d_model 512 (9.5 % of the
+// step).  Here the N / 64 workgroups of a row block exchange their ROW PARTIALS inside the launch and each normalises its own tile:
+//   * every wave owns 32 rows x 32 columns ("part" p = column / 32): per row two partial values -- forward (mean, M2) of its 32 columns
+//     (two passes over the registers; parts merged by Chan's formula in a fixed order: every workgroup arrives at bit-identical
+//     statistics); backward (sum g, sum g xhat), g = dy gamma;
+//   * hand-off = "data, drain, flag" (MI355X_MICROARCH.md, valid hand-off forms): the wave writes its 64 values as agent-scope
+//     (write-through) stores -- 256 contiguous bytes: layout [row block][part][row half][value][32 rows] --, waits for them
+//     (s_waitcnt vmcnt(0)), then ONE lane stores the part's READY word = this launch's sequence number.  A consumer polls the row block's
+//     N / 32 ready words (one 64- or 128-byte request per wave and round -- a first version that polled tagged 8-byte granules, 16 scattered
+//     loads per lane and round, cost 13 us per launch in L2 requests alone) and then reads the values once, coalesced;
+//   * sequence number: every part's ready word advances by exactly one per launch, so a wave reads its OWN word at its start and adds one
+//     -- no global counter, nothing is ever zeroed, a stale word can never match (the host emulator re-runs workgroups: there the
+//     launch serial of the emulator);
+//   * the workgroups of a row block must be resident together: the host takes this path only when the whole grid fits the chip at once
+//     (gemm64_ln_shape), they are 8 consecutive tiles of one XCD, and the polling loop is bounded -- a time-out raises the header's error
+//     word and the update kernels then apply nothing (groove_hip.h, gt_set_xchg_spin_max).
+// The arithmetic per element is that of ln_fwd_kernel / ln_bwd_v4_kernel (gt_misc.h).
+// (The host emulator runs a workgroup's lanes as fibers, one after the other, and re-runs a workgroup whose poll fails from its start: every
+//  lane must have published before the first one polls, and the decision to re-run must be the whole workgroup's.)
+#ifdef GT_EMU
+#define G64_EMU_PUBLISHED() __syncthreads()
+static bool g64_emu_fail_ = false;
+#define G64_EMU_AGREE(ok) { __syncthreads(); g64_emu_fail_ = false; __syncthreads(); if (!(ok)) g64_emu_fail_ = true; __syncthreads(); if (g64_emu_fail_) emu::block_retry(); }
+#else
+#define G64_EMU_PUBLISHED()
+#define G64_EMU_AGREE(ok) (void)(ok);
+#endif
+#define GT_ROWX_HDR 64                                   /* floats: [0] error word */
+// region: header | ready words [M / 64 row blocks][2 row halves][N / 32 parts] | values [M / 64][N / 32][2 row halves][2][32]
+static inline int64_t gt_rowx_floats(int64_t M, int N) { return GT_ROWX_HDR + (M / 64) * 2 * (N / 32) + (M / 64) * (int64_t)(N / 32) * 128; }
+__device__ __forceinline__ uint32_t g64_ld_u32(const unsigned* p) {
+#ifdef GT_EMU
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// this launch's sequence number for the wave that owns ready word `mine`
+__device__ __forceinline__ uint32_t g64_seq(const unsigned* mine) {
+#ifdef GT_EMU
+  (void)mine;
+  return emu::launch_serial;
+#else
+  return g64_ld_u32(mine) + 1u;
+#endif
+}
+// publish: the wave's 64 values (lane (r32, h): value h of row r32) -> vals[h][r32], then the ready word
+__device__ __forceinline__ void g64_publish(float* vals, unsigned* ready, const float v, const int r32, const int h, const uint32_t seq) {
+  gt_pub_store(vals + h * 32 + r32, v);
+#ifdef GT_EMU
+  emu::wave_rendezvous();
+  if ((threadIdx.x & 63) == 0) *ready = seq;
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every lane's store has been acknowledged (write-through) ...
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(ready, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag leaves
+#endif
+}
+// wait until all NP parts of the row block carry `seq`; false: gave up (error word raised) / emulator: a partner has not run yet
+template <int NP>
+__device__ __forceinline__ bool g64_wait(const unsigned* ready_rb, const uint32_t seq, unsigned* err, const int spin_max) {
+  const int lane = threadIdx.x & 63;
+#ifdef GT_EMU
+  return lane >= NP || ready_rb[lane] == seq;
+#else
+  int spins = 0;
+  for (;;) {
+    const bool ok = lane >= NP || g64_ld_u32(ready_rb + (lane < NP ? lane : 0)) == seq;
+    if (__all(ok)) return true;                                // (wave-uniform exit)
+    if (++spins > spin_max) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+#endif
+}
+// NPH = N / 64 column tiles per row block (4: d_model 256, 8: d_model 512).  acc: the wave's 32x32 block in the store epilogue's lane map
+// (lane (r32, h): ONE row, registers 4 q + j = column 8 q + 4 h + j of the block).  smem: the operand buffers, free behind the main loop.
+struct G64Rowx { unsigned* err; unsigned* ready_rb; float* vals_rb; };      // of one row block
+__device__ __forceinline__ G64Rowx g64_rowx(const GemmArgs& g, const int m0) {
+  const int NP = g.N / 32, nrb = g.M / 64, rb = m0 >> 6;
+  G64Rowx r;
+  r.err = g.rowx;
+  r.ready_rb = g.rowx + GT_ROWX_HDR + rb * 2 * NP;             // [row half][part]
+  r.vals_rb = reinterpret_cast<float*>(g.rowx + GT_ROWX_HDR + nrb * 2 * NP) + (size_t)rb * NP * 128;
+  return r;
+}
+template <int EPI, int NPH>
+__device__ __forceinline__ void gemm64_ln_epilogue(const GemmArgs& g, const f32x16& acc, const int m0, const int n0, const int wm, const int wn,
+                                                   const int r32, const int h, const uint32_t seq, float* smem) {
+  constexpr int N = 64 * NPH, NP = 2 * NPH, NG = NP;          // parts of 32 columns per row; values a lane reads (NP / 2 parts x 2)
+  const int row = m0 + wm * 32 + r32, cb = n0 + wn * 32 + 4 * h;       // this lane's row; its columns: cb + 8 q + j
+  const G64Rowx X = g64_rowx(g, m0);
+  const int part = (n0 >> 5) + wn;
+  float* const my_vals = X.vals_rb + (part * 2 + wm) * 64;
+  // the values this lane combines: parts [h NP / 2, (h + 1) NP / 2) of its row -- for a fixed (part, value) the 32 lanes of a half read 128
+  // contiguous bytes
+  auto fetch = [&](float (&pv)[NG]) {
+#pragma unroll
+    for (int i = 0; i < NG / 2; ++i) {
+      const float* src = X.vals_rb + ((h * (NP / 2) + i) * 2 + wm) * 64 + r32;
+      pv[2 * i] = gt_pub_load(src); pv[2 * i + 1] = gt_pub_load(src + 32);
+    }
+  };
+  const uint32_t dkey = gt_drop_key(g.drop);
+  const float invN = 1.0f / (float)N;
+  f32x4 ga[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ga[q] = *reinterpret_cast<const f32x4*>(g.gamma + cb + 8 * q);
+  if constexpr (EPI == EPI_RES_LN) {
+    // z = drop(acc + bias) + res;  y = LN(z) gamma + beta;  aux = xhat, aux2 = rstd, C16 = bf16(y)
+    f32x4 bi[4], re[4], be[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bi[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + cb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      re[q] = g.res ? *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + cb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      be[q] = *reinterpret_cast<const f32x4*>(g.beta + cb + 8 * q);
+    }
+    float z[16], s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = (acc[4 * q + j] + bi[q][j]) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + cb + 8 * q + j)) + re[q][j];
+        z[4 * q + j] = v; s += v;
+      }
+    s += __shfl_xor(s, 32);
+    const float mw = s * (1.0f / 32.0f);
+    float qq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const float d = z[e] - mw; qq += d * d; }
+    qq += __shfl_xor(qq, 32);
+    g64_publish(my_vals, X.ready_rb + wm * NP + part, h ? qq : mw, r32, h, seq);          // (lane half 0: the means, half 1: M2)
+    G64_EMU_PUBLISHED();
+    const bool gotf = g64_wait<NP>(X.ready_rb + wm * NP, seq, X.err, g.spin_max);
+    G64_EMU_AGREE(gotf)
+    float pv[NG];
+    fetch(pv);                                                  // (mean, M2) pairs of this half's parts
+    // Chan's merge over this half's parts, in order (32 columns each) ...
+    float mean = pv[0], m2 = pv[1], cnt = 32.f;
+#pragma unroll
+    for (int i = 1; i < NG / 2; ++i) {
+      const float d = pv[2 * i] - mean, n = cnt + 32.f;
+      mean += d * (32.f / n);
+      m2 += pv[2 * i + 1] + d * d * (cnt * 32.f / n);
+      cnt = n;
+    }
+    // ... then the two halves, lower columns first on both lanes: identical statistics in every lane and workgroup of the row
+    const float om = __shfl_xor(mean, 32), o2 = __shfl_xor(m2, 32);
+    const float ma = h ? om : mean, a2 = h ? o2 : m2, mb = h ? mean : om, b2 = h ? m2 : o2;
+    const float d = mb - ma;
+    mean = ma + d * 0.5f;
+    m2 = a2 + b2 + d * d * (cnt * 0.5f);
+    const float rstd = 1.0f / sqrtf(m2 * invN + GT_LN_EPS);
+    if (n0 == 0 && wn == 0 && h == 0) g.aux2[row] = rstd;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 xh, yv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xh[j] = (z[4 * q + j] - mean) * rstd; yv[j] = xh[j] * ga[q][j] + be[q][j]; }
+      *reinterpret_cast<f32x4*>(g.aux + (size_t)row * N + cb + 8 * q) = xh;
+      *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + cb + 8 * q) = yv;
+      if (g.C16 != nullptr) {
+        uint2 pk;
+        pk.x = (uint32_t)gt_f2bf(yv[0]) | ((uint32_t)gt_f2bf(yv[1]) << 16); pk.y = (uint32_t)gt_f2bf(yv[2]) | ((uint32_t)gt_f2bf(yv[3]) << 16);
+        *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + cb + 8 * q) = pk;
+      }
+    }
+  } else {
+    // d = acc (+ res);  dz = LNbwd(d) with (xhat, rstd, gamma);  C2 = dz dropmask;  C16 = bf16 of the masked copy (or of dz);
+    // ln_part[row block][2][N]: this tile's column sums of d xhat and d
+    f32x4 re[4], xh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      re[q] = g.res ? *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + cb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xh[q] = *reinterpret_cast<const f32x4*>(g.xhat + (size_t)row * N + cb + 8 * q);
+    }
+    const float rs = g.rstd[row];
+    float dd[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dv = acc[4 * q + j] + re[q][j], gd = dv * ga[q][j];
+        dd[4 * q + j] = dv; s1 += gd; s2 += gd * xh[q][j];
+      }
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    g64_publish(my_vals, X.ready_rb + wm * NP + part, h ? s2 : s1, r32, h, seq);
+    G64_EMU_PUBLISHED();
+    const bool gotb = g64_wait<NP>(X.ready_rb + wm * NP, seq, X.err, g.spin_max);
+    G64_EMU_AGREE(gotb)
+    float pv[NG];
+    fetch(pv);
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG / 2; ++i) { t1 += pv[2 * i]; t2 += pv[2 * i + 1]; }
+    const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+    const float m1 = (h ? o1 + t1 : t1 + o1) * invN, m2 = (h ? o2 + t2 : t2 + o2) * invN;       // (lower columns first on both lanes)
+    const bool masked = g.C2 != nullptr || (g.C16 != nullptr && g.drop.thr != 0u && g.drop.st != nullptr);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v, vm;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = rs * (dd[4 * q + j] * ga[q][j] - m1 - xh[q][j] * m2);
+        vm[j] = masked ? v[j] * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + cb + 8 * q + j)) : v[j];
+      }
+      *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + cb + 8 * q) = v;
+      if (g.C2 != nullptr) *reinterpret_cast<f32x4*>(g.C2 + (size_t)row * g.ldc + cb + 8 * q) = vm;
+      if (g.C16 != nullptr) {
+        uint2 pk;
+        pk.x = (uint32_t)gt_f2bf(vm[0]) | ((uint32_t)gt_f2bf(vm[1]) << 16); pk.y = (uint32_t)gt_f2bf(vm[2]) | ((uint32_t)gt_f2bf(vm[3]) << 16);
+        *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + cb + 8 * q) = pk;
+      }
+    }
+    // dgamma / dbeta partials of this 64 x 64 tile: (d xhat, d) through LDS [2][64 rows][64 + 1], 16-row runs summed per thread, then 4 runs
+    __syncthreads();                                             // (every wave is past its last operand read)
+    constexpr int TS = 65;
+    float* const sg = smem, * const sb = smem + 64 * TS;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rr = wm * 32 + r32, cc = wn * 32 + 4 * h + 8 * q + j;
+        sg[rr * TS + cc] = dd[4 * q + j] * xh[q][j];
+        sb[rr * TS + cc] = dd[4 * q + j];
+      }
+    __syncthreads();
+    const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
+    float ag = 0.f, ab = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ag += sg[(rg * 16 + r) * TS + c]; ab += sb[(rg * 16 + r) * TS + c]; }
+    float* const sp = smem + 2 * 64 * TS;                        // [4 runs][2][64]
+    sp[(rg * 2) * 64 + c] = ag; sp[(rg * 2 + 1) * 64 + c] = ab;
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6;
+      const float v = (sp[(0 * 2 + which) * 64 + c] + sp[(1 * 2 + which) * 64 + c]) + (sp[(2 * 2 + which) * 64 + c] + sp[(3 * 2 + which) * 64 + c]);
+      g.ln_part[((size_t)(m0 >> 6) * 2 + which) * N + n0 + c] = v;
+    }
+  }
+}
+// host side: the fused LayerNorm epilogues apply when the Linear itself can take the 64x64 kernels, N = d_model is 256 or 512 and the
+// WHOLE grid is resident at once (two workgroups per CU)
+static inline bool gemm64_ln_shape(const GemmArgs& g, int cus) {
+  return (g.N == 256 || g.N == 512) && g.M % 64 == 0 && (long)(g.M / 64) * (g.N / 64) <= 2l * cus;
+}
+
 template <bool BKM, int EPI, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void gemm64_kernel(GemmArgs g) {
   typedef Gemm64Cfg Cfg;
@@ -57,6 +316,8 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(GemmArgs g) {
   const int m0 = (bid / gx) * 64, n0 = (bid % gx) * 64, nk = g.K / BK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
+  uint32_t xtag = 0;            // LayerNorm epilogues: this launch's sequence number = the wave's OWN ready word + 1 (read before the wave publishes)
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) xtag = g64_seq(g64_rowx(g, m0).ready_rb + wm * (g.N / 32) + (n0 >> 5) + wn);
 
   f32x4 va[PER], vb[PER], wa[PER], wb[PER];
   const char* pa[PER];
@@ -87,9 +348,14 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(GemmArgs g) {
   const int offa = (wm * 32 + r32) * STR + 4 * h;
   const int offb = 2 * SZ + (BKM ? (4 * h) * STR + wn * 32 + r32 : (wn * 32 + r32) * STR + 4 * h);
 
+  // (GT_G64_DEEP: the third register set of the three-deep ring -- slab t + 1 waits in registers, t + 2 and t + 3 are in flight)
+  f32x4 ua[PER], ub[PER];
+  auto kof = [&](const int t) { return (t < nk ? t : nk - 1) * BK; };
   G64_LD(va, vb, 0)
   G64_LD(wa, wb, BK)
+  if constexpr (PREC == 0 && GT_G64_DEEP) { G64_LD(ua, ub, kof(2)) }
   G64_ST(va, vb, 0)
+  if constexpr (PREC == 0 && GT_G64_DEEP) { G64_LD(va, vb, kof(3)) }
   __syncthreads();
 
   if constexpr (PREC == 1) {
@@ -182,17 +448,51 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(GemmArgs g) {
     G64_GRPW3() G64_GRPW3() G64_GRPW2() GT_SCHED_FENCE()                                       \
     __syncthreads();                                                                           \
     G64_RD(fa0, fb0, (CUR) ^ 1, 0) G64_MM(fa1, fb1) G64_GRP0() GT_SCHED_FENCE()
-    for (int kt = 0; kt < nk; kt += 2) {
-      G64_SLAB(0, wa, wb, va, vb, kt)
-      G64_SLAB(1, va, vb, wa, wb, kt + 1)
+    // the same slab on the three-deep ring.  CUR: LDS buffer holding slab t; (NA, NB): registers holding slab t + 1 -- written to the other
+    // buffer behind groups 0-2, then reloaded with slab t + 4 behind groups 3-5
+#define G64_SLAB3(CUR, NA, NB, t)                                                              \
+    if ((t) < nk) {                                                                            \
+    G64_STA(NA, (CUR) ^ 1, 0) G64_STB(NB, (CUR) ^ 1, 0) G64_STA(NA, (CUR) ^ 1, 1)              \
+    G64_RD(fa1, fb1, CUR, 1) G64_MM(fa0, fb0)                                                  \
+    G64_STB(NB, (CUR) ^ 1, 1) G64_STA(NA, (CUR) ^ 1, 2) G64_STB(NB, (CUR) ^ 1, 2)              \
+    G64_RD(fa0, fb0, CUR, 2) G64_MM(fa1, fb1)                                                  \
+    G64_STA(NA, (CUR) ^ 1, 3) G64_STB(NB, (CUR) ^ 1, 3)                                        \
+    G64_RD(fa1, fb1, CUR, 3) G64_MM(fa0, fb0)                                                  \
+    G64_GRPW3() G64_GRPW3() G64_GRPW2() GT_SCHED_FENCE()                                       \
+    { const int k4_ = kof((t) + 4);                                                            \
+      G64_LD(NA, NB, k4_) }                                                                    \
+    G64_RD(fa0, fb0, CUR, 4) G64_MM(fa1, fb1)                                                  \
+    G64_RD(fa1, fb1, CUR, 5) G64_MM(fa0, fb0)                                                  \
+    G64_RD(fa0, fb0, CUR, 6) G64_MM(fa1, fb1)                                                  \
+    G64_RD(fa1, fb1, CUR, 7) G64_MM(fa0, fb0)                                                  \
+    G64_GRP3(0x20) G64_GRP3(0x20) G64_GRP2(0x20) G64_GRP0() GT_SCHED_FENCE()                   \
+    __syncthreads();                                                                           \
+    G64_RD(fa0, fb0, (CUR) ^ 1, 0) G64_MM(fa1, fb1) G64_GRP0() GT_SCHED_FENCE()                \
     }
+    if constexpr (GT_G64_DEEP) {
+      for (int kt = 0; kt < nk; kt += 6) {
+        G64_SLAB3(0, wa, wb, kt) G64_SLAB3(1, ua, ub, kt + 1) G64_SLAB3(0, va, vb, kt + 2)
+        G64_SLAB3(1, wa, wb, kt + 3) G64_SLAB3(0, ua, ub, kt + 4) G64_SLAB3(1, va, vb, kt + 5)
+      }
+    } else {
+      for (int kt = 0; kt < nk; kt += 2) {
+        G64_SLAB(0, wa, wb, va, vb, kt)
+        G64_SLAB(1, va, vb, wa, wb, kt + 1)
+      }
+    }
+#undef G64_SLAB3
 #undef G64_SLAB
 #undef G64_RD
 #undef G64_MM
   }
 #undef G64_LD
 #undef G64_ST
-  gemm32_store_epilogue<EPI, 1, 1>(g, acc, m0, n0, wm, wn, r32, h);
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) {
+    if (g.N == 512) gemm64_ln_epilogue<EPI, 8>(g, acc[0][0], m0, n0, wm, wn, r32, h, xtag, smem);
+    else            gemm64_ln_epilogue<EPI, 4>(g, acc[0][0], m0, n0, wm, wn, r32, h, xtag, smem);
+  } else {
+    gemm32_store_epilogue<EPI, 1, 1>(g, acc, m0, n0, wm, wn, r32, h);
+  }
 }
 
 // GT_TRACE_GEMM64=1: one line on stderr per launch (tests assert that a shape really took this kernel)
@@ -226,6 +526,8 @@ __global__ __launch_bounds__(256, 2) void gemm64h_kernel(GemmArgs g) {
   const int m0 = (bid / gx) * 64, n0 = (bid % gx) * 64, nk = g.K / BK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
+  uint32_t xtag = 0;
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) xtag = g64_seq(g64_rowx(g, m0).ready_rb + wm * (g.N / 32) + (n0 >> 5) + wn);
   G32hRegs a0[PER], b0[PER], a1[PER], b1[PER], a2[PER], b2[PER];
   const uint16_t* pa[PER];
   const uint16_t* pb[PER];
@@ -277,7 +579,13 @@ __global__ __launch_bounds__(256, 2) void gemm64h_kernel(GemmArgs g) {
 #undef G64H_SLAB
 #undef G64H_LD
 #undef G64H_ST
-  gemm32_store_epilogue<EPI, 1, 1>(g, acc, m0, n0, wm, wn, r32, h);
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) {
+    float* const fsm = reinterpret_cast<float*>(sm);             // (4 x 64 x 136 bf16 = 69632 bytes: room for the partials' 35 KB)
+    if (g.N == 512) gemm64_ln_epilogue<EPI, 8>(g, acc[0][0], m0, n0, wm, wn, r32, h, xtag, fsm);
+    else            gemm64_ln_epilogue<EPI, 4>(g, acc[0][0], m0, n0, wm, wn, r32, h, xtag, fsm);
+  } else {
+    gemm32_store_epilogue<EPI, 1, 1>(g, acc, m0, n0, wm, wn, r32, h);
+  }
 }
 // host side: shadows present, interior tiles, whole 128-wide slabs, 16-byte rows
 static inline bool gemm64h_ok(const GemmArgs& g, int epi) {

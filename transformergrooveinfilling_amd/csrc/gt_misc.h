@@ -489,24 +489,30 @@ __global__ void step_inc_kernel(gt_step_state* st) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1u; st->opt_step += 1u; }
 }
 
+// Fail-safe of the in-launch exchanges (QUAD pair exchange of gt_seq.h, row exchange of gt_gemm64.h): with the region's error word set
+// (err; nullptr: this caller has none), or with a non-zero GUARD element g[n - 1] -- padding behind the 27-float output bias, zero in a
+// single process; a data-parallel host writes its error flag there before the gradient all-reduce, so every rank sees the sum -- the
+// update applies NOTHING: parameters and moments stay, the consumed gradients are cleared.  n - 1 itself is neither updated nor cleared.
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n, const gt_step_state* st,
-                                                  int zero_grads) {
-  const float k = st->lr * st->grad_scale;
+                                                  int zero_grads, const unsigned* err = nullptr) {
+  const bool skip = (err != nullptr && *err != 0u) || g[n - 1] != 0.f;
+  const float k = skip ? 0.f : st->lr * st->grad_scale;
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i + 3 < n) {
+  if (i + 4 < n) {
     float4 pv = *reinterpret_cast<float4*>(p + i);
     const float4 gv = *reinterpret_cast<const float4*>(g + i);
-    pv.x -= k * gv.x; pv.y -= k * gv.y; pv.z -= k * gv.z; pv.w -= k * gv.w;
+    if (!skip) { pv.x -= k * gv.x; pv.y -= k * gv.y; pv.z -= k * gv.z; pv.w -= k * gv.w; }
     *reinterpret_cast<float4*>(p + i) = pv;
     if (zero_grads) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    for (int64_t j = i; j < n; ++j) { p[j] -= k * g[j]; if (zero_grads) g[j] = 0.f; }
+    for (int64_t j = i; j < n - 1; ++j) { if (!skip) p[j] -= k * g[j]; if (zero_grads) g[j] = 0.f; }
   }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const gt_step_state* st, int zero_grads,
-                                                   int step_advanced) {
+                                                   int step_advanced, const unsigned* err = nullptr) {
+  const bool skip = (err != nullptr && *err != 0u) || g[n - 1] != 0.f;        // (see sgd_kernel)
   const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->opt_step + (step_advanced ? 0u : 1u));
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = st->lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
@@ -515,12 +521,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int64_t i = i0 + u;
-    if (i < n) {
-      const float gi = g[i] * gs;
-      const float mi = b1 * m[i] + (1.0f - b1) * gi;
-      const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-      m[i] = mi; v[i] = vi;
-      p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    if (i < n - 1) {
+      if (!skip) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+      }
       if (zero_grads) g[i] = 0.f;
     }
   }

@@ -611,12 +611,12 @@ class StepEngine:
             s = s_or_ws
             if s.xchg_off is None:
                 try:
-                    s.xchg_off = self.lib.ws_find(s.cfg, "seq_xchg")[0]
+                    s.xchg_off = self.lib.ws_find(s.cfg, "xchg_err")[0]
                 except Exception:
                     s.xchg_off = -1
             return s.ws[s.xchg_off:s.xchg_off + 1].view(torch.int32) if s.xchg_off >= 0 else None
         try:
-            off = self.lib.ws_find(cfg, "seq_xchg")[0]
+            off = self.lib.ws_find(cfg, "xchg_err")[0]
         except Exception:
             return None
         return s_or_ws[off:off + 1].view(torch.int32) if off >= 0 else None
@@ -640,6 +640,7 @@ class StepEngine:
         warnings.warn(msg + " -- the affected updates were skipped on the device; falling back to two workgroups per sequence "
                       "(GT_SEQ_QUAD=0) for the rest of this process", RuntimeWarning)
         self.lib.cdll.gt_set_seq_quad(0)
+        self.lib.cdll.gt_set_ln_exchange(0)        # (d_model 256 / 512: the LayerNorm as a row pass of its own again)
         self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)      # (zeroes the region: stale granules, the word)
         for t in self._slots.values():             # captured graphs hold QUAD launches; the launch count changes with the schedule
             t.graphs.clear(); t.keep.clear(); t.use_graph = None
