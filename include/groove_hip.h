@@ -51,7 +51,13 @@ typedef struct gt_config {
                            * forward / dgrad / wgrad GEMM are rounded to bf16 (round-to-nearest-even) on their way into the
                            * matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulate); master weights, activations in HBM,
                            * attention core, LayerNorm, softmax, loss and optimizer stay fp32.  Bias gradients are column sums
-                           * of the bf16-rounded output gradient. */
+                           * of the bf16-rounded output gradient.
+                           * 2 = bf16 where the bytes are (round 5): on top of 1, the Linear OUTPUTS of the encoder layers that
+                           * torch.autocast(bfloat16) hands on as bf16 are stored in bf16 alone -- qkv (the attention kernels then do
+                           * fp32 arithmetic on bf16-stored q / k / v), the out-proj / linear2 outputs ahead of their LayerNorm, the
+                           * dgrad outputs ahead of a LayerNorm backward, dctx.  Residual stream, LayerNorm statistics, softmax, loss,
+                           * master weights and optimizer stay fp32.  In force where the bf16 operand shadows apply at level 2 and
+                           * the heads are 64 / 128 wide (gt_precision_in_force); elsewhere it runs as precision 1. */
 } gt_config;
 
 /* device-resident per-step state, so that a captured hipGraph replays with fresh dropout masks,
@@ -248,6 +254,8 @@ int gt_debug_occupy_cus(int nblocks, int usec, gt_stream_t stream);
  * which gt_ws_find names are live: set it before sizing a workspace.  gt_operand_shadow_level: the level in force for a configuration. */
 int gt_set_operand_shadows(int level);
 int gt_operand_shadow_level(const gt_config* cfg);
+/* The precision a configuration really runs at: 2 only where gt_config.precision = 2 applies (see there), else 1 / 0. */
+int gt_precision_in_force(const gt_config* cfg);
 /* Weight gradients as RIDER workgroups (csrc/gt_seq_wg.h): in the SPLIT mode at d_model 128 the backward phases' launches carry, on
  * the CUs their 2 x batch sequence workgroups leave idle, the weight gradients whose operands the earlier phases completed; one
  * workgroup owns a 32 x 64 gradient tile over ALL tokens (no atomics: bitwise reproducible), and a tail launch does what cannot ride

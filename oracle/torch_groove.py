@@ -221,3 +221,24 @@ def train_step(model, opt, x, y, hit_loss_penalty, encoder_only=True):
     out[0].backward()
     opt.step()
     return out
+
+
+def forward_autocast(P, cfg, x, tgt=None):
+    """Eval-mode forward of the stock modules under ``torch.autocast("cpu", dtype=torch.bfloat16)`` and, beside it, in fp32 -- the
+    third-party definition of "bf16 where the bytes are" that gt_config.precision = 2 is anchored on (tests/: the device's outputs must sit
+    within the bf16 effect of this run).  P: {state-dict name: array}.  -> (autocast [h | v | o], fp32 [h | v | o]) as float64 arrays."""
+    import numpy as np
+    m = build(dict(cfg, dropout=0.0))
+    sd = m.state_dict()
+    for k in sd:
+        if k in P:
+            sd[k] = torch.from_numpy(np.asarray(P[k], np.float32)).reshape(sd[k].shape)
+    m.load_state_dict(sd)
+    m.eval()
+    xt = torch.from_numpy(np.asarray(x, np.float32))
+    args = (xt,) if tgt is None else (xt, torch.from_numpy(np.asarray(tgt, np.float32)))
+    with torch.no_grad():
+        ref = torch.cat([t.float() for t in m(*args)], -1).double().numpy()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = torch.cat([t.float() for t in m(*args)], -1).double().numpy()
+    return out, ref

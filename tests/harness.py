@@ -165,8 +165,15 @@ class Runner:
 
     BF16_ONLY = ("ctx", "hact", "dhid", "dqkv", "dzAm", "dzBm")
 
+    def precision_in_force(self):
+        """0 / 1 / 2: what gt_config.precision really runs as for this shape (2 needs the level-2 operand shadows and 64- / 128-wide heads)"""
+        return int(self.lib.cdll.gt_precision_in_force(ctypes.byref(self.c)))
+
     def bf16_only(self, name, layer=0):
-        """Is this saved tensor stored in bf16 alone (gt_set_operand_shadows level 2: the encoder layers' operand-only tensors)?"""
+        """Is this saved tensor stored in bf16 alone (gt_set_operand_shadows level 2: the encoder layers' operand-only tensors;
+        precision 2: qkv as well)?"""
+        if name == "qkv":
+            return layer < self.cfgd["num_encoder_layers"] and self.precision_in_force() == 2
         return (name in self.BF16_ONLY and layer < self.cfgd["num_encoder_layers"]
                 and self.lib.cdll.gt_operand_shadow_level(ctypes.byref(self.c)) == 2)
 

@@ -114,7 +114,7 @@ def _rms(a):
     return float(np.sqrt((np.asarray(a, np.float64) ** 2).mean()))
 
 
-def _close(dev, ref, what, tol=BF16_OP_TOL, where=None, stored16=False):
+def _close(dev, ref, what, tol=BF16_OP_TOL, where=None, stored16=False, rms_tol=None):
     """stored16: the device keeps this tensor in bf16 alone (operand-only tensors, gt_set_operand_shadows level 2) -- what is read back
     is the RNE rounding of the value the bar applies to, so each element may additionally be off by half a bf16 ulp of itself (2^-9;
     2^-8 allowed: the fp32 value may sit a hair on the other side of a rounding boundary)."""
@@ -126,6 +126,8 @@ def _close(dev, ref, what, tol=BF16_OP_TOL, where=None, stored16=False):
         err = err * where
     scale = max(float(np.abs(ref).max()), 1e-6)
     assert err.max() <= tol * scale, "%s: max |err| %.3g of max |ref| %.3g (ratio %.3g)" % (what, err.max(), scale, err.max() / scale)
+    if rms_tol is not None:      # behind a HIDDEN bf16 rounding single elements may sit one ulp off (max bar 2^-8-ish); on average nothing may
+        assert _rms(err) <= rms_tol * scale, "%s: rms err %.3g of max |ref| %.3g (ratio %.3g)" % (what, _rms(err), scale, _rms(err) / scale)
 
 
 def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
@@ -162,6 +164,21 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
         gdy = dy * g
         return rstd * (gdy - gdy.mean(-1, keepdims=True) - xh * (gdy * xh).mean(-1, keepdims=True)), (dy * xh).sum(0), dy.sum(0)
 
+    # precision 2 (encoder layers): Linear outputs are STORED in bf16 -- qkv and dqkv observably (stored16), the out-proj / linear2 outputs
+    # ahead of their LayerNorm and the dgrad outputs ahead of a LayerNorm backward only transiently: the oracle rounds the same value (hrb)
+    # and an element whose fp32 and fp64 values straddle a rounding boundary lands one bf16 ulp apart -- max bar 2^-7 of the tensor's
+    # largest entry, RMS bar 2e-4 (the flips are rare)
+    P2 = r.precision_in_force() == 2
+    hrb = (lambda a: rb(a)) if P2 else (lambda a: a)
+    HID = dict(tol=2.0 ** -7, rms_tol=2e-4) if P2 else {}
+    heads, hd = cfg["n_heads"], cfg["d_model"] // cfg["n_heads"]
+
+    def split_heads(a):                                   # (M, d) -> (B, H, 32, hd)
+        return a.reshape(M // 32, 32, heads, hd).transpose(0, 2, 1, 3)
+
+    def merge_heads(a):
+        return a.transpose(0, 2, 1, 3).reshape(M, heads * hd)
+
     n = 0
     # ---------------------------------------------------------------------------------------------- forward
     def input_layer(xin, pre, a0name, outname, site):
@@ -174,10 +191,12 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
 
     def attn_block(name, gl, xin, inw, qkvname, ctxname, outname, xhname, normname, site, q_rows=None):
         nonlocal n
-        out = lin(ws(ctxname, gl), P[name + "out_proj.weight"], P[name + "out_proj.bias"]) * mask(site, M * d, (M, d))
+        enc = P2 and gl < L
+        out = lin(ws(ctxname, gl), P[name + "out_proj.weight"], P[name + "out_proj.bias"])
+        out = (hrb(out) if enc else out) * mask(site, M * d, (M, d))
         y, xh = ln(xin + out, P[normname + ".weight"], P[normname + ".bias"])
-        _close(ws(outname, gl), y, "%s out-proj + norm (layer %d)" % (name, gl), tol=2e-5)
-        _close(ws(xhname, gl), xh, "%s xhat (layer %d)" % (name, gl), tol=2e-5)
+        _close(ws(outname, gl), y, "%s out-proj + norm (layer %d)" % (name, gl), **(HID if enc else dict(tol=2e-5)))
+        _close(ws(xhname, gl), xh, "%s xhat (layer %d)" % (name, gl), **(HID if enc else dict(tol=2e-5)))
         n += 2
         return ws(outname, gl)
 
@@ -186,9 +205,11 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
         hp = lin(xin, P[pre + "linear1.weight"], P[pre + "linear1.bias"])
         _close(ws("hact", gl), np.maximum(hp, 0) * mask(ng.layer_site(gl, ng.S_FFN), hp.size, hp.shape),
                pre + "linear1", where=np.abs(hp) > 1e-4, stored16=r.bf16_only("hact", gl))
-        f = lin(ws("hact", gl), P[pre + "linear2.weight"], P[pre + "linear2.bias"]) * mask(ng.layer_site(gl, ng.S_DROPF), M * d, (M, d))
+        enc = P2 and gl < L - 1          # (the top encoder layer's linear2 feeds the two-norm pass from fp32)
+        f = lin(ws("hact", gl), P[pre + "linear2.weight"], P[pre + "linear2.bias"])
+        f = (hrb(f) if enc else f) * mask(ng.layer_site(gl, ng.S_DROPF), M * d, (M, d))
         y, xh = ln(xin + f, P[pre + normname + ".weight"], P[pre + normname + ".bias"])
-        _close(ws(outname, gl), y, pre + "linear2 + norm", tol=2e-5)
+        _close(ws(outname, gl), y, pre + "linear2 + norm", **(HID if enc else dict(tol=2e-5)))
         n += 2
         return ws(outname, gl)
 
@@ -198,8 +219,18 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
     for l in range(L):
         pre = "Encoder.Encoder.layers.%d." % l
         enc_in.append(cur)
-        _close(ws("qkv", l), lin(cur, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"]), pre + "in_proj")
+        _close(ws("qkv", l), lin(cur, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"]), pre + "in_proj",
+               stored16=r.bf16_only("qkv", l))
         n += 1
+        if P2:      # the attention core on bf16-STORED q / k / v (fp32 arithmetic; attn_fwd_lds_kernel): probabilities and ctx
+            qkv = ws("qkv", l)
+            q_, k_, v_ = (split_heads(qkv[:, i * d:(i + 1) * d]) for i in range(3))
+            sc = q_ @ k_.transpose(0, 1, 3, 2) / np.sqrt(hd)
+            pr = np.exp(sc - sc.max(-1, keepdims=True)); pr /= pr.sum(-1, keepdims=True)
+            _close(f64(r.ws_get("P", l)).reshape(pr.shape), pr, pre + "attention probabilities over bf16-stored q / k", tol=2e-5)
+            pm = pr * mask(ng.layer_site(l, ng.S_ATTN), pr.size, pr.shape)
+            _close(ws("ctx", l), merge_heads(pm @ v_), pre + "attention output over bf16-stored v", stored16=True)
+            n += 2
         x1 = attn_block(pre + "self_attn.", l, cur, None, "qkv", "ctx", "x1", "xhat1", pre + "norm1", ng.layer_site(l, ng.S_DROP1))
         cur = ffn_block(pre, l, x1, "norm2")
     mem, _ = ln(cur, P["Encoder.Encoder.norm.weight"], P["Encoder.Encoder.norm.bias"])
@@ -252,11 +283,14 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
         _close(tmp("dhid", gl, F), dh, pre + "linear2 dgrad (relu / dropout mask)", stored16=r.bf16_only("dhid", gl))
         dhid = tmp("dhid", gl, F)
         wgrad(dhid, xin, pre + "linear1.weight", pre + "linear1.bias")
-        pre_ln = rb(dhid) @ rb(P[pre + "linear1.weight"]) + dz
+        enc = P2 and gl < L
+        pre_ln = rb(dhid) @ rb(P[pre + "linear1.weight"])
+        pre_ln = (hrb(pre_ln) if enc else pre_ln) + dz
         want, dg, db = ln_bwd(pre_ln, ws(prev_xh, gl), ws(prev_rstd, gl, 1), P[pre + prev_norm + ".weight"])
-        _close(tmp(dzprev_name, gl, d), want, pre + "linear1 dgrad + " + prev_norm + " backward", tol=1e-4)
-        _close(G[pre + prev_norm + ".weight"], dg, "grad " + pre + prev_norm + ".weight", tol=1e-4)
-        _close(G[pre + prev_norm + ".bias"], db, "grad " + pre + prev_norm + ".bias", tol=1e-4)
+        HB = dict(tol=2.0 ** -7, rms_tol=4e-4) if enc else dict(tol=1e-4)
+        _close(tmp(dzprev_name, gl, d), want, pre + "linear1 dgrad + " + prev_norm + " backward", **HB)
+        _close(G[pre + prev_norm + ".weight"], dg, "grad " + pre + prev_norm + ".weight", **HB)
+        _close(G[pre + prev_norm + ".bias"], db, "grad " + pre + prev_norm + ".bias", **HB)
         n += 4
 
     if Ld:
@@ -282,12 +316,26 @@ def check_ops_bf16(r, P, cfg, x, tgt, rng, p, G=None):
                    stored16=r.bf16_only("dzBm", l))
         wgrad(dz1m, ws("ctx", l), pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias")
         dqkv = tmp("dqkv", l, 3 * d)
+        if P2:      # attention backward over bf16-stored q / k / v / dctx (attn_bwd_lds_kernel, IN16): dctx = the out-proj dgrad, itself stored in bf16
+            dctx = hrb(rb(dz1m) @ rb(P[pre + "self_attn.out_proj.weight"]))
+            qkv = ws("qkv", l)
+            q_, k_, v_ = (split_heads(qkv[:, i * d:(i + 1) * d]) for i in range(3))
+            pr = f64(r.ws_get("P", l)).reshape(M // 32, heads, 32, 32)
+            mk = mask(ng.layer_site(l, ng.S_ATTN), pr.size, pr.shape)
+            do = split_heads(dctx)
+            dp = (do @ v_.transpose(0, 1, 3, 2)) * mk
+            ds = pr * (dp - (dp * pr).sum(-1, keepdims=True)) / np.sqrt(hd)
+            want = np.concatenate([merge_heads(ds @ k_), merge_heads(ds.transpose(0, 1, 3, 2) @ q_), merge_heads((pr * mk).transpose(0, 1, 3, 2) @ do)], 1)
+            _close(dqkv, want, pre + "attention backward over bf16-stored operands", tol=2.0 ** -6, rms_tol=2e-3)
+            n += 1
         wgrad(dqkv, enc_in[l], pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias")
-        dx = rb(dqkv) @ rb(P[pre + "self_attn.in_proj_weight"]) + dz1
+        dx = rb(dqkv) @ rb(P[pre + "self_attn.in_proj_weight"])
+        dx = (hrb(dx) if (P2 and l > 0) else dx) + dz1
         if l > 0:
             pp = "Encoder.Encoder.layers.%d." % (l - 1)
             want, _, _ = ln_bwd(dx, ws("xhat2", l - 1), ws("rstd2", l - 1, 1), P[pp + "norm2.weight"])
-            _close(tmp("dzA", l - 1, d), want, pre + "in_proj dgrad + previous layer's norm2 backward", tol=1e-4)
+            _close(tmp("dzA", l - 1, d), want, pre + "in_proj dgrad + previous layer's norm2 backward",
+                   **(dict(tol=2.0 ** -7, rms_tol=4e-4) if P2 else dict(tol=1e-4)))
         else:
             da = dx * mask(ng.SITE_PE_ENC, M * d, (M, d)) * (ws("a0") > 0)
             _close(ws("dctx"), da, "InputLayer backward (in_proj dgrad, dropout, relu mask)", tol=1e-4)
@@ -362,8 +410,10 @@ def _check_bf16_shadows(backend, cfg, B, p, P, x, y):
     return n
 
 
-def check_step_bf16(backend, cfg, B, p=0.0, penalty=0.47, seed=3):
-    cfg = dict(cfg, dropout=p, precision=1)
+def check_step_bf16(backend, cfg, B, p=0.0, penalty=0.47, seed=3, precision=1):
+    """precision = 2: the same two bars; the end-to-end sanity bound is taken against the bf16-OPERAND oracle with a wider factor (the
+    storage roundings of precision 2 are additional noise of the same size: 2.5 x the bf16 effect)"""
+    cfg = dict(cfg, dropout=p, precision=precision)
     cfg0 = dict(cfg, precision=0)
     P = ng.init_params(cfg, seed=seed, perturb=0.05)
     x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=seed + 2)
@@ -380,7 +430,8 @@ def check_step_bf16(backend, cfg, B, p=0.0, penalty=0.47, seed=3):
     eq = _rms(ref0 - ref)
     assert eq > 1e-5, "the bf16 rounding has no visible effect on this case: pick another"
     assert np.abs(hvo - ref).max() < BF16_OUT_MAX, "forward max-abs %g" % np.abs(hvo - ref).max()
-    assert _rms(hvo - ref) <= BF16_E2E_FRAC * eq + 1e-5, "forward rms %g vs bf16 effect %g" % (_rms(hvo - ref), eq)
+    frac = BF16_E2E_FRAC if r.precision_in_force() < 2 else 2.5
+    assert _rms(hvo - ref) <= frac * eq + 1e-5, "forward rms %g vs bf16 effect %g" % (_rms(hvo - ref), eq)
     stats, d_hvo = r.loss(y, penalty)
     rstats, _ = ng.calculate_loss((h, v, o), y.astype(np.float64), penalty)
     assert abs(stats[0] - rstats[0]) < 1e-2 * max(1.0, abs(rstats[0]))
@@ -391,11 +442,32 @@ def check_step_bf16(backend, cfg, B, p=0.0, penalty=0.47, seed=3):
     return r, P, G
 
 
-def check_train_step_bf16(backend, cfg, B, p):
+def check_autocast_anchor(backend, cfg, B, seed=3):
+    """precision = 2 against the third-party definition it is anchored on: the eval forward of the stock torch modules under
+    torch.autocast(bfloat16) (oracle.torch_groove.forward_autocast).  Two realisations of "bf16 where the bytes are" cannot agree element
+    for element (autocast also runs the attention products in bf16 and rounds more tensors); the device must sit within the bf16 effect
+    itself: RMS(device - autocast) and RMS(device - fp32) <= 1.5 x RMS(fp32 - autocast)."""
+    from oracle import torch_groove as tg
+    cfg = dict(cfg, dropout=0.0, precision=2)
+    P = ng.init_params(cfg, seed=seed, perturb=0.05)
+    x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=seed + 2)
+    r = Runner(cfg, B, backend)
+    assert r.precision_in_force() == 2, "precision 2 is not in force for this shape"
+    r.set_params(P)
+    hvo = r.forward(x, None, train=False)
+    ac, ref = tg.forward_autocast(P, cfg, x)
+    eq = _rms(ref - ac)
+    assert eq > 1e-5
+    assert _rms(hvo - ac) <= 1.5 * eq + 1e-5 and _rms(hvo - ref) <= 1.5 * eq + 1e-5, (_rms(hvo - ac), _rms(hvo - ref), eq)
+    assert np.abs(hvo - ac).max() < BF16_OUT_MAX
+    return _rms(hvo - ac), _rms(hvo - ref), eq
+
+
+def check_train_step_bf16(backend, cfg, B, p, precision=1):
     """gt_train_step with precision = 1 (fp32 master weights): after each of two SGD steps the per-operation checks hold on the
     step's own saved state, the update is exactly  w -= lr * g  of the device's gradients ... observed through the parameters:
     they move along the bf16-operand oracle's gradient within the end-to-end bound."""
-    cfg = dict(cfg, dropout=p, precision=1)
+    cfg = dict(cfg, dropout=p, precision=precision)
     P = ng.init_params(cfg, seed=9, perturb=0.05)
     x, y = ng.synthetic_batch(B, cfg["embedding_size_src"], seed=4)
     tgt = shift_right(y) if cfg.get("num_decoder_layers", 0) else None

@@ -121,6 +121,21 @@ def test_big_tile_kernel_variant():
                           dict(GT_EMU_LIB_PATH=so, GT_T64R_MIN="1", GT_TRACE_GEMM64="1"))
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
     assert any(ln.startswith("[gemm64] bf16-source") for ln in out.stderr.splitlines())
+    # gt_config.precision = 2 (round 5): the Linear outputs of the encoder layers stored in bf16 alone -- qkv (attention kernels staging bf16 q /
+    # k / v / dctx into LDS: head_dim 64 and 128), the out-proj / linear2 outputs ahead of their LayerNorm, the dgrad outputs ahead of a
+    # LayerNorm backward, dctx.  Per-operation teacher-forced parity (hidden roundings restated), a train step, the torch.autocast anchor,
+    # and the shapes where it falls back to precision 1 (decoder layers; narrow heads)
+    out = _emu_subprocess("r, P, G = parity.check_step_bf16('emu', cfg_dict(256, 4, 128, 2), 4, 0.2, precision=2)\n"
+                          "assert r.precision_in_force() == 2\n"
+                          "parity.check_step_bf16('emu', cfg_dict(256, 2, 256, 1), 4, 0.0, precision=2)\n"       # head_dim 128, no dropout
+                          "parity.check_train_step_bf16('emu', cfg_dict(256, 4, 128, 1), 4, 0.1, precision=2)\n"
+                          "parity.check_autocast_anchor('emu', cfg_dict(256, 4, 128, 2), 4)\n"
+                          "r, P, G = parity.check_step_bf16('emu', cfg_dict(256, 4, 128, 1, 1), 4, 0.1, precision=2)\n"   # encoder-decoder: the decoder layers keep fp32 tensors
+                          "assert r.precision_in_force() == 2\n"
+                          "r, P, G = parity.check_step_bf16('emu', cfg_dict(256, 8, 128, 1), 4, 0.0, precision=2)\n"      # head_dim 32: runs as precision 1
+                          "assert r.precision_in_force() == 1\n",
+                          dict(GT_EMU_LIB_PATH=so))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
 
 
 def _emu_subprocess(code, env):

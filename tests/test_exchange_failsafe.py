@@ -21,7 +21,9 @@ def _engine(B, world=1, seed=3, **kw):
     from transformergrooveinfilling_amd import layout
     from transformergrooveinfilling_amd.engine import StepEngine
     lib = emu_lib()
-    lib.cdll.gt_set_seq_quad(-1)
+    for f in ("gt_set_seq_quad", "gt_set_seq_split", "gt_set_seq_ride"):      # (process-global switches other tests of this run may have left)
+        getattr(lib.cdll, f)(-1)
+    lib.cdll.gt_set_seq(1)
     eng = StepEngine(batch_size=B, optimizer=kw.pop("optimizer", "sgd"), learning_rate=0.05, hit_loss_penalty=0.47, seed=seed, device="cpu",
                      world_size=world, lib=lib, **DIMS)
     eng.load_named(layout.init_params(DIMS, seed=5))

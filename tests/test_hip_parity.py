@@ -182,6 +182,23 @@ def test_bf16_shadows_of_the_gemm_operands():
         lib.cdll.gt_set_operand_shadows(-1)
 
 
+@pytest.mark.parametrize("cfg,B,p", [(cfg_dict(512, 8, 512, 2, embedding_size_src=27), 64, 0.24),     # a GPU's share of configs[4]: 64x64 bf16-source tiles, attn_bwd <64, 1>
+                                     (cfg_dict(512, 8, 512, 1), 256, 0.1),                            # 8192 tokens: 128x128 bf16-source tiles for the QKV projection
+                                     (cfg_dict(512, 8, 512, 1), 16, 0.0),                             # below the shadows' threshold: precision 2 is not in force
+                                     (cfg_dict(256, 2, 512, 1), 256, 0.3)])                           # head_dim 128
+def test_step_parity_precision2_bf16_storage(cfg, B, p):
+    """gt_config.precision = 2: Linear outputs of the encoder layers stored in bf16 alone (qkv, pre-LayerNorm outputs, pre-LayerNorm-backward
+    dgrads, dctx) -- per-operation teacher-forced parity with the hidden roundings restated, end-to-end sanity bound"""
+    r, P, G = parity.check_step_bf16("hip", cfg, B, p, precision=2)
+    assert r.precision_in_force() == (2 if B >= 64 else 1)      # (bs 16: below the threshold of the operand shadows -- runs as precision 1)
+
+
+def test_precision2_train_step_and_autocast_anchor():
+    parity.check_train_step_bf16("hip", cfg_dict(512, 8, 512, 1, embedding_size_src=27), 64, 0.2, precision=2)
+    dev_ac, dev_fp32, eq = parity.check_autocast_anchor("hip", cfg_dict(512, 8, 512, 2, embedding_size_src=27), 64)
+    print("precision 2 vs torch.autocast: rms(device - autocast) %.3g, rms(device - fp32) %.3g, rms(fp32 - autocast) %.3g" % (dev_ac, dev_fp32, eq))
+
+
 def test_layernorm_row_exchange_of_the_64_tile_linears():
     """opt-in (gt_set_ln_exchange(1)): LayerNorm forward / backward inside the producing Linear / dgrad at 2048 tokens, the 8 workgroups of a
     row block meeting through the in-launch row exchange (csrc/gt_gemm64.h) -- oracle parity at a GPU's share of configs[3] / [4], a train

@@ -32,7 +32,7 @@ for _ in range(5):
 prof = eng.profile(steps)
 tot = sum(v[1] for v in prof.values())
 print(name, "-- kernel time per step %.1f us, %d launches" % (1e3 * tot / steps, sum(v[0] for v in prof.values()) // steps))
-peak = 2500.0 if dims.get("precision") == "bf16" else 157.3
+peak = 2500.0 if dims.get("precision") in ("bf16", "autocast") else 157.3
 out = {}
 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1]):
     tf = v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0

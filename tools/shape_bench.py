@@ -26,6 +26,8 @@ SHAPES = [
     ("C5 bf16 operands: symbolic S=27, d512/H8/F512/L6 bs64", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3, embedding_size_src=27, precision="bf16"), 64),
     ("C5 bf16 operands: audio (MSO) S=16, d512/H8/F512/L6 bs64", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3, precision="bf16"), 64),
     ("C5 bf16 operands, S=27, bs512 on one GPU", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3, embedding_size_src=27, precision="bf16"), 512),
+    ("C5 precision 2 (bf16 storage of the Linear outputs): S=27, d512/H8/F512/L6 bs64", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3, embedding_size_src=27, precision="autocast"), 64),
+    ("C5 precision 2, S=27, bs512 on one GPU", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3, embedding_size_src=27, precision="autocast"), 512),
 ]
 
 
@@ -56,7 +58,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         ft = bench.f_train_per_seq(dims)
-        bf = dims.get("precision") == "bf16"
+        bf = dims.get("precision") in ("bf16", "autocast")
         peak = 2500.0 if bf else 157.3            # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
         print("%-58s %8.3f ms/step %10.0f seq/s %7.2f TFLOP/s (%.1f %% of %s MFMA peak)  loss %.3f" %
               (name, 1e3 * dt, B / dt, B / dt * ft / 1e12, 100 * B / dt * ft / 1e12 / peak, "bf16" if bf else "fp32", float(eng.stats[0])), flush=True)

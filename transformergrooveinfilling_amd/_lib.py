@@ -74,6 +74,7 @@ _SIGS = {
     "gt_debug_occupy_cus": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
     "gt_set_operand_shadows": (ctypes.c_int, [ctypes.c_int]),
     "gt_operand_shadow_level": (ctypes.c_int, [_cfgp]),
+    "gt_precision_in_force": (ctypes.c_int, [_cfgp]),
     "gt_workspace_init": (ctypes.c_int, [_cfgp, _vp, _vp]),
     "gt_set_seq_ride": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_deterministic": (ctypes.c_int, [ctypes.c_int]),
@@ -152,7 +153,8 @@ def get_lib():
     return _default
 
 
-PRECISION = {"fp32": 0, "f32": 0, "float32": 0, 0: 0, None: 0, "bf16": 1, "bfloat16": 1, 1: 1}
+# 0 fp32 | 1 bf16 GEMM operands | 2 ... and bf16 storage of the Linear outputs ("autocast": what torch.autocast(bfloat16) keeps in bf16)
+PRECISION = {"fp32": 0, "f32": 0, "float32": 0, 0: 0, None: 0, "bf16": 1, "bfloat16": 1, 1: 1, "bf16_storage": 2, "bf16s": 2, "autocast": 2, 2: 2}
 
 
 def make_config(batch, src_dim, d_model, n_heads, dim_ff, n_enc_layers, n_dec_layers=0, dropout=0.0, precision=0):

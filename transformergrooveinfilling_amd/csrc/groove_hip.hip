@@ -382,6 +382,11 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
     *offset = (n == "w16" ? W.w16 : W.w16t) + W.w16_stride * layer; *count = W.w16_stride;
     return 0;
   }
+  if ((n == "qkv16" || n == "dctx16") && p2(c)) {       // precision = 2: bf16 tensors in the first half of the fp32 tensor's buffer
+    if (n == "qkv16") { if (layer < 0 || layer >= c.n_enc_layers) return gt_fail("gt_ws_find: qkv16: layer %d is not an encoder layer", layer); *offset = W.layers[layer].qkv; *count = (M * 3 * d + 1) / 2; }
+    else { *offset = W.dctx; *count = (M * d + 1) / 2; }
+    return 0;
+  }
   const bool want16 = n.size() > 2 && n.compare(n.size() - 2, 2, "16") == 0;
   if (want16) n.resize(n.size() - 2);
   if (n == "x0") set(W.x0, M * d); else if (n == "a0") set(W.a0, M * d);
@@ -527,12 +532,14 @@ static GemmArgs mk_gemm(const float* A, int lda, const float* B, int ldb, float*
   g.bf16 = g_bf16;
   return g;
 }
-// y = x W^T + b  (forward "NT")
+static bool p2(const gt_config& c);
+// y = x W^T + b  (forward "NT");  out16 (precision = 2): y stored in bf16 ALONE at out16 (row stride ldout), `out` not written
 static void linear_fwd(const Ctx& x, const float* in, int ldin, const float* W, const float* b, float* out, int ldout,
-                       int N, int K) {
-  GemmArgs g = mk_gemm(in, ldin, W, K, out, ldout, x.M, N, K);
+                       int N, int K, uint16_t* out16 = nullptr) {
+  GemmArgs g = mk_gemm(in, ldin, W, K, out16 ? nullptr : out, ldout, x.M, N, K);
   g.bias = b;
   if (ldin == K) { g.A16 = sh_act(x, in); g.B16 = sh_w(x, W, false); g.lda16 = g.ldb16 = K; }
+  if (out16) { g.C16 = out16; g.ldc16 = ldout; need16(gemm_on_big_kernel<false, EPI_STORE>(g), "Linear with a bf16-only output (precision 2)"); }
   if (only16(x, in)) need16(g.A16 && g.B16 && gemm32h_ok(g, EPI_STORE), "Linear forward of a bf16-only tensor");
   gemm_launch<false, false, EPI_STORE>(g, x.s);
 }
@@ -606,7 +613,17 @@ static void acquire_set(Ctx& x, int set) {
 #endif
 }
 // dX = dY W   ("NN")
-static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, int ldw, float* dX, int N, int K, int accumulate) {
+// out16 (precision = 2): the result stored in bf16 ALONE at out16 (dense rows of N); dX is then not written
+static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, int ldw, float* dX, int N, int K, int accumulate,
+                        uint16_t* out16 = nullptr) {
+  if (out16 != nullptr) {
+    GemmArgs g = mk_gemm(dY, ldy, W, ldw, nullptr, N, x.M, N, K);
+    if (ldy == K && ldw == N) { g.A16 = sh_act(x, dY); g.B16 = sh_w(x, W, true); g.lda16 = g.ldb16 = K; }
+    g.C16 = out16; g.ldc16 = N;
+    need16(!accumulate && gemm_on_big_kernel<true, EPI_STORE>(g) && (!only16(x, dY) || (g.A16 && g.B16)), "dgrad with a bf16-only output (precision 2)");
+    gemm_launch<false, true, EPI_STORE>(g, x.s);
+    return;
+  }
   if (const float* wt = (ldw == N) ? wT_of(x, W) : nullptr) {      // dX = dY (W^T)^T: the NT form over the transposed copy
     GemmArgs g = mk_gemm(dY, ldy, wt, K, dX, N, x.M, N, K);
     g.accumulate = accumulate; g.as_dgrad = 1;
@@ -668,7 +685,7 @@ static bool row_fused(const Ctx& x) {
   return !x.c.precision && (x.d <= GT_ROW_FUSE_MAX_D || (x.M >= GT_ROW_FUSE_MIN_M && x.d <= GT_ROW_FUSE_BIG_MAX_D));
 }
 static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float* xhat, const float* rstd, int64_t gamma_off, float* dz,
-                   float* dzm, int site);
+                   float* dzm, int site, const uint16_t* dy16 = nullptr);
 static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, int K, const float* res, const float* xhat,
                        const float* rstd, int64_t gamma_off, float* dz, float* dzm, int site) {
   if (!row_fused(x)) {
@@ -693,8 +710,10 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
         return gt_fail("dgrad + LayerNorm backward: the fused launch was refused after its job was registered");
       }
     }
-    dgrad_store(x, dY, ldy, W, x.d, dz, x.d, K, 0);
-    ln_bwd(x, dz, res, xhat, rstd, gamma_off, dz, dzm, site);
+    // precision = 2: the dgrad output lives in bf16 alone -- in the region that receives the bf16 copy of the norm's result (in place)
+    uint16_t* t16 = (p2(x.c) && (x.d == 256 || x.d == 512) && x.ln && x.ln->n < GT_LN_JOBS_MAX) ? sh_act(x, x.drop ? dzm : dz) : nullptr;
+    dgrad_store(x, dY, ldy, W, x.d, dz, x.d, K, 0, t16);
+    ln_bwd(x, dz, res, xhat, rstd, gamma_off, dz, dzm, site, t16);
     return 0;
   }
   GemmArgs g = mk_gemm(dY, ldy, W, x.d, dz, x.d, x.M, x.d, K);
@@ -710,7 +729,7 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
 // dz = LNbwd(dy (+ res)); dzm = dz * dropout mask.  Few tokens: 2 rows per wave (one wave per CU cannot hide its own load
 // latency); many: 8 rows per wave, fewer partials to sum.
 static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float* xhat, const float* rstd, int64_t gamma_off, float* dz,
-                   float* dzm, int site) {
+                   float* dzm, int site, const uint16_t* dy16) {
   const int rpw = x.M <= 4096 ? 2 : GT_LNB_ROWS;
   const int rows_per_block = 4 * rpw;
   const int nblk = (x.M + rows_per_block - 1) / rows_per_block;
@@ -721,11 +740,12 @@ static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float*
     uint16_t* dzm16 = sh_act(x, x.drop ? dzm : dz);
     float* dzm32 = (x.drop && !only16(x, dzm)) ? dzm : (float*)nullptr;          // (level 2: the masked copy lives in bf16 alone)
     if (x.d == 512) gt_launch(ln_bwd_v4_kernel<2>, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd, x.prm + gamma_off, dz,
-                              dzm32, mk_drop(x, site), part, x.M, rpw, dzm16);
+                              dzm32, mk_drop(x, site), part, x.M, rpw, dzm16, dy16);
     else gt_launch(ln_bwd_v4_kernel<1>, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd, x.prm + gamma_off, dz,
-                   dzm32, mk_drop(x, site), part, x.M, rpw, dzm16);
+                   dzm32, mk_drop(x, site), part, x.M, rpw, dzm16, dy16);
     return;
   }
+  need16(dy16 == nullptr, "LayerNorm backward of a bf16-only gradient (precision 2)");
   gt_launch(ln_bwd_kernel, dim3(nblk), dim3(256), x.s, dy, res, xhat, rstd,
             x.prm + gamma_off, dz, (x.drop && !only16(x, dzm)) ? dzm : (float*)nullptr, mk_drop(x, site), x.grd + gamma_off,
             x.grd + gamma_off + (x.d + 63) / 64 * 64, part, x.M, x.d, rpw, sh_act(x, x.drop ? dzm : dz));
@@ -759,6 +779,25 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
   if (!row_fused(x)) {
     g.A16 = sh_act(x, in); g.B16 = sh_w(x, x.prm + w_off, false); g.lda16 = g.ldb16 = K;
     if (only16(x, in)) need16(g.A16 && g.B16 && gemm32h_ok(g, EPI_STORE), "Linear (+ LayerNorm) of a bf16-only tensor");
+    // precision = 2: the Linear output ahead of the norm lives in bf16 alone -- in the region that then receives the bf16 copy of the norm's
+    // result (the row pass reads a row into registers before it writes any of it)
+    uint16_t* t16 = p2(x.c) ? sh_act(x, out) : nullptr;
+    if (t16 != nullptr) {
+      g.C = nullptr; g.C16 = t16; g.ldc16 = x.d;
+      need16(gemm_on_big_kernel<false, EPI_STORE>(g), "Linear (+ LayerNorm) with a bf16-only output (precision 2)");
+      gemm_launch<false, false, EPI_STORE>(g, x.s);
+      if (second) {
+        gt_prof_tag("ln_fwd", 0, 22.0 * x.M * x.d);
+        gt_launch(ln_fwd2_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
+                  x.prm + gamma_off + bo, out, xhat, rstd, (const float*)(x.prm + second->gamma_off),
+                  (const float*)(x.prm + second->gamma_off + bo), second->y, second->xhat, second->rstd, x.M, x.d, (const uint16_t*)t16);
+        return 0;
+      }
+      gt_prof_tag("ln_fwd", 0, 14.0 * x.M * x.d);
+      gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
+                x.prm + gamma_off + bo, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d, t16, (const uint16_t*)t16);
+      return 0;
+    }
     if (!second && ln_xchg(x)) {
       // ONE launch: the Linear on 64x64 tiles, dropout + residual + LayerNorm in its epilogue (row statistics through the in-launch exchange)
       GemmArgs f = g;
@@ -773,12 +812,12 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
       gt_prof_tag("ln_fwd", 0, 24.0 * x.M * x.d);
       gt_launch(ln_fwd2_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
                 x.prm + gamma_off + bo, out, xhat, rstd, (const float*)(x.prm + second->gamma_off),
-                (const float*)(x.prm + second->gamma_off + bo), second->y, second->xhat, second->rstd, x.M, x.d);
+                (const float*)(x.prm + second->gamma_off + bo), second->y, second->xhat, second->rstd, x.M, x.d, (const uint16_t*)nullptr);
       return 0;
     }
     gt_prof_tag("ln_fwd", 0, 16.0 * x.M * x.d);
     gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, res, mk_drop(x, site), x.prm + gamma_off,
-              x.prm + gamma_off + bo, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d, sh_act(x, out));
+              x.prm + gamma_off + bo, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d, sh_act(x, out), (const uint16_t*)nullptr);
     return 0;
   }
   g.res = res; g.ldres = x.d;
@@ -789,7 +828,7 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
   if (second) {                                     // fused row tile for the first norm: the second one is its own pass
     gt_prof_tag("ln_fwd", 0, 12.0 * x.M * x.d);
     gt_launch(ln_fwd_kernel, dim3((x.M + 3) / 4), dim3(256), x.s, (const float*)out, (const float*)nullptr, no_drop(),
-              x.prm + second->gamma_off, x.prm + second->gamma_off + bo, second->y, second->xhat, second->rstd, x.M, x.d, x.d, x.d, x.d, (uint16_t*)nullptr);
+              x.prm + second->gamma_off, x.prm + second->gamma_off + bo, second->y, second->xhat, second->rstd, x.M, x.d, x.d, x.d, x.d, (uint16_t*)nullptr, (const uint16_t*)nullptr);
   }
   return 0;
 }
@@ -814,8 +853,9 @@ static bool attn_col_split(const Ctx& x, int pairs) {
   const int hd = attn_mfma_hd(x);
   return on && (hd == 64 || hd == 128) && pairs < GT_ATTN_CS_MAX_PAIRS;
 }
+// in16 (precision = 2): q / k / v are bf16 tensors at the same ELEMENT offsets (the qkv buffer holds bf16 in its first half)
 static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, float* P, float* ctx,
-                          int causal, int site) {
+                          int causal, int site, bool in16 = false) {
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = P; a.ctx = ctx; a.ldc = x.d;
@@ -824,6 +864,14 @@ static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k,
   if (only16(x, ctx)) { need16(a.ctx16 != nullptr, "attention output stored in bf16 alone"); if (a.ctx16) a.ctx = nullptr; }
   gt_prof_tag("attn_fwd", 4.0 * x.M * 32 * x.d, 4.0 * (4.0 * x.M * x.d + 1024.0 * x.c.batch * x.H));
   const dim3 grid(x.c.batch * x.H);
+  if (in16) {
+    a.q16 = reinterpret_cast<const uint16_t*>(q); a.k16 = a.q16 + (k - q); a.v16 = a.q16 + (v - q);
+    a.q = a.k = a.v = nullptr;
+    need16(((ldq | ldkv) & 3) == 0 && (attn_mfma_hd(x) == 64 || attn_mfma_hd(x) == 128), "attention over bf16-stored q / k / v (precision 2)");
+    if (attn_mfma_hd(x) == 128) gt_launch(attn_fwd_lds_kernel<128, true>, grid, dim3(128), x.s, a);
+    else gt_launch(attn_fwd_lds_kernel<64, true>, grid, dim3(128), x.s, a);
+    return;
+  }
   switch (attn_mfma_hd(x)) {
     case 16:  gt_launch(attn_fwd_mfma_kernel<16, false>, grid, dim3(128), x.s, a); break;
     case 32:  gt_launch(attn_fwd_mfma_kernel<32, false>, grid, dim3(128), x.s, a); break;
@@ -837,7 +885,7 @@ static void attention_fwd(const Ctx& x, const float* q, int ldq, const float* k,
 #define GT_ATTN_BWD_LDS_MIN 1024       // (sequence, head) pairs from which attention backward stages its operands in LDS
 #endif
 static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k, const float* v, int ldkv, const float* P,
-                          const float* dctx, float* dq, int lddq, float* dk, float* dv, int lddkv, int site) {
+                          const float* dctx, float* dq, int lddq, float* dk, float* dv, int lddkv, int site, bool in16 = false) {
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.P = const_cast<float*>(P);
@@ -850,6 +898,15 @@ static void attention_bwd(const Ctx& x, const float* q, int ldq, const float* k,
   // head_dim 64 with the chip full: the LDS-staged form (every operand byte requested once, 16 bytes at a time)
   static const int lds_min = [] { const char* e = getenv("GT_ATTN_BWD_LDS_MIN"); return e ? atoi(e) : GT_ATTN_BWD_LDS_MIN; }();
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (in16) {                                        // precision = 2: q / k / v / dctx stored in bf16 alone, widened on their way into LDS
+    a.q16 = reinterpret_cast<const uint16_t*>(q); a.k16 = a.q16 + (k - q); a.v16 = a.q16 + (v - q); a.dctx16 = reinterpret_cast<const uint16_t*>(dctx);
+    a.q = a.k = a.v = nullptr; a.dctx = nullptr;
+    need16(((ldq | ldkv | lddq | lddkv | x.d) & 3) == 0 && (attn_mfma_hd(x) == 64 || attn_mfma_hd(x) == 128), "attention backward over bf16-stored operands (precision 2)");
+    if (attn_mfma_hd(x) == 128) gt_launch(attn_bwd_lds_kernel<128, 4, true>, grid, dim3(512), x.s, a);
+    else if ((int)grid.x < GT_ATTN_CS_MAX_PAIRS) gt_launch(attn_bwd_lds_kernel<64, 4, true>, grid, dim3(512), x.s, a);
+    else gt_launch(attn_bwd_lds_kernel<64, 1, true>, grid, dim3(128), x.s, a);
+    return;
+  }
   const bool lds_ok = ((ldq | ldkv | lddq | lddkv | x.d) & 3) == 0 && al16(q) && al16(k) && al16(v) && al16(dctx) && al16(dq) && al16(dk) && al16(dv);
   if (attn_mfma_hd(x) == 64 && (int)grid.x >= lds_min && lds_ok) {
     gt_launch(attn_bwd_lds_kernel<64>, grid, dim3(128), x.s, a);
@@ -919,9 +976,10 @@ static int ffn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* 
 static int self_attn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int causal, int gl) {
   float* ws = x.ws;
   const int d = x.d;
-  linear_fwd(x, xin, d, x.prm + p.sa.in_w, x.prm + p.sa.in_b, ws + w.qkv, 3 * d, 3 * d, d);
+  const bool s16 = p2(x.c) && gl < x.c.n_enc_layers;          // precision = 2: qkv in bf16 alone (the first half of its buffer)
+  linear_fwd(x, xin, d, x.prm + p.sa.in_w, x.prm + p.sa.in_b, ws + w.qkv, 3 * d, 3 * d, d, s16 ? reinterpret_cast<uint16_t*>(ws + w.qkv) : nullptr);
   attention_fwd(x, ws + w.qkv, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.P, ws + w.ctx, causal,
-                lsite(gl, GT_SITE_ATTN));
+                lsite(gl, GT_SITE_ATTN), s16);
   return linear_res_ln(x, ws + w.ctx, d, p.sa.out_w, p.sa.out_b, xin, p.n1w, ws + w.x1, ws + w.xhat1, ws + w.rstd1,
                        lsite(gl, GT_SITE_DROP1));
 }
@@ -1169,7 +1227,7 @@ static void step_linear_res_ln(const Ctx& x, int B, const float* in, int ldin, i
                                int64_t gamma_off, float* out, float* xhat, float* rstd) {
   step_linear(x, B, in, ldin, x.prm + w_off, x.prm + b_off, out, x.d, x.d, K);
   gt_launch(ln_fwd_kernel, dim3((B + 3) / 4), dim3(256), x.s, (const float*)out, res, no_drop(), x.prm + gamma_off,
-            x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, B, x.d, 32 * x.d, 32 * x.d, 32 * x.d, (uint16_t*)nullptr);
+            x.prm + gamma_off + (x.d + 63) / 64 * 64, out, xhat, rstd, B, x.d, 32 * x.d, 32 * x.d, 32 * x.d, (uint16_t*)nullptr, (const uint16_t*)nullptr);
 }
 static void step_attention(const Ctx& x, int B, const float* q, int ldq, const float* k, const float* v, int ldkv, float* ctx, int nkeys) {
   AttnArgs a;
@@ -1208,7 +1266,7 @@ static void decoder_step(const Ctx& x, const float* pe, const float* tgt, int t,
     cur = ws + w.xout;
   }
   gt_launch(ln_fwd_kernel, dim3((B + 3) / 4), dim3(256), x.s, cur + r * d, (const float*)nullptr, no_drop(), x.prm + x.P.decn_w,
-            x.prm + x.P.decn_b, ws + x.W.dec_final + r * d, ws + x.W.dec_xhat, ws + x.W.dec_rstd, B, d, 32 * d, 32 * d, 32 * d, (uint16_t*)nullptr);
+            x.prm + x.P.decn_b, ws + x.W.dec_final + r * d, ws + x.W.dec_xhat, ws + x.W.dec_rstd, B, d, 32 * d, 32 * d, 32 * d, (uint16_t*)nullptr, (const uint16_t*)nullptr);
   GemmArgs g = mk_gemm(ws + x.W.dec_final + r * d, 32 * d, x.prm + x.P.out_w, d, hvo_tmp + r * GT_TGT, 32 * GT_TGT, B, GT_TGT, d);
   g.bias = x.prm + x.P.out_b;
   gemm_launch<false, false, EPI_HEADS>(g, x.s);
@@ -1282,9 +1340,10 @@ static void self_attn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const 
   float* ws = x.ws;
   const int d = x.d;
   wgrad(x, dz1m, d, ws + w.ctx, d, x.grd + p.sa.out_w, x.grd + p.sa.out_b, d, d);
-  dgrad_store(x, dz1m, d, x.prm + p.sa.out_w, d, ws + x.W.dctx, d, d, 0);
+  const bool s16 = p2(x.c) && gl < x.c.n_enc_layers;          // precision = 2: dctx in bf16 alone (the first half of its buffer), like qkv
+  dgrad_store(x, dz1m, d, x.prm + p.sa.out_w, d, ws + x.W.dctx, d, d, 0, s16 ? reinterpret_cast<uint16_t*>(ws + x.W.dctx) : nullptr);
   attention_bwd(x, ws + w.qkv, 3 * d, ws + w.qkv + d, ws + w.qkv + 2 * d, 3 * d, ws + w.P, ws + x.W.dctx, t.dqkv, 3 * d,
-                t.dqkv + d, t.dqkv + 2 * d, 3 * d, lsite(gl, GT_SITE_ATTN));
+                t.dqkv + d, t.dqkv + 2 * d, 3 * d, lsite(gl, GT_SITE_ATTN), s16);
   wgrad(x, t.dqkv, 3 * d, xin, d, x.grd + p.sa.in_w, x.grd + p.sa.in_b, 3 * d, d);
 }
 // grad of the InputLayer: da = (dqkv Win + dz1) * dropmask * (a0 > 0) -> da_out; dW = da^T in; db = colsum(da)
@@ -1655,7 +1714,8 @@ extern "C" int gt_optimizer_step_ws(const gt_config* cfg, int algo, float* param
   PLayout P = param_layout(*cfg);
   if (!use_seq(*cfg) || !zero_grads || !ws) {
     const WLayout W0 = ws ? ws_layout(*cfg) : WLayout();
-    const unsigned* err = (ws && W0.rowx >= 0) ? reinterpret_cast<const unsigned*>(ws + W0.rowx) : nullptr;      // (the row exchange's error word)
+    const int64_t eo = W0.rowx >= 0 ? W0.rowx : W0.seq_xchg;                                                  // (the error word of whichever exchange region the shape has)
+    const unsigned* err = (ws && eo >= 0) ? reinterpret_cast<const unsigned*>(ws + eo) : nullptr;
     return optimizer_step_impl(algo, params, grads, m, v, P.total, state, zero_grads, stream, 0, err);
   }
   if (!params || !grads || !state) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
@@ -1727,8 +1787,9 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
       gt_seq_launch_update_pack(a, algo, params, grads, m, v, P.total, state, 1, (hipStream_t)stream);
       return launch_status("gt_train_step");
     }
+    const int64_t eo = W.rowx >= 0 ? W.rowx : W.seq_xchg;
     if (optimizer_step_impl(algo, params, grads, m, v, P.total, state, 1, stream, 1,
-                            W.rowx >= 0 ? reinterpret_cast<const unsigned*>(ws + W.rowx) : nullptr)) return -1;
+                            eo >= 0 ? reinterpret_cast<const unsigned*>(ws + eo) : nullptr)) return -1;
   }
   return 0;
 }

@@ -30,6 +30,10 @@ struct AttnArgs {
   // bf16 copies for the GEMMs that take these outputs as operands at precision = 1 (GemmArgs::A16; the MFMA kernels only):
   // ctx16 (M, d) beside ctx; dqkv16 (M, 3 d) = [dq | dk | dv] beside a dqkv buffer the three gradients are written into.  nullptr: none
   uint16_t* ctx16; uint16_t* dqkv16;
+  // precision = 2: q / k / v (and, backward, dctx) stored in bf16 ALONE -- same strides (in elements) as the fp32 pointers, which are then
+  // unused.  Only the LDS-staged kernels (attn_fwd_lds_kernel / attn_bwd_lds_kernel) take them: the tiles are widened on their way into LDS
+  // and the arithmetic is the fp32 one.
+  const uint16_t* q16; const uint16_t* k16; const uint16_t* v16; const uint16_t* dctx16;
 };
 
 __device__ static inline void attn_load_slab(float (*s)[33], const float* src, int ld, int b, int h, int hd, int c0, int tid, const float* zp) {
@@ -205,16 +209,23 @@ __device__ __forceinline__ float attn_ld1(const float* p, int col, int hd, const
 }
 // (body: one (sequence, head) pair `bh`, query tile `ti` (0 / 1) per wave -- the stand-alone kernel runs it with 2 waves per
 //  workgroup; gt_seq.h carries the same scheme on LDS operands for the sequence-resident kernels)
+// operands of one (sequence, head): row 0 / first column of the head, in global memory or staged in LDS (the *_lds kernels)
+struct AttnOps { const float* q; const float* k; const float* v; const float* dctx; int ldq, ldk, ldv, lddc; };
+__device__ __forceinline__ AttnOps attn_ops_global(const AttnArgs& a, const int bh, const int hdr) {
+  const size_t row0 = (size_t)(bh / a.H) * 32;
+  const int hc = (bh % a.H) * hdr;
+  return AttnOps{a.q + row0 * a.ldq + hc, a.k + row0 * a.ldk + hc, a.v + row0 * a.ldv + hc, a.dctx ? a.dctx + row0 * a.lddc + hc : nullptr, a.ldq, a.ldk, a.ldv, a.lddc};
+}
 template <int HD, bool PAD>
-__device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const int bh, const int ti, const int lane) {
+__device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const AttnOps& op, const int bh, const int ti, const int lane) {
   constexpr int NQ = HD / 16;
   const int hdr = PAD ? a.hd : HD;               // real head_dim (PAD: < 16, operands zero-padded to 16 columns)
   const float* const zp = gt_zero_ptr();
   const int l16 = lane & 15, g = lane >> 4;
   const int b = bh / a.H, h = bh % a.H;
   const int i = 16 * ti + l16;                                   // this lane's query row
-  const float* qrow = a.q + (size_t)(b * 32 + i) * a.ldq + h * hdr + 4 * g;
-  const float* krow = a.k + (size_t)(b * 32 + l16) * a.ldk + h * hdr + 4 * g;      // key tile 0; tile 1 = + 16 rows
+  const float* qrow = op.q + (size_t)i * op.ldq + 4 * g;
+  const float* krow = op.k + (size_t)l16 * op.ldk + 4 * g;      // key tile 0; tile 1 = + 16 rows
   // Every operand of the kernel is requested up front (Q, K fragments and all of V: 40 registers at head_dim 32, 160 at
   // 128) so the loads are all in flight together; issued tile by tile each one would cost its own memory round trip.
   f32x4 st[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};           // S^T tiles [tj]
@@ -223,16 +234,16 @@ __device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const int 
   for (int q = 0; q < NQ; ++q) {
     qf[q] = attn_ld4<PAD>(qrow + 16 * q, 16 * q + 4 * g, hdr, zp);
     k0[q] = attn_ld4<PAD>(krow + 16 * q, 16 * q + 4 * g, hdr, zp);
-    k1[q] = attn_ld4<PAD>(krow + (size_t)16 * a.ldk + 16 * q, 16 * q + 4 * g, hdr, zp);
+    k1[q] = attn_ld4<PAD>(krow + (size_t)16 * op.ldk + 16 * q, 16 * q + 4 * g, hdr, zp);
   }
-  const float* __restrict__ vcol = a.v + (size_t)(b * 32 + 4 * g) * a.ldv + h * hdr + l16;     // V[4g + c + 16 tj][16 ct + l16]
+  const float* __restrict__ vcol = op.v + (size_t)(4 * g) * op.ldv + l16;     // V[4g + c + 16 tj][16 ct + l16]
   float vb[NQ][2][4];
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) vb[ct][tj][c] = attn_ld1<PAD>(vcol + (size_t)(16 * tj + c) * a.ldv + 16 * ct, 16 * ct + l16, hdr, zp);
+      for (int c = 0; c < 4; ++c) vb[ct][tj][c] = attn_ld1<PAD>(vcol + (size_t)(16 * tj + c) * op.ldv + 16 * ct, 16 * ct + l16, hdr, zp);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     st[0] = GT_MFMA16(k0[q].x, qf[q].x, st[0]); st[1] = GT_MFMA16(k1[q].x, qf[q].x, st[1]);
@@ -299,7 +310,46 @@ __device__ __forceinline__ void attn_fwd_mfma_body(const AttnArgs& a, const int 
 
 template <int HD, bool PAD>
 __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
-  attn_fwd_mfma_body<HD, PAD>(a, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63);
+  attn_fwd_mfma_body<HD, PAD>(a, attn_ops_global(a, blockIdx.x, PAD ? a.hd : HD), blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63);
+}
+// 32 x HD tile of one (sequence, head) into LDS (row stride HD + 4), from fp32 or -- IN16 -- from bf16 rows (8-byte loads of four elements,
+// widened: a bf16 value is the upper half of its fp32 neighbour): every global byte requested once, all loads of a thread in flight together
+template <int HD, int NT, bool IN16>
+__device__ __forceinline__ void attn_stage_tile(float* dst, const float* src, const uint16_t* src16, const size_t row0, const int ld, const int hc, const int tid) {
+  constexpr int LD = HD + 4, Q4 = HD / 4, PER = 32 * Q4 / NT;
+  static_assert(32 * Q4 % NT == 0, "staging passes");
+  float4 r[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = tid + NT * u, rr = e / Q4, c = (e % Q4) * 4;
+    if (IN16) {
+      const uint2 w = *reinterpret_cast<const uint2*>(src16 + (row0 + rr) * (size_t)ld + hc + c);
+      r[u] = make_float4(gt_u2f(w.x << 16), gt_u2f(w.x & 0xFFFF0000u), gt_u2f(w.y << 16), gt_u2f(w.y & 0xFFFF0000u));
+    } else {
+      r[u] = *reinterpret_cast<const float4*>(src + (row0 + rr) * (size_t)ld + hc + c);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = tid + NT * u;
+    *reinterpret_cast<float4*>(dst + (e / Q4) * LD + (e % Q4) * 4) = r[u];
+  }
+}
+// precision = 2: the forward with q / k / v staged in LDS from their bf16 storage (the register form above would read every bf16 row
+// fragment 2-4 bytes at a time); the body is the same, on LDS operands
+template <int HD, bool IN16>
+__global__ __launch_bounds__(128) void attn_fwd_lds_kernel(AttnArgs a) {
+  constexpr int LD = HD + 4;
+  __shared__ __attribute__((aligned(16))) float sm[3 * 32 * LD];
+  const int tid = threadIdx.x, bh = blockIdx.x;
+  const size_t row0 = (size_t)(bh / a.H) * 32;
+  const int hc = (bh % a.H) * HD;
+  attn_stage_tile<HD, 128, IN16>(sm, a.q, a.q16, row0, a.ldq, hc, tid);
+  attn_stage_tile<HD, 128, IN16>(sm + 32 * LD, a.k, a.k16, row0, a.ldk, hc, tid);
+  attn_stage_tile<HD, 128, IN16>(sm + 64 * LD, a.v, a.v16, row0, a.ldv, hc, tid);
+  __syncthreads();
+  const AttnOps op{sm, sm + 32 * LD, sm + 64 * LD, nullptr, LD, LD, LD, LD};
+  attn_fwd_mfma_body<HD, false>(a, op, bh, tid >> 6, tid & 63);
 }
 
 // Backward.  Each wave plays two roles, because dq contracts over keys and dk / dv contract over queries:
@@ -308,13 +358,6 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(AttnArgs a) {
 //   role 2 (key tile w, S layout: lane holds X[i = 16 ti + 4g + r][j = l16]): dPd = dO V^T, P reloaded in this layout,
 //           (P*mask) and dS are then the A operands (A[m = j][k = i]) of  dv = (P*mask)^T dO  and  dk = dS^T q.
 // (two bodies with a workgroup barrier between them -- srd, 32 floats of LDS per (sequence, head), carries the row sums)
-// operands of one (sequence, head): row 0 / first column of the head, in global memory or staged in LDS (attn_bwd_lds_kernel)
-struct AttnOps { const float* q; const float* k; const float* v; const float* dctx; int ldq, ldk, ldv, lddc; };
-__device__ __forceinline__ AttnOps attn_ops_global(const AttnArgs& a, const int bh, const int hdr) {
-  const size_t row0 = (size_t)(bh / a.H) * 32;
-  const int hc = (bh % a.H) * hdr;
-  return AttnOps{a.q + row0 * a.ldq + hc, a.k + row0 * a.ldk + hc, a.v + row0 * a.ldv + hc, a.dctx + row0 * a.lddc + hc, a.ldq, a.ldk, a.ldv, a.lddc};
-}
 template <int HD, bool PAD, int CS = 1>
 __device__ __forceinline__ void attn_bwd_mfma_role1(const AttnArgs& a, const AttnOps& op, const int bh, const int w, const int lane, float* srd,
                                                     f32x4 (&dq_out)[HD / 16 / CS], const int cs = 0) {
@@ -510,13 +553,21 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a) {
 // through the same LDS tiles as full 256-byte row segments.
 // CS > 1 (few (sequence, head) pairs, wide heads): 2 CS waves per pair -- every wave pair repeats the dP contraction of its query / key tile
 // from LDS and takes 1 / CS of the head's column tiles (role bodies above); the staging loads and the row stores spread over all of them.
-template <int HD, int CS = 1>
+template <int HD, int CS = 1, bool IN16 = false>
 __global__ __launch_bounds__(128 * CS) void attn_bwd_lds_kernel(AttnArgs a) {
   constexpr int NT = 128 * CS, LD = HD + 4, Q4 = HD / 4, PER = 32 * Q4 / NT, NC = HD / 16 / CS;
   static_assert(32 * Q4 % NT == 0, "staging passes");
   __shared__ __attribute__((aligned(16))) float sm[4 * 32 * LD];
   __shared__ float srd[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = wave & 1, cs = wave >> 1, bh = blockIdx.x;
+  if constexpr (IN16) {                                          // precision = 2: q / k / v / dctx stored in bf16 alone
+    const size_t r0 = (size_t)(bh / a.H) * 32;
+    const int hc0 = (bh % a.H) * HD;
+    attn_stage_tile<HD, NT, true>(sm, nullptr, a.q16, r0, a.ldq, hc0, tid);
+    attn_stage_tile<HD, NT, true>(sm + 32 * LD, nullptr, a.k16, r0, a.ldk, hc0, tid);
+    attn_stage_tile<HD, NT, true>(sm + 64 * LD, nullptr, a.v16, r0, a.ldv, hc0, tid);
+    attn_stage_tile<HD, NT, true>(sm + 96 * LD, nullptr, a.dctx16, r0, a.lddc, hc0, tid);
+  } else {
   const AttnOps og = attn_ops_global(a, bh, HD);
   float4 rq[PER], rk[PER], rv[PER], rd[PER];
 #pragma unroll
@@ -534,6 +585,7 @@ __global__ __launch_bounds__(128 * CS) void attn_bwd_lds_kernel(AttnArgs a) {
     *reinterpret_cast<float4*>(sm + 32 * LD + o) = rk[u];
     *reinterpret_cast<float4*>(sm + 64 * LD + o) = rv[u];
     *reinterpret_cast<float4*>(sm + 96 * LD + o) = rd[u];
+  }
   }
   __syncthreads();
   const AttnOps op{sm, sm + 32 * LD, sm + 64 * LD, sm + 96 * LD, LD, LD, LD, LD};

@@ -936,6 +936,16 @@ static inline bool gemm64_range(long t64, bool h) {
   static const long lo = gt_env_long("GT_T64R_MIN", GT_T64R_MIN), hi = gt_env_long("GT_T64R_MAX", GT_T64R_MAX), hih = gt_env_long("GT_T64H_MAX", GT_T64H_MAX);
   return t64 >= lo && t64 <= (h ? hih : hi);
 }
+// will gemm_launch put this problem on a kernel with the shared store epilogue of gt_gemm32.h (the only ones that write a bf16 output, C16,
+// and can leave the fp32 one out)?  Mirrors the rules below.
+template <bool BKM, int EPI>
+static inline bool gemm_on_big_kernel(const GemmArgs& g) {
+  const long b64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  if (g.bf16 && gemm64_range(b64, true) && gemm64h_ok(g, EPI)) return true;
+  if (!(g.bf16 && g.A16 && g.B16) && gemm64_range(b64, false) && gemm64_ok(g, EPI)) return true;
+  if (g.bf16 && b128 >= GT_T128H_MIN && gemm32h_ok(g, EPI)) return true;
+  return b128 >= GT_T128_BIG_MIN && gemm32_ok(g, EPI, BKM);
+}
 // standard (non-row) epilogues: pick the tile by how many workgroups the problem yields
 template <bool AKM, bool BKM, int EPI>
 static inline void gemm_launch(GemmArgs g, hipStream_t s) {

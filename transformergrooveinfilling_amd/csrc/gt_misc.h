@@ -15,8 +15,11 @@
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float* __restrict__ res, DropArgs drop,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* y,
                                                      float* __restrict__ xhat, float* __restrict__ rstd_out, int M, int N,
-                                                     int ldx, int ldres, int ldy, uint16_t* __restrict__ y16 = nullptr) {
+                                                     int ldx, int ldres, int ldy, uint16_t* __restrict__ y16 = nullptr,
+                                                     const uint16_t* x16 = nullptr) {
   // y16: a bf16 copy of y (dense rows of N), for the GEMM that takes y as its operand at precision = 1 (GemmArgs::A16)
+  // x16 (precision = 2): the Linear output ahead of this norm, stored in bf16 alone (dense rows of N; may be the y16 region: a row is read
+  // into registers before any of it is written)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* const zp = gt_zero_ptr();
@@ -27,10 +30,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
   for (int i = 0; i < GT_MAX_D / 64; ++i) {            // all loads first, branch-free (address select)
     const int c = lane + 64 * i;
     const bool ok = c < N;
-    z[i] = *(ok ? x + (size_t)row * ldx + c : zp);
     r[i] = *((ok && res != nullptr) ? res + (size_t)row * ldres + c : zp);
     ga[i] = *(ok ? gamma + c : zp);
     be[i] = *(ok ? beta + c : zp);
+  }
+  if (x16 != nullptr) {                                // (one uniform branch around ALL the loads: a select per element would serialise them)
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      z[i] = gt_bf2f(*(c < N ? x16 + (size_t)row * N + c : reinterpret_cast<const uint16_t*>(zp)));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      z[i] = *(c < N ? x + (size_t)row * ldx + c : zp);
+    }
   }
   float s = 0.f;
 #pragma unroll
@@ -137,8 +152,10 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* dy, const float* __restrict__ res, const float* __restrict__ xhat,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                         float* dz, float* __restrict__ dz_masked, DropArgs drop,
-                                                        float* __restrict__ part, int M, int rows_per_wave, uint16_t* __restrict__ dzm16 = nullptr) {
+                                                        float* __restrict__ part, int M, int rows_per_wave, uint16_t* __restrict__ dzm16 = nullptr,
+                                                        const uint16_t* dy16 = nullptr) {
   // dzm16: a bf16 copy of the tensor the next dgrad / weight gradient takes as its operand (dz_masked, or dz when there is no mask)
+  // dy16 (precision = 2): the dgrad output ahead of this backward, stored in bf16 alone (may be the dzm16 region: read before written)
   constexpr int N = 256 * NV;
   __shared__ float sred[4][2][N];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -157,9 +174,16 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* dy, const f
     const size_t base = (size_t)row * N + 4 * lane;
     float4 d[NV], xh[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {                   // all loads first
-      d[i] = *reinterpret_cast<const float4*>(dy + base + 256 * i);
-      xh[i] = *reinterpret_cast<const float4*>(xhat + base + 256 * i);
+    for (int i = 0; i < NV; ++i) xh[i] = *reinterpret_cast<const float4*>(xhat + base + 256 * i);      // all loads first
+    if (dy16 != nullptr) {                             // (one uniform branch around the loads of d)
+      uint2 w2[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) w2[i] = *reinterpret_cast<const uint2*>(dy16 + base + 256 * i);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) d[i] = make_float4(gt_u2f(w2[i].x << 16), gt_u2f(w2[i].x & 0xFFFF0000u), gt_u2f(w2[i].y << 16), gt_u2f(w2[i].y & 0xFFFF0000u));
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) d[i] = *reinterpret_cast<const float4*>(dy + base + 256 * i);
     }
     if (res != nullptr) {
 #pragma unroll
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(256) void ln_fwd2_kernel(const float* x, const floa
                                                       float* __restrict__ xhat1, float* __restrict__ rstd1,
                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2,
                                                       float* __restrict__ y2, float* __restrict__ xhat2, float* __restrict__ rstd2,
-                                                      int M, int N) {
+                                                      int M, int N, const uint16_t* x16 = nullptr) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* const zp = gt_zero_ptr();
@@ -229,10 +253,22 @@ __global__ __launch_bounds__(256) void ln_fwd2_kernel(const float* x, const floa
   for (int i = 0; i < GT_MAX_D / 64; ++i) {            // all loads first, branch-free (address select)
     const int c = lane + 64 * i;
     const bool ok = c < N;
-    z[i] = *(ok ? x + (size_t)row * N + c : zp);
     r[i] = *((ok && res != nullptr) ? res + (size_t)row * N + c : zp);
     ga[i] = *(ok ? gamma1 + c : zp); be[i] = *(ok ? beta1 + c : zp);
     gb[i] = *(ok ? gamma2 + c : zp); bb[i] = *(ok ? beta2 + c : zp);
+  }
+  if (x16 != nullptr) {
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      z[i] = gt_bf2f(*(c < N ? x16 + (size_t)row * N + c : reinterpret_cast<const uint16_t*>(zp)));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < GT_MAX_D / 64; ++i) {
+      const int c = lane + 64 * i;
+      z[i] = *(c < N ? x + (size_t)row * N + c : zp);
+    }
   }
   float s = 0.f;
 #pragma unroll
