@@ -682,7 +682,8 @@ static bool ln_xchg_launch(const Ctx& x, const GemmArgs& g, bool in_only16) {
   return true;
 }
 static bool row_fused(const Ctx& x) {
-  return !x.c.precision && (x.d <= GT_ROW_FUSE_MAX_D || (x.M >= GT_ROW_FUSE_MIN_M && x.d <= GT_ROW_FUSE_BIG_MAX_D));
+  static const int big_max_d = [] { const char* e = getenv("GT_ROW_FUSE_BIG_MAX_D"); return e ? atoi(e) : GT_ROW_FUSE_BIG_MAX_D; }();     // (A/B switch)
+  return !x.c.precision && (x.d <= GT_ROW_FUSE_MAX_D || (x.M >= GT_ROW_FUSE_MIN_M && x.d <= big_max_d));
 }
 static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float* xhat, const float* rstd, int64_t gamma_off, float* dz,
                    float* dzm, int site, const uint16_t* dy16 = nullptr);
@@ -1573,7 +1574,10 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   }
   // ws.dctx now holds the grad w.r.t. the last layer's output (the input of the final norm) unless top_norm_done
   if (Ld > 0) {
-    (void)hipMemsetAsync(ws + W.dmem, 0, (size_t)M * d * sizeof(float), x.s);
+    // (ws.dmem, the memory gradient, is the SUM of the decoder layers' cross-attention k / v dgrads: the first one processed stores, the
+    //  others add.  Round 5: it used to be zeroed by a hipMemsetAsync here -- a memset NODE inside the step's captured graph -- and the
+    //  encoder-decoder step then went non-finite intermittently when replays were separated by a host synchronisation (C3, and already
+    //  the L1+1 model: 2 of 3 processes; never eagerly, never without the decoder): the only memset node of the fused step is gone.)
     if (!top_norm_done) {
       const LayerW& w = W.layers[top];
       Tmp t = tmp_set(x, top);
@@ -1595,7 +1599,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
                     lsite(gl, GT_SITE_XATTN));
       wgrad(x, dqx, d, ws + w.x1, d, grads + p.xa.in_w, grads + p.xa.in_b, d, d);
       wgrad(x, dkvx, 2 * d, ws + W.memory, d, grads + p.xa.in_w + (int64_t)d * d, grads + p.xa.in_b + d, 2 * d, d);
-      dgrad_store(x, dkvx, 2 * d, params + p.xa.in_w + (int64_t)d * d, d, ws + W.dmem, d, 2 * d, 1);
+      dgrad_store(x, dkvx, 2 * d, params + p.xa.in_w + (int64_t)d * d, d, ws + W.dmem, d, 2 * d, l == Ld - 1 ? 0 : 1);
       // dz1 = LNbwd_norm1(dqx Wq + dz2) -> (dzC, dzCm) masked for the self-attn out-proj
       if (dgrad_lnbwd(x, dqx, d, params + p.xa.in_w, d, t.dzB, ws + w.xhat1, ws + w.rstd1, p.n1w, t.dzC, t.dzCm, lsite(gl, GT_SITE_DROP1)))
         return -1;

@@ -929,7 +929,9 @@ static inline void gemm64h_launch(const GemmArgs& g, hipStream_t s);
 #define GT_T64R_MAX 2047        /* 64x64 tiles; from 512 tiles of 128x128 the big tile (half the operand bytes per flop) has two full rounds */
 #endif
 #ifndef GT_T64H_MAX
-#define GT_T64H_MAX 2047
+#define GT_T64H_MAX 767         /* both operands bf16: 64x64 tiles only below 192 tiles of 128x128 (measured, gemm_bench: M 2048 N 512 6.2 vs 10.4 us, M 8192
+                                   N 256 7.7 vs 8.6 -- but M 2048 N 1536 12.9 vs 11.7, M 8192 N 768 18.6 vs 13.7, M 16384 N 512 29 vs 18.6: at the bf16 MFMA rate
+                                   the 64x64 tile's doubled operand bytes per flop bind as soon as the big tile has a round of its own) */
 #endif
 static inline long gt_env_long(const char* name, long dflt) { const char* e = getenv(name); return (e && e[0]) ? atol(e) : dflt; }
 static inline bool gemm64_range(long t64, bool h) {
