@@ -46,9 +46,23 @@ def klass(name):
             return EPI.get(epi) or ("gemm_dgrad" if bkm else "gemm_fwd_bias")
         except (ValueError, IndexError):
             return "gemm"
-    m = re.match(r"void gemm32h_kernel<(\d+)>", name)          # bf16-source big-tile kernel: NT for forward AND dgrad (the transposed weight copy)
+    m = re.match(r"void (gemm32h_kernel|gemm64h_kernel)<(\d+)>", name)          # bf16-source kernels: NT for forward AND dgrad (the transposed weight copy)
     if m:
-        return EPI.get(int(m.group(1))) or "gemm_fwd_bias"      # (EPI 0 = the plain store: forward Linears and dgrads share the kernel)
+        return EPI.get(int(m.group(2))) or "gemm_fwd_bias"      # (EPI 0 = the plain store: forward Linears and dgrads share the kernel)
+    m = re.match(r"void gemm64_kernel<(.*?)>", name)            # gemm64_kernel<BKM, EPI, PREC>
+    if m:
+        a = [x.strip() for x in m.group(1).split(",")]
+        try:
+            return EPI.get(int(a[1])) or ("gemm_dgrad" if a[0] == "true" else "gemm_fwd_bias")
+        except (ValueError, IndexError):
+            return "gemm"
+    m = re.match(r"void gemm32row_kernel<(.*?)>", name)         # gemm32row_kernel<BN, BMW, BKM, EPI>: the LayerNorm-fused row tiles
+    if m:
+        a = [x.strip() for x in m.group(1).split(",")]
+        try:
+            return EPI.get(int(a[3])) or "gemm"
+        except (ValueError, IndexError):
+            return "gemm"
     if "wgrad32t_group_kernel" in name:
         return "gemm_wgrad"
     for k, v in PLAIN:
@@ -130,6 +144,11 @@ def main():
         rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
     except Exception:
         rev = None
+    if not rev:          # (the GPU box gets the tree without .git: tools/gpu_final_r05.sh stamps the revision into this file before it ships)
+        try:
+            rev = open(os.path.join(ROOT, "tools", ".git_rev")).read().strip() or None
+        except OSError:
+            rev = None
     stats = find(os.path.join(base, "trace"), "*kernel_stats.csv")
     trace = find(os.path.join(base, "trace"), "*kernel_trace.csv")
     if stats:

@@ -1743,6 +1743,8 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   if (skip_update < 0 || skip_update > 7) return gt_fail("gt_train_step: skip_update %d outside 0..7", skip_update);
   const bool packs_current = (skip_update & GT_STEP_PACKS_CURRENT) != 0;
   skip_update &= 3;
+  // the hand-offs to the sequence-resident forward / backward travel in thread-locals: whatever path leaves this function, they are cleared
+  struct Handoffs { ~Handoffs() { g_seq_loss.y = nullptr; g_seq_packs_current = false; g_seq_b0_fused = false; } } handoffs_guard;
   const int M = cfg->batch * 32;
   hipStream_t s = (hipStream_t)stream;
   const float* tgt_in = nullptr;

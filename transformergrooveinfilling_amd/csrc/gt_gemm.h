@@ -775,6 +775,14 @@ static inline void gemm_launch_cfg(const GemmArgs& g, int splitk, hipStream_t s)
 // Deterministic mode (gt_set_deterministic / GT_DETERMINISTIC=1): ONE workgroup per output tile walks all tokens, so every
 // gradient element (and bias-gradient element) has exactly one contributor and the fp32 atomics add onto a known value in a fixed
 // order -- gradients, and with them the whole training run, repeat bit for bit.  Costs the small shapes their token parallelism.
+#ifndef GT_WGRAD128_MIN_CHUNK
+#define GT_WGRAD128_MIN_CHUNK 512
+#endif
+#ifndef GT_WGRAD128H_MIN_CHUNK
+#define GT_WGRAD128H_MIN_CHUNK 1024     /* bf16 operands: measured at 2048 tokens (C5 bs 64): chunks >= 512 / 1024 / 2048 -> 0.958 / 0.946 / 0.984 ms (precision 2:
+                                           0.952 / 0.927 / 0.968); fp32 (C4 bs 64): 1.494 / 1.508 / 1.572 -- stays at 512 */
+#endif
+static inline long gt_env_long(const char* name, long dflt);
 static int g_deterministic = -1;
 static inline bool gt_deterministic() {
   if (g_deterministic < 0) { const char* e = getenv("GT_DETERMINISTIC"); g_deterministic = (e && e[0] == '1') ? 1 : 0; }
@@ -784,7 +792,10 @@ static inline int wgrad_split(GemmArgs& g, long target, int tile = 32) {
   if (gt_deterministic()) target = 1;
   const long tiles = (long)((g.M + tile - 1) / tile) * ((g.N + tile - 1) / tile);
   long want = (target + tiles - 1) / tiles;
-  const long maxs = tile >= 128 ? (g.K + 511) / 512 : tile >= 64 ? (g.K + 255) / 256 : (g.K + 127) / 128;
+  // (128x128 tiles: token chunks of at least GT_WGRAD128_MIN_CHUNK -- every chunk ends in 64 KB of fp32 atomics per tile)
+  static const long c128 = gt_env_long("GT_WGRAD128_MIN_CHUNK", GT_WGRAD128_MIN_CHUNK), c128h = gt_env_long("GT_WGRAD128H_MIN_CHUNK", GT_WGRAD128H_MIN_CHUNK);
+  const long ch128 = g.bf16 ? c128h : c128;
+  const long maxs = tile >= 128 ? (g.K + ch128 - 1) / ch128 : tile >= 64 ? (g.K + 255) / 256 : (g.K + 127) / 128;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   int chunk = (int)((g.K + want - 1) / want);
@@ -923,7 +934,7 @@ static inline bool gemm64h_ok(const GemmArgs& g, int epi);
 template <bool BKM, int EPI>
 static inline void gemm64h_launch(const GemmArgs& g, hipStream_t s);
 #ifndef GT_T64R_MIN
-#define GT_T64R_MIN 192
+#define GT_T64R_MIN 256         /* one tile per CU at least (192 -- the QKV projection of the d_model-256 YAMLs at batch 32 -- measured 0.648 vs 0.642 ms per step) */
 #endif
 #ifndef GT_T64R_MAX
 #define GT_T64R_MAX 2047        /* 64x64 tiles; from 512 tiles of 128x128 the big tile (half the operand bytes per flop) has two full rounds */

@@ -332,7 +332,10 @@ class StepEngine:
         s = self.slot(self.B)
         two = len(self.lib.grad_buckets(s.cfg)) == 2
         cand = [(False, False)] + ([(True, False)] if two else [])
-        if not self.on_host:
+        # the one-hipGraph-per-step recipes (collectives recorded as graph nodes) join the comparison only on request (GT_DP_TUNE_GRAPH=1):
+        # they have run with a 1-rank RCCL group only, and a collective that HANGS under capture on real ranks -- unlike one that raises,
+        # which _dp_whole survives -- would take the whole run with it.  The eager recipes are the safe set for a first multi-GPU run.
+        if not self.on_host and os.environ.get("GT_DP_TUNE_GRAPH", "0") == "1":
             cand += [(False, True)] + ([(True, True)] if two else [])
         if modes is not None:
             cand = [c for c in cand if c in modes]
