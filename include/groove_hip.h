@@ -234,6 +234,9 @@ int gt_set_seq_quad(int on);
  * 27-float output bias; a data-parallel host writes its error flag there before the all-reduce) is non-zero, so every rank skips
  * together.  gt_set_xchg_spin_max: polls before giving up (<= 0: the default, 2^22 = seconds; tests lower it). */
 int gt_set_xchg_spin_max(int polls);
+/* Data-parallel hosts: grads[n_floats - 1] = 1 if this workspace's exchange error word is set, else 0 -- enqueue between the backward
+ * (gt_train_step(skip_update = 1 / 2)) and the gradient all-reduce; a no-op for shapes without an exchange region. */
+int gt_dp_guard(const gt_config* cfg, float* grads, const float* ws, gt_stream_t stream);
 /* LayerNorm inside the producing Linear / dgrad (csrc/gt_gemm64.h, round 5): at d_model 256 / 512, where the 64 x 64-tile kernels apply and
  * the whole grid is resident at once (a GPU's share of a data-parallel batch: 2048 tokens), the N / 64 workgroups of a row block exchange
  * their row partials inside the launch (tagged 8-byte granules, agent-scope stores / polling loads; "rowx" workspace region, zeroed once

@@ -70,6 +70,7 @@ _SIGS = {
     "gt_set_seq_split": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_seq_quad": (ctypes.c_int, [ctypes.c_int]),
     "gt_set_xchg_spin_max": (ctypes.c_int, [ctypes.c_int]),
+    "gt_dp_guard": (ctypes.c_int, [_cfgp, _vp, _vp, _vp]),
     "gt_set_ln_exchange": (ctypes.c_int, [ctypes.c_int]),
     "gt_debug_occupy_cus": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
     "gt_set_operand_shadows": (ctypes.c_int, [ctypes.c_int]),

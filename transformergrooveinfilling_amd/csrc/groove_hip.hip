@@ -1800,6 +1800,22 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   return 0;
 }
 
+// ------------------------------------------------------------------------------------ data-parallel guard element
+// grads[n_floats - 1] = (error word of this workspace's in-launch exchange region set ? 1 : 0): what a data-parallel host enqueues between the
+// backward and the gradient all-reduce, so that the flag rides the collective and every rank's update kernel skips together.  One tiny launch
+// (a no-op for shapes without such a region).
+__global__ __launch_bounds__(64) void dp_guard_kernel(float* guard, const unsigned* err) { if (threadIdx.x == 0) *guard = (*err != 0u) ? 1.0f : 0.0f; }
+extern "C" int gt_dp_guard(const gt_config* cfg, float* grads, const float* ws, gt_stream_t stream) {
+  if (check_cfg(cfg)) return -1;
+  if (!grads || !ws) return gt_fail("gt_dp_guard: grads / ws must not be NULL");
+  const WLayout W = ws_layout(*cfg);
+  const int64_t eo = W.rowx >= 0 ? W.rowx : W.seq_xchg;
+  if (eo < 0) return 0;
+  const PLayout P = param_layout(*cfg);
+  gt_launch(dp_guard_kernel, dim3(1), dim3(64), (hipStream_t)stream, grads + P.total - 1, reinterpret_cast<const unsigned*>(ws + eo));
+  return launch_status("gt_dp_guard");
+}
+
 // ------------------------------------------------------------------------------------ test aid: hold CUs
 // nblocks workgroups that each pin 96 KB of LDS (no 136 KB sequence workgroup fits beside one) and spin for `usec` microseconds of the
 // 100 MHz constant clock: a second stream's kernel (an RCCL collective, an evaluation predict) holding CUs while a four-workgroups-per-

@@ -627,11 +627,9 @@ class StepEngine:
     def _guard_fn(self, s):
         """Data-parallel: before the gradient all-reduce every rank writes its error flag into the guard element (the last float of the
         gradient buffer: padding behind the 27-float output bias); the update kernel of EVERY rank skips when the sum is non-zero."""
-        w = self._xchg_word(s)
-        if w is None:
+        if self._xchg_word(s) is None:
             return lambda: None
-        g = self.grads[self.total - 1:]
-        return lambda: g.copy_(w != 0)
+        return lambda: self.lib.call("gt_dp_guard", ctypes.byref(s.cfg), _ptr(self.grads), _ptr(s.ws), self.stream)      # (one 1-thread launch)
 
     def _recover_exchange(self, ws, cfg, what):
         self.exchange_timeouts += 1
