@@ -40,3 +40,9 @@ python tools/predict_bench.py > $O/predict.txt 2>&1
 bash tools/profile_rev.sh $TAG c2 c3 c4 c5 c4s c5s > $O/profile_rev.log 2>&1
 tail -3 $O/profile_rev.log
 cat $O/shapes.txt | tail -30
+# the bench lines again AFTER the PMC pass of this revision, so that roofline.traffic is this revision's own (bench.py refuses a traffic file of another csrc_sha)
+mkdir -p profiles && cp gpurun_out/profiles_$TAG/* profiles/ 2>/dev/null
+python bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
+python bench.py --steps 20 --warmup 5 > $O/bench_driver_style_full.json 2>/dev/null
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1
+tail -3 $O/pytest_gpu.txt

@@ -73,8 +73,9 @@ def build_parser():
     p.add_argument("--save-dir", default=None, help="where checkpoints go (default: wandb run dir or ./checkpoints)")
     p.add_argument("--override", action="append", default=[], metavar="KEY=VALUE", help="override a YAML key (bench shapes)")
     p.add_argument("--seed", default=0, type=int)
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                   help="bf16: the Linear GEMMs take bf16 operands on the matrix cores (fp32 accumulate, fp32 master weights; BASELINE configs[4])")
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "autocast"],
+                   help="bf16: the Linear GEMMs take bf16 operands on the matrix cores (fp32 accumulate, fp32 master weights; BASELINE configs[4]); "
+                        "autocast: ... and the encoder layers' Linear outputs are stored in bf16 (gt_config.precision = 2: what torch.autocast keeps in bf16)")
     p.add_argument("--deterministic", action="store_true",
                    help="bitwise-reproducible weight gradients (gt_set_deterministic: no token split in the weight-gradient kernels; +9-30 %% step time)")
     return p

@@ -152,7 +152,7 @@ def initialize_model(params):
                   dropout=mp["dropout"], embedding_size_src=mp["embedding_size_src"],
                   embedding_size_tgt=mp["embedding_size_tgt"], max_len=mp["max_len"], device=mp.get("device", "cuda"),
                   seed=int(params.get("seed", tp.get("seed", 0)) or 0),      # dropout stream (train.py --seed); rank mixed in by the model
-                  precision=mp.get("precision", "fp32"))                     # "bf16": GEMM operands in bf16 (BASELINE configs[4])
+                  precision=mp.get("precision", "fp32"))                     # "bf16": GEMM operands in bf16 (BASELINE configs[4]); "autocast": ... and bf16 storage of the Linear outputs (precision 2)
     if mp["encoder_only"]:
         model = GrooveTransformerEncoder(num_encoder_layers=mp["num_encoder_layers"], **common)
     else:
