@@ -240,8 +240,8 @@ int gt_dp_guard(const gt_config* cfg, float* grads, const float* ws, gt_stream_t
 /* LayerNorm inside the producing Linear / dgrad (csrc/gt_gemm64.h, round 5): at d_model 256 / 512, where the 64 x 64-tile kernels apply and
  * the whole grid is resident at once (a GPU's share of a data-parallel batch: 2048 tokens), the N / 64 workgroups of a row block exchange
  * their row partials inside the launch (tagged 8-byte granules, agent-scope stores / polling loads; "rowx" workspace region, zeroed once
- * by gt_workspace_init) and each normalises its own tile -- no row pass of its own.  OPT-IN: -1 = the environment (GT_LN_XCHG=1), default off; 1 = on; 0 = off -- measured at 2048 tokens it
- * costs what the separate row pass costs (csrc/groove_hip.hip, ln_xchg).  Same
+ * by gt_workspace_init) and each normalises its own tile -- no row pass of its own.  -1 = default (on where it applies: 3/4 .. 2 tiles of 64 x 64 per CU), 0 = off (env GT_LN_XCHG=0): the norm as a
+ * row pass of its own; 1-1.5 % of the step at 2048 tokens (csrc/groove_hip.hip, ln_xchg).  Same
  * bounded-spin / error-word / skipped-update contract as the pair exchange above ("xchg_err" names the word of whichever a shape has). */
 int gt_set_ln_exchange(int on);
 /* Test aid: nblocks workgroups that each pin 96 KB of LDS (no sequence workgroup fits beside one) for `usec` microseconds -- a second

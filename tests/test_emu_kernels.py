@@ -164,7 +164,7 @@ def test_tile64_ring_kernel():
 
 def test_layernorm_fused_into_the_64_tile_linears():
     """gt_gemm64.h, EPI_RES_LN / EPI_RES_LNBWD: the N / 64 workgroups of a row block exchange their row partials inside the launch
-    (opt-in, gt_set_ln_exchange(1)): forward (Chan-merged mean / M2) and backward (row sums, dgamma / dbeta partials) against the oracle, NT
+    (forced here on a small shape, gt_set_ln_exchange(1); the default from 3/4 tile per CU): forward (Chan-merged mean / M2) and backward (row sums, dgamma / dbeta partials) against the oracle, NT
     and NN, fp32 and bf16 fragments, N = 256 and 512; the emulator re-runs workgroups that find a partner's ready word missing."""
     from harness import emu_lib
     lib = emu_lib()

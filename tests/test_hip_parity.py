@@ -200,7 +200,7 @@ def test_precision2_train_step_and_autocast_anchor():
 
 
 def test_layernorm_row_exchange_of_the_64_tile_linears():
-    """opt-in (gt_set_ln_exchange(1)): LayerNorm forward / backward inside the producing Linear / dgrad at 2048 tokens, the 8 workgroups of a
+    """LayerNorm forward / backward inside the producing Linear / dgrad at 2048 tokens (the default there; forced on here so that the d_model-256 case takes it too), the 8 workgroups of a
     row block meeting through the in-launch row exchange (csrc/gt_gemm64.h) -- oracle parity at a GPU's share of configs[3] / [4], a train
     step, and the time-out path: a polling bound of one raises the error word and the update applies nothing."""
     import ctypes

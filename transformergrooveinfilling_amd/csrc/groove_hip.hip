@@ -653,20 +653,24 @@ static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, 
 #ifndef GT_ROW_FUSE_BIG_MAX_D
 #define GT_ROW_FUSE_BIG_MAX_D 256
 #endif
-// LayerNorm inside the producing Linear / dgrad on 64x64 tiles with the in-launch row exchange (gt_gemm64.h).  OPT-IN (GT_LN_XCHG=1 /
-// gt_set_ln_exchange(1); -1 = the environment, default off): parity-green, 22 launches fewer per step at d_model 512 -- and not faster.
-// Measured at 2048 tokens (round 5, A/B on one box): C4 bs 64 1.494 ms fused vs 1.494 separate, C5 bf16 bs 64 0.984 vs 0.968: the hand-off
-// (data, drain, ready word, poll, fetch: every hop an agent-scope round trip of ~1-2 us, plus the start skew of the 8 workgroups of a row
-// block) costs what the row pass of its own costs (5.3 us per Linear + LayerNorm launch at fp32, 8 us at bf16 against 5.8-6.2 us).  A
-// first version that polled tagged granules (16 scattered 8-byte loads per lane and round) cost 13 us per launch: 1.811 ms.
+// LayerNorm inside the producing Linear / dgrad on 64x64 tiles with the in-launch row exchange (gt_gemm64.h): -1 = wherever it applies (d_model 256 /
+// 512 outside the row-owning tiles, 3/4 .. 2 tiles of 64x64 per CU: the whole grid resident at once), 0 = off (GT_LN_XCHG=0 / gt_set_ln_exchange(0):
+// the norm as a row pass of its own).  22 launches fewer per step at d_model 512.  Measured at 2048 tokens (round 5, A/B on one box, two rounds): C4 bs 64
+// 1.488 / 1.492 -> 1.472 / 1.474 ms, C5 bf16 bs 64 0.944 / 0.936 -> 0.931 / 0.933, precision 2 0.929 / 0.932 -> 0.916 / 0.918 -- with the one-hop hand-off
+// (tagged granules, coalesced); the three-hop "data, drain, ready word" form was neutral (1.494 vs 1.494, bf16 0.984 vs 0.968), a first form with
+// per-row granules (16 scattered polls per lane) cost 13 us per launch (1.811 ms).  C3 (d_model 256, 8192 tokens) keeps its row-owning tiles: 5.18 ms
+// against 5.29 (64x64 tiles + row pass) and 5.44 (+ exchange).
 static int g_ln_xchg = -1;
 extern "C" int gt_set_ln_exchange(int on) { g_ln_xchg = on < 0 ? -1 : on != 0; return 0; }
 static int seq_cu_count();
 static int g_xchg_spin_max = 0;
-static bool ln_xchg(const Ctx& x) {
-  if (g_ln_xchg < 0) { const char* e = getenv("GT_LN_XCHG"); g_ln_xchg = (e && e[0] == '1') ? 1 : 0; }
-  return g_ln_xchg != 0 && x.W.rowx >= 0;
+// 0 = off, 1 = on where it applies (the default), 2 = forced (gt_set_ln_exchange(1) / GT_LN_XCHG=1: no lower bound on the tile count -- tests)
+static int ln_xchg_mode() {
+  if (g_ln_xchg >= 0) return g_ln_xchg ? 2 : 0;
+  static const int env = [] { const char* e = getenv("GT_LN_XCHG"); return !e ? 1 : e[0] == '0' ? 0 : 2; }();
+  return env;
 }
+static bool ln_xchg(const Ctx& x) { return ln_xchg_mode() != 0 && x.W.rowx >= 0; }
 static void ln_xchg_args(const Ctx& x, GemmArgs& g) {
   g.rowx = reinterpret_cast<unsigned*>(x.ws + x.W.rowx);
   g.spin_max = g_xchg_spin_max > 0 ? g_xchg_spin_max : GT_XCHG_SPIN_MAX;
@@ -674,7 +678,7 @@ static void ln_xchg_args(const Ctx& x, GemmArgs& g) {
 // the fused launch on whichever 64x64 kernel the operands allow (both bf16 shadows -> gemm64h; a bf16-ONLY input needs that one); false: not taken
 template <bool BKM, int EPI>
 static bool ln_xchg_launch(const Ctx& x, const GemmArgs& g, bool in_only16) {
-  if (!gemm64_ln_shape(g, seq_cu_count())) return false;
+  if (!gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2)) return false;
   if (g.bf16 && g.A16 && g.B16 && gemm64h_ok(g, EPI)) { gemm64h_launch<false, EPI>(g, x.s); return true; }
   if (in_only16 || (g.bf16 && g.A16 && g.B16)) return false;
   if (!gemm64_ok(g, EPI)) return false;
@@ -704,7 +708,7 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
       ln_xchg_args(x, g);
       const bool h16 = g.bf16 && g.A16 && g.B16 && gemm64h_ok(g, EPI_RES_LNBWD);
       const bool f32 = !only16(x, dY) && !(g.bf16 && g.A16 && g.B16) && gemm64_ok(g, EPI_RES_LNBWD);
-      if (gemm64_ln_shape(g, seq_cu_count()) && (h16 || f32)) {
+      if (gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2) && (h16 || f32)) {
         g.ln_part = ln_job(x, gamma_off, x.M / 64);
         if (wt) { if (ln_xchg_launch<false, EPI_RES_LNBWD>(x, g, only16(x, dY))) return 0; }
         else if (ln_xchg_launch<true, EPI_RES_LNBWD>(x, g, only16(x, dY))) return 0;

@@ -67,13 +67,14 @@ __device__ __forceinline__ int gemm64_bid() {
 //   * every wave owns 32 rows x 32 columns ("part" p = column / 32): per row two partial values -- forward (mean, M2) of its 32 columns
 //     (two passes over the registers; parts merged by Chan's formula in a fixed order: every workgroup arrives at bit-identical
 //     statistics); backward (sum g, sum g xhat), g = dy gamma;
-//   * hand-off = "data, drain, flag" (MI355X_MICROARCH.md, valid hand-off forms): the wave writes its 64 values as agent-scope
-//     (write-through) stores -- 256 contiguous bytes: layout [row block][part][row half][value][32 rows] --, waits for them
-//     (s_waitcnt vmcnt(0)), then ONE lane stores the part's READY word = this launch's sequence number.  A consumer polls the row block's
-//     N / 32 ready words (one 64- or 128-byte request per wave and round -- a first version that polled tagged 8-byte granules, 16 scattered
-//     loads per lane and round, cost 13 us per launch in L2 requests alone) and then reads the values once, coalesced;
-//   * sequence number: every part's ready word advances by exactly one per launch, so a wave reads its OWN word at its start and adds one
-//     -- no global counter, nothing is ever zeroed, a stale word can never match (the host emulator re-runs workgroups: there the
+//   * hand-off = ONE hop: a value travels as an 8-byte granule {value bits, sequence number} written by one agent-scope (write-through, never
+//     torn) store and polled by agent-scope loads -- the QUAD pair exchange of gt_seq.h widened to N / 32 parties.  Layout [row block][part]
+//     [row half][value][32 rows]: a wave publishes 512 contiguous bytes, and the 32 lanes of a half poll 256 contiguous bytes per load (2 x N / 32
+//     loads per lane and round).  Three versions were measured at d_model 512 / 2048 tokens: (1) granules laid out per ROW (16 scattered 8-byte
+//     loads per lane and round: ~1 M L2 requests per round chip-wide) 13 us per launch; (2) "data, drain, ready word, poll, fetch" (three hops)
+//     5.3 us -- what the LayerNorm pass of its own costs; (3) this one;
+//   * sequence number: every granule advances by exactly one per launch, so a lane reads its OWN granule's number at its start and adds one
+//     -- no global counter, nothing is ever zeroed, a stale granule can never match (the host emulator re-runs workgroups: there the
 //     launch serial of the emulator);
 //   * the workgroups of a row block must be resident together: the host takes this path only when the whole grid fits the chip at once
 //     (gemm64_ln_shape), they are 8 consecutive tiles of one XCD, and the polling loop is bounded -- a time-out raises the header's error
@@ -90,79 +91,78 @@ static bool g64_emu_fail_ = false;
 #define G64_EMU_AGREE(ok) (void)(ok);
 #endif
 #define GT_ROWX_HDR 64                                   /* floats: [0] error word */
-// region: header | ready words [M / 64 row blocks][2 row halves][N / 32 parts] | values [M / 64][N / 32][2 row halves][2][32]
-static inline int64_t gt_rowx_floats(int64_t M, int N) { return GT_ROWX_HDR + (M / 64) * 2 * (N / 32) + (M / 64) * (int64_t)(N / 32) * 128; }
-__device__ __forceinline__ uint32_t g64_ld_u32(const unsigned* p) {
+// region: header | granules [M / 64 row blocks][N / 32 parts][2 row halves][2 values][32 rows] of 8 bytes
+static inline int64_t gt_rowx_floats(int64_t M, int N) { return GT_ROWX_HDR + (M / 64) * (int64_t)(N / 32) * 128 * 2; }
+__device__ __forceinline__ unsigned long long g64_ld(const unsigned long long* p) {
 #ifdef GT_EMU
   return *p;
 #else
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-// this launch's sequence number for the wave that owns ready word `mine`
-__device__ __forceinline__ uint32_t g64_seq(const unsigned* mine) {
+// this launch's sequence number, from the lane's OWN granule
+__device__ __forceinline__ uint32_t g64_seq(const unsigned long long* mine) {
 #ifdef GT_EMU
   (void)mine;
   return emu::launch_serial;
 #else
-  return g64_ld_u32(mine) + 1u;
+  return (uint32_t)(g64_ld(mine) >> 32) + 1u;
 #endif
 }
-// publish: the wave's 64 values (lane (r32, h): value h of row r32) -> vals[h][r32], then the ready word
-__device__ __forceinline__ void g64_publish(float* vals, unsigned* ready, const float v, const int r32, const int h, const uint32_t seq) {
-  gt_pub_store(vals + h * 32 + r32, v);
+__device__ __forceinline__ void g64_publish(unsigned long long* mine, const float v, const uint32_t seq) {
+  const unsigned long long w = ((unsigned long long)seq << 32) | (unsigned long long)gt_f2u(v);
 #ifdef GT_EMU
-  emu::wave_rendezvous();
-  if ((threadIdx.x & 63) == 0) *ready = seq;
+  *mine = w;
 #else
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every lane's store has been acknowledged (write-through) ...
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(ready, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag leaves
+  __hip_atomic_store(mine, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-// wait until all NP parts of the row block carry `seq`; false: gave up (error word raised) / emulator: a partner has not run yet
-template <int NP>
-__device__ __forceinline__ bool g64_wait(const unsigned* ready_rb, const uint32_t seq, unsigned* err, const int spin_max) {
-  const int lane = threadIdx.x & 63;
+// the NG = 2 x (NP / 2) granules this lane combines -- parts [h NP / 2, (h + 1) NP / 2) of its row, (value 0, value 1) each; `base` = the row
+// block's granules + this lane's (row half, row) offset.  false: gave up (error word raised) / emulator: a partner has not run yet
+template <int NG>
+__device__ __forceinline__ bool g64_collect(const unsigned long long* base, const int h, const uint32_t seq, float (&v)[NG], unsigned* err, const int spin_max) {
+  unsigned long long w[NG];
+  bool ok = true;
+  auto load_all = [&]() {
+    ok = true;
+#pragma unroll
+    for (int i = 0; i < NG / 2; ++i) {
+      const unsigned long long* src = base + (size_t)(h * (NG / 2) + i) * 128;       // part stride: [2 row halves][2 values][32 rows]
+      w[2 * i] = g64_ld(src); w[2 * i + 1] = g64_ld(src + 32);
+      ok = ok && (uint32_t)(w[2 * i] >> 32) == seq && (uint32_t)(w[2 * i + 1] >> 32) == seq;
+    }
+  };
 #ifdef GT_EMU
-  return lane >= NP || ready_rb[lane] == seq;
+  load_all();                                                    // (missing: G64_EMU_AGREE re-runs the workgroup after the others)
 #else
   int spins = 0;
   for (;;) {
-    const bool ok = lane >= NP || g64_ld_u32(ready_rb + (lane < NP ? lane : 0)) == seq;
-    if (__all(ok)) return true;                                // (wave-uniform exit)
-    if (++spins > spin_max) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    load_all();
+    if (__all(ok)) break;                                        // (wave-uniform exit)
+    if (++spins > spin_max) { if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     __builtin_amdgcn_s_sleep(2);
   }
 #endif
+#pragma unroll
+  for (int j = 0; j < NG; ++j) v[j] = gt_u2f((uint32_t)w[j]);
+  return ok;
 }
 // NPH = N / 64 column tiles per row block (4: d_model 256, 8: d_model 512).  acc: the wave's 32x32 block in the store epilogue's lane map
 // (lane (r32, h): ONE row, registers 4 q + j = column 8 q + 4 h + j of the block).  smem: the operand buffers, free behind the main loop.
-struct G64Rowx { unsigned* err; unsigned* ready_rb; float* vals_rb; };      // of one row block
-__device__ __forceinline__ G64Rowx g64_rowx(const GemmArgs& g, const int m0) {
-  const int NP = g.N / 32, nrb = g.M / 64, rb = m0 >> 6;
-  G64Rowx r;
-  r.err = g.rowx;
-  r.ready_rb = g.rowx + GT_ROWX_HDR + rb * 2 * NP;             // [row half][part]
-  r.vals_rb = reinterpret_cast<float*>(g.rowx + GT_ROWX_HDR + nrb * 2 * NP) + (size_t)rb * NP * 128;
-  return r;
+// granules of row block m0 / 64: [part][row half][value][32 rows]
+__device__ __forceinline__ unsigned long long* g64_rowx(const GemmArgs& g, const int m0) {
+  return reinterpret_cast<unsigned long long*>(g.rowx + GT_ROWX_HDR) + (size_t)(m0 >> 6) * (g.N / 32) * 128;
 }
 template <int EPI, int NPH>
 __device__ __forceinline__ void gemm64_ln_epilogue(const GemmArgs& g, const f32x16& acc, const int m0, const int n0, const int wm, const int wn,
                                                    const int r32, const int h, const uint32_t seq, float* smem) {
-  constexpr int N = 64 * NPH, NP = 2 * NPH, NG = NP;          // parts of 32 columns per row; values a lane reads (NP / 2 parts x 2)
+  constexpr int N = 64 * NPH, NP = 2 * NPH, NG = NP;          // parts of 32 columns per row; granules a lane combines (NP / 2 parts x 2 values)
   const int row = m0 + wm * 32 + r32, cb = n0 + wn * 32 + 4 * h;       // this lane's row; its columns: cb + 8 q + j
-  const G64Rowx X = g64_rowx(g, m0);
+  unsigned* const xerr = g.rowx;
+  unsigned long long* const xrb = g64_rowx(g, m0);
   const int part = (n0 >> 5) + wn;
-  float* const my_vals = X.vals_rb + (part * 2 + wm) * 64;
-  // the values this lane combines: parts [h NP / 2, (h + 1) NP / 2) of its row -- for a fixed (part, value) the 32 lanes of a half read 128
-  // contiguous bytes
-  auto fetch = [&](float (&pv)[NG]) {
-#pragma unroll
-    for (int i = 0; i < NG / 2; ++i) {
-      const float* src = X.vals_rb + ((h * (NP / 2) + i) * 2 + wm) * 64 + r32;
-      pv[2 * i] = gt_pub_load(src); pv[2 * i + 1] = gt_pub_load(src + 32);
-    }
-  };
+  unsigned long long* const mine = xrb + (size_t)part * 128 + wm * 64 + h * 32 + r32;       // this lane's granule: value h of its row
+  const unsigned long long* const theirs = xrb + wm * 64 + r32;                               // + part * 128 (+ 32: value 1)
   const uint32_t dkey = gt_drop_key(g.drop);
   const float invN = 1.0f / (float)N;
   f32x4 ga[4];
@@ -191,12 +191,11 @@ __device__ __forceinline__ void gemm64_ln_epilogue(const GemmArgs& g, const f32x
 #pragma unroll
     for (int e = 0; e < 16; ++e) { const float d = z[e] - mw; qq += d * d; }
     qq += __shfl_xor(qq, 32);
-    g64_publish(my_vals, X.ready_rb + wm * NP + part, h ? qq : mw, r32, h, seq);          // (lane half 0: the means, half 1: M2)
+    g64_publish(mine, h ? qq : mw, seq);                        // (lane half 0: the means, half 1: M2)
     G64_EMU_PUBLISHED();
-    const bool gotf = g64_wait<NP>(X.ready_rb + wm * NP, seq, X.err, g.spin_max);
-    G64_EMU_AGREE(gotf)
     float pv[NG];
-    fetch(pv);                                                  // (mean, M2) pairs of this half's parts
+    const bool gotf = g64_collect<NG>(theirs, h, seq, pv, xerr, g.spin_max);       // (mean, M2) pairs of this half's parts
+    G64_EMU_AGREE(gotf)
     // Chan's merge over this half's parts, in order (32 columns each) ...
     float mean = pv[0], m2 = pv[1], cnt = 32.f;
 #pragma unroll
@@ -246,12 +245,11 @@ __device__ __forceinline__ void gemm64_ln_epilogue(const GemmArgs& g, const f32x
         dd[4 * q + j] = dv; s1 += gd; s2 += gd * xh[q][j];
       }
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-    g64_publish(my_vals, X.ready_rb + wm * NP + part, h ? s2 : s1, r32, h, seq);
+    g64_publish(mine, h ? s2 : s1, seq);
     G64_EMU_PUBLISHED();
-    const bool gotb = g64_wait<NP>(X.ready_rb + wm * NP, seq, X.err, g.spin_max);
-    G64_EMU_AGREE(gotb)
     float pv[NG];
-    fetch(pv);
+    const bool gotb = g64_collect<NG>(theirs, h, seq, pv, xerr, g.spin_max);
+    G64_EMU_AGREE(gotb)
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NG / 2; ++i) { t1 += pv[2 * i]; t2 += pv[2 * i + 1]; }
@@ -303,8 +301,10 @@ __device__ __forceinline__ void gemm64_ln_epilogue(const GemmArgs& g, const f32x
 }
 // host side: the fused LayerNorm epilogues apply when the Linear itself can take the 64x64 kernels, N = d_model is 256 or 512 and the
 // WHOLE grid is resident at once (two workgroups per CU)
-static inline bool gemm64_ln_shape(const GemmArgs& g, int cus) {
-  return (g.N == 256 || g.N == 512) && g.M % 64 == 0 && (long)(g.M / 64) * (g.N / 64) <= 2l * cus;
+// (forced: gt_set_ln_exchange(1) -- tests on small shapes: no lower bound on the tile count)
+static inline bool gemm64_ln_shape(const GemmArgs& g, int cus, bool forced = false) {
+  const long tiles = (long)(g.M / 64) * (g.N / 64);
+  return (g.N == 256 || g.N == 512) && g.M % 64 == 0 && tiles <= 2l * cus && (forced || 4 * tiles >= 3l * cus);       // (and at least 3/4 of the CUs get a tile)
 }
 
 template <bool BKM, int EPI, int PREC = 0>
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
   uint32_t xtag = 0;            // LayerNorm epilogues: this launch's sequence number = the wave's OWN ready word + 1 (read before the wave publishes)
-  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) xtag = g64_seq(g64_rowx(g, m0).ready_rb + wm * (g.N / 32) + (n0 >> 5) + wn);
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) xtag = g64_seq(g64_rowx(g, m0) + (size_t)((n0 >> 5) + wn) * 128 + wm * 64 + h * 32 + r32);
 
   f32x4 va[PER], vb[PER], wa[PER], wb[PER];
   const char* pa[PER];
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void gemm64h_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
   uint32_t xtag = 0;
-  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) xtag = g64_seq(g64_rowx(g, m0).ready_rb + wm * (g.N / 32) + (n0 >> 5) + wn);
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) xtag = g64_seq(g64_rowx(g, m0) + (size_t)((n0 >> 5) + wn) * 128 + wm * 64 + h * 32 + r32);
   G32hRegs a0[PER], b0[PER], a1[PER], b1[PER], a2[PER], b2[PER];
   const uint16_t* pa[PER];
   const uint16_t* pb[PER];
