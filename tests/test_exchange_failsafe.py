@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIMS = dict(d_model=128, n_heads=4, dim_feedforward=32, num_encoder_layers=1, num_decoder_layers=0, dropout=0.0, embedding_size_src=16)
 
 
-DIMS2 = dict(DIMS, num_encoder_layers=2)        # (two gradient buckets: the rider path cuts after a backward phase)
+DIMS2 = dict(d_model=48, n_heads=4, dim_feedforward=24, num_encoder_layers=2, num_decoder_layers=0, dropout=0.0, embedding_size_src=16)   # (one kernel per op: two gradient buckets)
 
 
 def _engine(B, world=1, seed=3, dims=None, **kw):

@@ -80,13 +80,55 @@ def run_riders(n, seed, backend="hip", verbose=True):
     return fails
 
 
+def run_mid(n, seed, backend="hip", verbose=True):
+    """round 5: the 64x64 ring tiles (gt_gemm64.h; run with GT_T64R_MIN=1 so that every eligible problem takes them), the LayerNorm row exchange
+    (forced on at random), fp32 / bf16 operands / precision 2, d_model 256 / 384 / 512, 64 ... 2048 tokens, encoder-only and encoder-decoder."""
+    rnd = random.Random(2000 + seed)
+    fails = 0
+    lib = parity.Runner(cfg_dict(32, 4, 16, 1), 1, backend).lib
+    for k in range(n):
+        d = rnd.choice([256, 256, 384, 512, 512])
+        H = rnd.choice([h for h in (2, 4, 8, 16) if (d // h) in (16, 24, 32, 48, 64, 96, 128, 192)])
+        F = rnd.choice([128, 256, 384, 512, 640])
+        L = rnd.choice([1, 2])
+        Ld = rnd.choice([0, 0, 0, 1])
+        B = rnd.choice([2, 4, 6, 8, 16, 64])
+        S = rnd.choice([16, 27])
+        p = rnd.choice([0.0, 0.1, 0.3])
+        prec = rnd.choice([0, 0, 1, 2])
+        xchg = rnd.choice([-1, 1])
+        if B == 64 and (L + Ld > 2 or d == 384):
+            L, Ld = 1, 0
+        cfg = cfg_dict(d, H, F, L, Ld, embedding_size_src=S)
+        tag = "mid d%d H%d F%d L%d+%d B%d S%d p%.1f prec %d xchg %d" % (d, H, F, L, Ld, B, S, p, prec, xchg)
+        t0 = time.time()
+        lib.cdll.gt_set_ln_exchange(xchg)
+        try:
+            if prec:
+                r, _, _ = parity.check_step_bf16(backend, cfg, B, p, seed=k, precision=prec)
+                tag += " (in force %d)" % r.precision_in_force()
+            else:
+                parity.check_step(backend, cfg, B, p, seed=k)
+                if B <= 16:
+                    parity.check_train_step(backend, cfg, B, p, seq=False)
+            if verbose:
+                print("ok   %-64s %.1fs" % (tag, time.time() - t0), flush=True)
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print("FAIL %-64s %s: %s" % (tag, type(e).__name__, str(e)[:200]), flush=True)
+        finally:
+            lib.cdll.gt_set_ln_exchange(-1)
+    return fails
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=24)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--riders", action="store_true", help="d_model-128 SPLIT / rider shapes only")
+    ap.add_argument("--mid", action="store_true", help="round 5: d_model 256 ... 512 through the 64x64 ring tiles / row exchange / precision 2 (set GT_T64R_MIN=1)")
     args = ap.parse_args()
-    fails = run_riders(args.n, args.seed) if args.riders else run(args.n, args.seed)
+    fails = run_mid(args.n, args.seed) if args.mid else run_riders(args.n, args.seed) if args.riders else run(args.n, args.seed)
     print("failures:", fails)
     sys.exit(1 if fails else 0)
 
