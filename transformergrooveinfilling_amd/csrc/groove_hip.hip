@@ -670,10 +670,12 @@ static int ln_xchg_mode() {
   static const int env = [] { const char* e = getenv("GT_LN_XCHG"); return !e ? 1 : e[0] == '0' ? 0 : 2; }();
   return env;
 }
-static bool ln_xchg(const Ctx& x) { return ln_xchg_mode() != 0 && x.W.rowx >= 0; }
+// (never beside the side-stream weight gradients, GT_OVERLAP=1: their workgroups hold the LDS the rest of a row block's workgroups wait for -- measured:
+//  the exchange then runs into its polling bound, seconds per step)
+static bool ln_xchg(const Ctx& x) { return ln_xchg_mode() != 0 && x.W.rowx >= 0 && x.side == nullptr; }
 static void ln_xchg_args(const Ctx& x, GemmArgs& g) {
   g.rowx = reinterpret_cast<unsigned*>(x.ws + x.W.rowx);
-  g.spin_max = g_xchg_spin_max > 0 ? g_xchg_spin_max : GT_XCHG_SPIN_MAX;
+  g.spin_max = g_xchg_spin_max > 0 ? g_xchg_spin_max : GT_ROWX_SPIN_MAX;
 }
 // the fused launch on whichever 64x64 kernel the operands allow (both bf16 shadows -> gemm64h; a bf16-ONLY input needs that one); false: not taken
 template <bool BKM, int EPI>

@@ -91,6 +91,9 @@ static bool g64_emu_fail_ = false;
 #define G64_EMU_AGREE(ok) (void)(ok);
 #endif
 #define GT_ROWX_HDR 64                                   /* floats: [0] error word */
+#ifndef GT_ROWX_SPIN_MAX
+#define GT_ROWX_SPIN_MAX (1 << 18)                       /* polls before a workgroup gives its row block up (~0.2 s; a partner delayed by another stream's kernel arrives within milliseconds) */
+#endif
 // region: header | granules [M / 64 row blocks][N / 32 parts][2 row halves][2 values][32 rows] of 8 bytes
 static inline int64_t gt_rowx_floats(int64_t M, int N) { return GT_ROWX_HDR + (M / 64) * (int64_t)(N / 32) * 128 * 2; }
 __device__ __forceinline__ unsigned long long g64_ld(const unsigned long long* p) {

@@ -140,6 +140,7 @@ class StepEngine:
         self._loss_slots = {}
         self._train_B = None           # batch size of the most recent train step (its slot is never evicted)
         self._predict_ws = {}          # chunk size -> (cfg, workspace, tgt scratch) of predict()
+        self._ln_xchg_off = False      # the bucketed-overlap data-parallel recipe switched the LayerNorm row exchange off (see train_step)
         self.exchange_timeouts = 0     # QUAD pair exchanges that timed out (each: updates skipped until noticed, then SPLIT schedule)
         self.xchg_strict = os.environ.get("GT_XCHG_STRICT", "0") == "1"       # raise instead of recovering
         self.B = int(batch_size) if batch_size else None
@@ -368,6 +369,9 @@ class StepEngine:
         best = min(cand, key=lambda c: table[name(c)])
         self.overlap_allreduce, self.dp_graph = best
         self.dp_graph_failed = False
+        if not best[0] and self._ln_xchg_off:      # (trying the bucketed recipe switched the LayerNorm row exchange off: back on for the single all-reduce)
+            self.lib.cdll.gt_set_ln_exchange(-1)
+            self._ln_xchg_off = False
         self.dp_tune = {"modes": {k: (None if v >= 1e29 else round(v, 5)) for k, v in table.items()}, "chosen": name(best), "steps": steps}
         return self.dp_tune
 
@@ -400,6 +404,11 @@ class StepEngine:
         else:
             import torch.distributed as dist
             buckets = self.lib.grad_buckets(s.cfg) if self.overlap_allreduce else []
+            if len(buckets) == 2 and not self._ln_xchg_off:
+                # bucket 0's all-reduce runs UNDER the rest of backward: a collective's workgroups beside launches whose workgroups wait for each
+                # other (the LayerNorm row exchange needs its whole grid resident) -- the norm runs as a row pass of its own in this recipe
+                self.lib.cdll.gt_set_ln_exchange(0)
+                self._ln_xchg_off = True
             guard = self._guard_fn(s)
             if self.dp_graph and on_grads is None and not self.on_host:
                 # ONE enqueue per step: forward + backward, the all-reduce(s) and the update captured in one hipGraph -- the collectives are
