@@ -19,12 +19,15 @@ YAML_KS = cfg_dict(256, 2, 512, 6)                # InfillingKicksAndSnares / In
 C3 = cfg_dict(256, 2, 512, 2, 2)                  # encoder-decoder (layers reduced for oracle time)
 C4 = cfg_dict(512, 8, 512, 2)                     # d_model 512 / 8 heads (layers reduced for oracle time)
 SYM = cfg_dict(64, 16, 64, 2, embedding_size_src=27)
+YAML_LM = cfg_dict(256, 2, 2048, 2)               # InfillingRandomLow_lm_training.yaml (dim_feedforward 2048, L 8: layers reduced for oracle time)
+YAML_LARGE = cfg_dict(256, 16, 64, 3)             # InfillingRandom_test_large.yaml (16 heads of 16, dim_feedforward 64, L 11: layers reduced)
 
 
 @pytest.mark.parametrize("cfg,B,p", [(ENC, 2, 0.0), (ENC, 5, 0.25), (ENCDEC, 3, 0.0), (ENCDEC, 2, 0.25), (C1, 32, 0.18),
                                      (YAML_HH, 16, 0.24), (SYM, 3, 0.1), (cfg_dict(16, 16, 16, 1), 1, 0.0),
                                      (C2, 8, 0.0), (C2, 64, 0.24), (YAML_KS, 4, 0.3), (C3, 4, 0.0), (C3, 3, 0.3),
-                                     (C4, 4, 0.0), (C4, 3, 0.15), (cfg_dict(64, 4, 2048, 1), 2, 0.16)])
+                                     (C4, 4, 0.0), (C4, 3, 0.15), (cfg_dict(64, 4, 2048, 1), 2, 0.16),
+                                     (YAML_LM, 32, 0.16), (YAML_LARGE, 16, 0.15)])      # the two YAMLs at their own batch sizes
 def test_step_parity(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 

@@ -658,8 +658,8 @@ static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, 
 // the norm as a row pass of its own).  22 launches fewer per step at d_model 512.  Measured at 2048 tokens (round 5, A/B on one box, two rounds): C4 bs 64
 // 1.488 / 1.492 -> 1.472 / 1.474 ms, C5 bf16 bs 64 0.944 / 0.936 -> 0.931 / 0.933, precision 2 0.929 / 0.932 -> 0.916 / 0.918 -- with the one-hop hand-off
 // (tagged granules, coalesced); the three-hop "data, drain, ready word" form was neutral (1.494 vs 1.494, bf16 0.984 vs 0.968), a first form with
-// per-row granules (16 scattered polls per lane) cost 13 us per launch (1.811 ms).  C3 (d_model 256, 8192 tokens) keeps its row-owning tiles: 5.18 ms
-// against 5.29 (64x64 tiles + row pass) and 5.44 (+ exchange).
+// per-row granules (16 scattered polls per lane) cost 13 us per launch (1.811 ms).  C3 (d_model 256, 8192 tokens): 5.20 ms on the row-owning tiles, 5.29
+// on 64x64 tiles + row pass, 5.44 with the three-hop exchange, 5.06 with this one (row_fused below).
 static int g_ln_xchg = -1;
 extern "C" int gt_set_ln_exchange(int on) { g_ln_xchg = on < 0 ? -1 : on != 0; return 0; }
 static int seq_cu_count();
@@ -687,9 +687,22 @@ static bool ln_xchg_launch(const Ctx& x, const GemmArgs& g, bool in_only16) {
   gemm64_launch<BKM, EPI>(g, x.s);
   return true;
 }
+// does the row exchange take this shape's d_model-wide Linears?  (the shape rule of gemm64_ln_shape for N = d_model)
+static bool ln_xchg_rows(const Ctx& x) {
+  if (!ln_xchg(x) || x.M % 64 != 0) return false;
+  GemmArgs g{};
+  g.M = x.M; g.N = x.d;
+  return gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2);
+}
+// Round 5: where the row exchange applies the 64x64 ring tiles + the norm in their epilogue beat the row-owning tiles too (d_model 256 at 8192 tokens,
+// C3: 5.20 ms with the row-owning tiles, 5.06 with 64x64 tiles + exchange -- 5.29 with 64x64 tiles and the norm as a row pass); GT_ROW_FUSE_XCHG=0
+// or GT_LN_XCHG=0 keeps the row-owning tiles
 static bool row_fused(const Ctx& x) {
   static const int big_max_d = [] { const char* e = getenv("GT_ROW_FUSE_BIG_MAX_D"); return e ? atoi(e) : GT_ROW_FUSE_BIG_MAX_D; }();     // (A/B switch)
-  return !x.c.precision && (x.d <= GT_ROW_FUSE_MAX_D || (x.M >= GT_ROW_FUSE_MIN_M && x.d <= big_max_d));
+  static const bool over_xchg = [] { const char* e = getenv("GT_ROW_FUSE_XCHG"); return e && e[0] == '0'; }();
+  if (x.c.precision) return false;
+  if (x.d <= GT_ROW_FUSE_MAX_D) return true;
+  return x.M >= GT_ROW_FUSE_MIN_M && x.d <= big_max_d && (over_xchg || !ln_xchg_rows(x));
 }
 static void ln_bwd(const Ctx& x, const float* dy, const float* res, const float* xhat, const float* rstd, int64_t gamma_off, float* dz,
                    float* dzm, int site, const uint16_t* dy16 = nullptr);

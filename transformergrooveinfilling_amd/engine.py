@@ -520,8 +520,8 @@ class StepEngine:
                           int(train), self.stream)
         run()
         # evaluation forwards are consumed on the host right away: a timed-out pair exchange is noticed here and the forward repeated on
-        # the fallback schedule (a forward has no side effects).  Training forwards of the module API are covered by the device-side
-        # skip of the update (backward_guard) and the next synchronising check.
+        # the fallback schedule (a forward has no side effects).  Training forwards of the module API are covered by backward(): gradients
+        # computed through a raised word are zeroed on the device, so the optimizer step that follows changes nothing.
         if not train and not self.on_host and self._xchg_word(s) is not None and self.check_exchange(s, "an evaluation forward"):
             run()
         return s.hvo
