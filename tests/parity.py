@@ -389,6 +389,10 @@ def _check_bf16_shadows(backend, cfg, B, p, P, x, y):
         return r.ws.numpy()[o:o + c].view(np.uint16)
 
     n = 0
+    want = bf(r.ws_get("x0", 0))                          # the input layer's output (operand of layer 0's in-proj and of its weight gradient)
+    got = shadow("x0", 0)[:want.size]
+    assert np.array_equal(got, want), ("x0", int((got != want).sum()), want.size)
+    n += 1
     for l in range(L):
         for name in ["ctx", "x1", "hact"] + (["xout"] if l + 1 < L else []) + ["dhid", "dqkv", "dzAm" if p > 0 else "dzA", "dzBm" if p > 0 else "dzB"]:
             want = bf(r.ws_get(name, l))

@@ -173,9 +173,9 @@ def test_bf16_shadows_of_the_gemm_operands():
     the same shape through that path."""
     from transformergrooveinfilling_amd import _lib
     c5 = dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=2, num_decoder_layers=0, embedding_size_src=27)
-    assert parity.check_bf16_shadows("hip", c5, 192, 0.3) == 31
-    assert parity.check_bf16_shadows("hip", dict(c5, n_heads=16, num_encoder_layers=1), 192, 0.0) == 15
-    assert parity.check_bf16_shadows("hip", c5, 64, 0.3) == 31          # 2048 tokens: the same through the 64x64-tile kernels (gt_gemm64.h)
+    assert parity.check_bf16_shadows("hip", c5, 192, 0.3) == 32
+    assert parity.check_bf16_shadows("hip", dict(c5, n_heads=16, num_encoder_layers=1), 192, 0.0) == 16
+    assert parity.check_bf16_shadows("hip", c5, 64, 0.3) == 32          # 2048 tokens: the same through the 64x64-tile kernels (gt_gemm64.h)
     lib = _lib.get_lib()
     try:
         for level in (2, 1):                        # 2 (the default): operand-only tensors in bf16 ALONE; 1: beside their fp32 tensors

@@ -318,6 +318,7 @@ static WLayout ws_layout(const gt_config& c) {
   if (bf16_shadows(c)) {
     auto sh = [&](int64_t off, int64_t n) { W.sh.emplace_back(off, add((n + 1) / 2)); };
     const bool only = bf16_shadow_level() >= 2;
+    sh(W.x0, M * d);        // (round 5: the input layer's output -- layer 0's in-proj and its weight gradient then run with both operands in bf16 like every other layer's)
     for (int l = 0; l < c.n_enc_layers; ++l) {
       const LayerW& w = W.layers[l];
       sh(w.ctx, M * d); sh(w.x1, M * d); sh(w.hact, M * F);
@@ -978,6 +979,7 @@ static void input_layer_fwd(const Ctx& x, const float* in, int S, int64_t w, int
                             int site) {
   GemmArgs g = mk_gemm(in, S, x.prm + w, S, out, x.d, x.M, x.d, S);
   g.bias = x.prm + b; g.aux = a0; g.pe = pe; g.drop = mk_drop(x, site);
+  g.C16 = sh_act(x, out); g.ldc16 = x.d;           // (bf16 shadow of x0 where the encoder's operands have them: written by the generic kernel's EPI_RELU_PE epilogue)
   gemm_launch<false, false, EPI_RELU_PE>(g, x.s);
 }
 // FFN block + last norm of a layer:  xout = LN(xin + drop(W2 drop(relu(W1 xin + b1)) + b2))

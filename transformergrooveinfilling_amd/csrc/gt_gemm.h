@@ -645,6 +645,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
           if (row0 < g.M && col0 < g.N) {
             *reinterpret_cast<float4*>(&g.C[(size_t)row0 * g.ldc + col0]) = make_float4(o[0], o[1], o[2], o[3]);
             if (EPI == EPI_RELU_PE) *reinterpret_cast<float4*>(&g.aux[(size_t)row0 * g.N + col0]) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+            if (EPI == EPI_RELU_PE && g.C16 != nullptr) {                 // bf16 shadow of the input layer's output (operand of layer 0's in-proj and of its weight gradient)
+              uint2 pk;
+              pk.x = (uint32_t)gt_f2bf(o[0]) | ((uint32_t)gt_f2bf(o[1]) << 16);
+              pk.y = (uint32_t)gt_f2bf(o[2]) | ((uint32_t)gt_f2bf(o[3]) << 16);
+              *reinterpret_cast<uint2*>(g.C16 + (size_t)row0 * g.ldc16 + col0) = pk;
+            }
           }
         } else {
 #pragma unroll
@@ -655,6 +661,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
               if (EPI == EPI_ATOMIC) atomicAdd(&g.C[ci], o[r]);
               else g.C[ci] = o[r];
               if (EPI == EPI_RELU_PE) g.aux[(size_t)row * g.N + col] = o2[r];
+              if (EPI == EPI_RELU_PE && g.C16 != nullptr) g.C16[(size_t)row * g.ldc16 + col] = gt_f2bf(o[r]);
             }
           }
         }
