@@ -19,10 +19,10 @@ for b in 16 32 80 96 128 192; do python tools/shape_bench.py --only 2 --batch $b
 # round 5: the 2048-token regime (a GPU's share of configs[3] / [4]) with the switches one by one
 for i in 6 9 12; do
   GT_T64R_MIN=100000000 python tools/shape_bench.py --only $i --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_T64R_MIN=inf (no 64x64 ring tiles: round 4 tile rules) /' >> $O/shapes.txt
-  GT_LN_XCHG=1 python tools/shape_bench.py --only $i --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_LN_XCHG=1 (LayerNorm inside the Linear, in-launch row exchange) /' >> $O/shapes.txt
+  GT_LN_XCHG=0 python tools/shape_bench.py --only $i --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_LN_XCHG=0 (LayerNorm as a row pass of its own instead of the in-launch row exchange) /' >> $O/shapes.txt
 done
-GT_ROW_FUSE_BIG_MAX_D=0 python tools/shape_bench.py --only 5 --steps 40 2>/dev/null | tail -1 | sed 's/^/GT_ROW_FUSE_BIG_MAX_D=0 (C3: 64x64 ring tiles + LayerNorm row pass instead of row-owning tiles) /' >> $O/shapes.txt
-GT_ROW_FUSE_BIG_MAX_D=0 GT_LN_XCHG=1 python tools/shape_bench.py --only 5 --steps 40 2>/dev/null | tail -1 | sed 's/^/GT_ROW_FUSE_BIG_MAX_D=0 GT_LN_XCHG=1 (C3: ... + in-launch row exchange) /' >> $O/shapes.txt
+GT_ROW_FUSE_XCHG=0 python tools/shape_bench.py --only 5 --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_ROW_FUSE_XCHG=0 (C3: row-owning LayerNorm tiles, the path until round 5) /' >> $O/shapes.txt
+GT_ROW_FUSE_BIG_MAX_D=0 GT_LN_XCHG=0 python tools/shape_bench.py --only 5 --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_ROW_FUSE_BIG_MAX_D=0 GT_LN_XCHG=0 (C3: 64x64 ring tiles + LayerNorm row pass) /' >> $O/shapes.txt
 python bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_style_1.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_style_2.json 2>/dev/null
@@ -33,7 +33,7 @@ GT_DP_GRAPH=1 GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp > $O/
 for i in 0 1; do GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py $i > $O/seq_stamps_$i.txt 2>&1; done     # (the shipped path of these shapes: SPLIT)
 GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py 2 > $O/seq_stamps_c2.txt 2>&1
 python tools/wg_unit_bench.py 64 > $O/wg_unit_bench.txt 2>&1
-for i in 0 1 4 6 9 12 13; do python tools/class_profile.py $i > $O/class_profile_$i.txt 2>&1; done
+for i in 0 1 4 5 6 9 12 13; do python tools/class_profile.py $i > $O/class_profile_$i.txt 2>&1; done
 ./tools/ubench/gemm_bench > $O/gemm_bench.txt 2>&1
 for s in "2048 512 512" "2048 1536 512" "2048 512 1536" "8192 256 256" "8192 768 256"; do echo "== $s" >> $O/gemm_bench_mid.txt; ./tools/ubench/gemm_bench $s 2>&1 | grep -E "gemm64|gemm32.h|^NN|32x32   <|64x64   <2,2,2,2,BK32" >> $O/gemm_bench_mid.txt; done
 python tools/predict_bench.py > $O/predict.txt 2>&1

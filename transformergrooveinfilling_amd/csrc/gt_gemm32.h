@@ -583,6 +583,15 @@ __device__ __forceinline__ bf16x8 wg32t_join(const Wg32tFrag& lo, const Wg32tFra
 #endif
   return r;
 }
+// sum of the four bf16 values of a transposed-read fragment (the bias gradient = column sums of the dY slabs, taken from the fragments the
+// MFMAs consume instead of 32 dependent 2-byte LDS reads per thread and slab -- the first-column tiles ran ~20 % behind the others)
+__device__ __forceinline__ float wg32t_sum(const Wg32tFrag& f) {
+#ifdef GT_EMU
+  return (gt_bf2f(f.v[0]) + gt_bf2f(f.v[1])) + (gt_bf2f(f.v[2]) + gt_bf2f(f.v[3]));
+#else
+  return (gt_bf2f((uint16_t)f[0]) + gt_bf2f((uint16_t)f[1])) + (gt_bf2f((uint16_t)f[2]) + gt_bf2f((uint16_t)f[3]));
+#endif
+}
 __device__ __forceinline__ void wgrad32t_body(const GemmArgs& g, const int m0, const int n0, const int kbeg, const int nk, const bool want_dbias,
                                               uint16_t* sm) {
   typedef Wg32tCfg Cfg;
@@ -623,7 +632,8 @@ __device__ __forceinline__ void wgrad32t_body(const GemmArgs& g, const int m0, c
   const int L16 = lane & 15, tq = L16 >> 2, tp = L16 & 3;
   const int toff = (8 * h + tq) * STR + 16 * ((lane >> 4) & 1) + 4 * tp;
   const int fa = toff + wm * 64, fb = SZ + toff + wn * 64;
-  float bsum = 0.f;
+  float bsum[2] = {0.f, 0.f};                      // bias gradient: lane (r32, h) sums row wm * 64 + 32 ti + r32 of dY^T over its tokens (k = 16 s + 8 h + j)
+  const bool bias_wave = want_dbias && wn == 0;    // (both column waves hold the same A fragments: one of them sums)
   auto tof = [&](const int t) { return t < nk ? t : nk - 1; };
   W32T_LD(a0, b0, 0)
   W32T_LD(a1, b1, tof(1))
@@ -638,15 +648,14 @@ __device__ __forceinline__ void wgrad32t_body(const GemmArgs& g, const int m0, c
     _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) {                                         \
       const uint16_t* qa = &sm[(CUR) * 2 * SZ + fa + 32 * ti + 16 * s_ * STR];                 \
       const uint16_t* qb = &sm[(CUR) * 2 * SZ + fb + 32 * ti + 16 * s_ * STR];                 \
-      a16[ti] = wg32t_join(wg32t_tr(qa), wg32t_tr(qa + 4 * STR));                              \
+      const Wg32tFrag alo_ = wg32t_tr(qa), ahi_ = wg32t_tr(qa + 4 * STR);                      \
+      a16[ti] = wg32t_join(alo_, ahi_);                                                        \
       b16[ti] = wg32t_join(wg32t_tr(qb), wg32t_tr(qb + 4 * STR));                              \
+      if (bias_wave) bsum[ti] += wg32t_sum(alo_) + wg32t_sum(ahi_);   /* (wave-uniform) */     \
     }                                                                                          \
     _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                           \
     _Pragma("unroll") for (int tb = 0; tb < 2; ++tb)                                           \
       acc[ta][tb] = GT_MFMA32_BF16(a16[ta], b16[tb], acc[ta][tb]);                             \
-  }                                                                                            \
-  if (want_dbias && tid < 128) {  /* column sums of the dY slab (the bias gradient) */           \
-    _Pragma("unroll 8") for (int kk_ = 0; kk_ < BK; ++kk_) bsum += gt_bf2f(sm[(CUR) * 2 * SZ + kk_ * STR + tid]); \
   }                                                                                            \
   W32T_ST(NA, NB, (CUR) ^ 1)                                                                   \
   W32T_LD(NA, NB, tof((t) + 4))                                                                \
@@ -659,7 +668,13 @@ __device__ __forceinline__ void wgrad32t_body(const GemmArgs& g, const int m0, c
 #undef W32T_SLAB
 #undef W32T_LD
 #undef W32T_ST
-  if (want_dbias && tid < 128) atomicAdd(&g.dbias[m0 + tid], bsum);
+  if (bias_wave) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const float t = bsum[ti] + __shfl_xor(bsum[ti], 32);
+      if (h == 0) atomicAdd(&g.dbias[m0 + wm * 64 + 32 * ti + r32], t);
+    }
+  }
 #pragma unroll
   for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
