@@ -256,6 +256,9 @@ int gt_debug_occupy_cus(int nblocks, int usec, gt_stream_t stream);
  * (GT_BF16_SHADOWS=0/1/2) or the default.  Outputs, losses and gradients are bit-identical at every level.  Changes gt_workspace_bytes and
  * which gt_ws_find names are live: set it before sizing a workspace.  gt_operand_shadow_level: the level in force for a configuration. */
 int gt_set_operand_shadows(int level);
+/* Bumped by every call that changes a switch the workspace layout depends on (today: gt_set_operand_shadows).  A host that keeps workspaces
+ * across calls compares it with the value it saw when it sized them and re-makes them on a mismatch (StepEngine.slot does). */
+int gt_layout_epoch(void);
 int gt_operand_shadow_level(const gt_config* cfg);
 /* The precision a configuration really runs at: 2 only where gt_config.precision = 2 applies (see there), else 1 / 0. */
 int gt_precision_in_force(const gt_config* cfg);

@@ -160,3 +160,36 @@ def test_data_parallel_autotune_agrees_across_ranks(tmp_path):
     x, y = layout.synthetic_batch(4, 16, seed=9)
     ref.train_step(torch.from_numpy(x), torch.from_numpy(y))
     assert (ref.params - a["params"]).abs().max() < 1e-6
+
+
+def test_layout_switch_after_a_slot_was_sized_remakes_the_slot():
+    """the workspace layout depends on process-global switches (gt_set_operand_shadows); a cached slot sized before such a
+    switch changed must not be reused -- gt_layout_epoch() tells, StepEngine.slot re-makes the slot and training goes on from the same parameters."""
+    from transformergrooveinfilling_amd import layout
+    eng = _engine(2, dims=DIMS2)
+    ref = _engine(2, dims=DIMS2)
+    lib = eng.lib
+    x, y = layout.synthetic_batch(2, 16, seed=9)
+    x, y = torch.from_numpy(x), torch.from_numpy(y)
+    try:
+        eng.train_step(x, y); ref.train_step(x, y)
+        s0, e0 = eng.slot(2), lib.cdll.gt_layout_epoch()
+        eng.predict(x)
+        assert eng.slot(2) is s0                                     # (nothing changed: the slot is reused)
+        lib.cdll.gt_set_operand_shadows(1)
+        assert lib.cdll.gt_layout_epoch() == e0 + 1
+        lib.cdll.gt_set_operand_shadows(1)
+        assert lib.cdll.gt_layout_epoch() == e0 + 1                  # (same value again: no change)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            eng.train_step(x, y)
+        assert any("workspace layout changed" in str(m.message) for m in w)
+        assert eng.slot(2) is not s0 and eng.slot(2).layout_epoch == e0 + 1
+        assert not eng._predict_ws or eng._predict_epoch == e0 + 1
+        eng.predict(x)
+        assert eng._predict_epoch == e0 + 1
+        lib.cdll.gt_set_operand_shadows(-1)                         # (ref's slot is re-made too: same numbers either way)
+        ref.train_step(x, y)
+        assert torch.allclose(eng.params, ref.params, rtol=0, atol=0)
+    finally:
+        lib.cdll.gt_set_operand_shadows(-1)

@@ -74,6 +74,7 @@ _SIGS = {
     "gt_set_ln_exchange": (ctypes.c_int, [ctypes.c_int]),
     "gt_debug_occupy_cus": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
     "gt_set_operand_shadows": (ctypes.c_int, [ctypes.c_int]),
+    "gt_layout_epoch": (ctypes.c_int, []),
     "gt_operand_shadow_level": (ctypes.c_int, [_cfgp]),
     "gt_precision_in_force": (ctypes.c_int, [_cfgp]),
     "gt_workspace_init": (ctypes.c_int, [_cfgp, _vp, _vp]),

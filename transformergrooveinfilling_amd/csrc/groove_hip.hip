@@ -223,7 +223,16 @@ static bool seq_supported(const gt_config& c);
 // losses and gradients are bit for bit those of level 0 / 1 (the fp32-source GEMMs round the same values at fragment assembly):
 // C5 bs 512 4.06 -> 3.6 ms.  gt_ws_find names the bf16 tensors "<name>16"; the fp32 regions of those six stay allocated, unwritten.
 static int g_bf16_shadows = -1;
-extern "C" int gt_set_operand_shadows(int level) { g_bf16_shadows = level < 0 ? -1 : level > 2 ? 2 : level; return 0; }
+// every change of a switch the workspace LAYOUT depends on bumps this counter: a host that caches workspaces compares it before it reuses one
+// (StepEngine.slot re-makes the slot: offsets move with the shadow level, and a workspace sized for another level is too small or mis-read)
+static int g_layout_epoch = 0;
+extern "C" int gt_layout_epoch() { return g_layout_epoch; }
+extern "C" int gt_set_operand_shadows(int level) {
+  const int nv = level < 0 ? -1 : level > 2 ? 2 : level;
+  if (nv != g_bf16_shadows) ++g_layout_epoch;
+  g_bf16_shadows = nv;
+  return 0;
+}
 static int bf16_shadow_level() {
   if (g_bf16_shadows < 0) { const char* e = getenv("GT_BF16_SHADOWS"); g_bf16_shadows = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
   return g_bf16_shadows;

@@ -14,6 +14,7 @@ all-reduce over the flat buffer and averaged inside the optimizer kernel (grad_s
 """
 import ctypes
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -44,6 +45,7 @@ class _Slot:
         self.B = B
         self.cfg = _lib.make_config(B, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
                                     d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
+        self.layout_epoch = eng.lib.cdll.gt_layout_epoch()      # (the workspace below is laid out for the switches in force NOW: StepEngine.slot)
         self.ws = torch.empty(eng.lib.workspace_floats(self.cfg), **f32)
         eng.lib.call("gt_workspace_init", ctypes.byref(self.cfg), _ptr(self.ws), eng.stream)   # (zeroes the regions whose protocol relies on it)
         self.x = torch.zeros(B, 32, d["embedding_size_src"], **f32)
@@ -140,6 +142,7 @@ class StepEngine:
         self._loss_slots = {}
         self._train_B = None           # batch size of the most recent train step (its slot is never evicted)
         self._predict_ws = {}          # chunk size -> (cfg, workspace, tgt scratch) of predict()
+        self._predict_epoch = None     # gt_layout_epoch() those were sized at
         self._ln_xchg_off = False      # the bucketed-overlap data-parallel recipe switched the LayerNorm row exchange off (see train_step)
         self.exchange_timeouts = 0     # QUAD pair exchanges that timed out (each: updates skipped until noticed, then SPLIT schedule)
         self.xchg_strict = os.environ.get("GT_XCHG_STRICT", "0") == "1"       # raise instead of recovering
@@ -150,6 +153,13 @@ class StepEngine:
     # ---- buffers ---------------------------------------------------------------------------------
     def slot(self, B):
         B = int(B)
+        s = self._slots.get(B)
+        if s is not None and s.layout_epoch != self.lib.cdll.gt_layout_epoch():
+            # a layout switch (gt_set_operand_shadows) changed after this slot's workspace was sized: every offset may have moved and the
+            # bf16-only regions may no longer fit -- the slot is re-made (its saved activations, graphs and weight packs go with it)
+            warnings.warn("StepEngine: the workspace layout changed after the batch-%d slot was sized; re-making the slot" % B)
+            del self._slots[B]
+            self._predict_ws.clear()
         if B not in self._slots:
             if len(self._slots) >= MAX_SLOTS:                     # evaluation remainders etc.: bounded, like the loss slots
                 # least recently USED first; never the engine's own batch size nor the slot the last train step ran on
@@ -586,6 +596,9 @@ class StepEngine:
         out = torch.empty(n, 32, 27, dtype=torch.float32, device=self.device)
         for i in range(0, n, chunk):
             m = min(chunk, n - i)
+            if self._predict_epoch != self.lib.cdll.gt_layout_epoch():      # (a layout switch changed: see slot())
+                self._predict_ws.clear()
+                self._predict_epoch = self.lib.cdll.gt_layout_epoch()
             if m not in self._predict_ws:
                 if len(self._predict_ws) >= 2:             # the full chunk + one remainder size at most
                     self._predict_ws.pop(next(k for k in self._predict_ws if k != chunk), None)
