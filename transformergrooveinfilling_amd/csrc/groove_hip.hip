@@ -1304,6 +1304,13 @@ static void decoder_step(const Ctx& x, const float* pe, const float* tgt, int t,
 }
 static void output_layer_fwd(const Ctx& x, float* hvo_out) {
   const float* fin = x.ws + (x.c.n_dec_layers > 0 ? x.W.dec_final : x.W.memory);
+  static const bool skinny = [] { const char* e = getenv("GT_HEADS_KERNEL"); return !(e && e[0] == '0'); }();     // (A/B switch: 0 = the generic GEMM)
+  if (skinny && heads_fwd_ok(x.M, x.d, x.d, fin, x.prm + x.P.out_w)) {
+    gt_prof_tag("gemm_fwd_heads", 2.0 * x.M * GT_TGT * x.d, 4.0 * ((double)x.M * x.d + (double)GT_TGT * x.d + (double)x.M * GT_TGT));
+    if (x.c.precision) gt_launch(heads_fwd_kernel<1>, dim3(x.M / 16), dim3(256), x.s, fin, (const float*)(x.prm + x.P.out_w), (const float*)(x.prm + x.P.out_b), hvo_out, x.M, x.d);
+    else               gt_launch(heads_fwd_kernel<0>, dim3(x.M / 16), dim3(256), x.s, fin, (const float*)(x.prm + x.P.out_w), (const float*)(x.prm + x.P.out_b), hvo_out, x.M, x.d);
+    return;
+  }
   GemmArgs g = mk_gemm(fin, x.d, x.prm + x.P.out_w, x.d, hvo_out, GT_TGT, x.M, GT_TGT, x.d);
   g.bias = x.prm + x.P.out_b;
   gemm_launch<false, false, EPI_HEADS>(g, x.s);

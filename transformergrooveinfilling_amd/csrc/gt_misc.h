@@ -735,3 +735,62 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(WShadowArgs a) {
     ot[(size_t)(32 * tcx + c) * R + 32 * tr + tx] = gt_f2bf(t[tx][c]);
   }
 }
+
+// ---- OutputLayer on a kernel of its own (round 5): hvo[M][27] = act(X[M][d] W^T + b) -- [h logits | sigmoid v | 0.5 tanh o].
+// The generic GEMM ran it as 32 x 32 tiles with ONE column tile: M / 32 workgroups (64 at 2048 tokens) each walking d / 64 dependent slabs -- 12-16 us
+// for 57 MFLOP at d_model 512.  Here a workgroup owns 16 rows, its four waves split the contraction (d / 4 each), every operand fragment goes
+// from global memory straight into registers and ALL of a wave's loads are in flight together (3 d / 64 16-byte loads per lane); the four
+// partial 16 x 32 tiles meet in LDS, in a fixed order.  PREC 1: both operands rounded to bf16 (the numbers gt_config.precision >= 1 defines for
+// every Linear), products and sums in fp32.  Needs d % 64 == 0, 128 <= d <= 512, M % 16 == 0, dense rows of X (ldx = d).
+#define GT_HEADS_MAX_D 512
+template <int PREC>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                        float* __restrict__ hvo, const int M, const int d) {
+  __shared__ __attribute__((aligned(16))) float part[4][16][36];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int kw = d >> 2, k0 = wave * kw;                      // this wave's slice of the contraction
+  const float* const zp = gt_zero_ptr();
+  constexpr int NKMAX = GT_HEADS_MAX_D / 64;                 // 16-wide k-steps per wave at most
+  const int nks = kw >> 4;
+  float4 a[NKMAX], b0[NKMAX], b1[NKMAX];
+  const float* pa = X + (size_t)(m0 + l16) * d + k0 + 4 * lg;
+  const float* pb0 = W + (size_t)l16 * d + k0 + 4 * lg;                                   // columns 0..15
+  const float* pb1 = (16 + l16 < GT_TGT) ? W + (size_t)(16 + l16) * d + k0 + 4 * lg : zp;      // columns 16..26 (27..31: zeros)
+  const int sb1 = (16 + l16 < GT_TGT) ? 16 : 0;                                           // (the zero page does not advance)
+#pragma unroll
+  for (int u = 0; u < NKMAX; ++u) {
+    if (u < nks) {
+      a[u] = *reinterpret_cast<const float4*>(pa + 16 * u);
+      b0[u] = *reinterpret_cast<const float4*>(pb0 + 16 * u);
+      b1[u] = *reinterpret_cast<const float4*>(pb1 + sb1 * u);
+    }
+  }
+  auto rnd = [](const float v) { return PREC ? gt_bf2f(gt_f2bf(v)) : v; };
+  f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+  for (int u = 0; u < NKMAX; ++u) {
+    if (u < nks) {
+      const float av[4] = {rnd(a[u].x), rnd(a[u].y), rnd(a[u].z), rnd(a[u].w)};
+      const float bv0[4] = {rnd(b0[u].x), rnd(b0[u].y), rnd(b0[u].z), rnd(b0[u].w)};
+      const float bv1[4] = {rnd(b1[u].x), rnd(b1[u].y), rnd(b1[u].z), rnd(b1[u].w)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c0 = GT_MFMA16(bv0[j], av[j], c0); c1 = GT_MFMA16(bv1[j], av[j], c1); }
+    }
+  }
+  // lane (l16, lg) holds row l16, columns 4 lg + 0..3 of its column tile (the accumulator map of gt_seq.h's matmul primitives)
+  *reinterpret_cast<float4*>(&part[wave][l16][4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+  *reinterpret_cast<float4*>(&part[wave][l16][16 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+  __syncthreads();
+  for (int e = tid; e < 16 * GT_TGT; e += 256) {
+    const int r = e / GT_TGT, c = e % GT_TGT;
+    float v = ((part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c])) + bias[c];
+    if (c >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
+    else if (c >= GT_VOICES) v = gt_sigmoid(v);
+    hvo[(size_t)(m0 + r) * GT_TGT + c] = v;
+  }
+}
+static inline bool heads_fwd_ok(int M, int d, int ldx, const void* X, const void* W) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return M % 16 == 0 && d % 64 == 0 && d >= 128 && d <= GT_HEADS_MAX_D && ldx == d && al16(X) && al16(W);
+}
