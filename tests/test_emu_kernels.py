@@ -148,6 +148,21 @@ def _emu_subprocess(code, env):
     return subprocess.run([sys.executable, "-c", head + code + "print('ok')\n"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
 
 
+def test_output_layer_kernel_with_the_loss_inside():
+    """d_model 192 (outside the sequence-resident class, a multiple of 64): the OutputLayer runs on heads_fwd_kernel -- 16 rows per workgroup, the
+    contraction split over four waves -- and, in the fused train step, that launch computes the loss, d loss / d logits and the statistics too
+    (ticket hand-off); encoder-only and encoder-decoder, fp32 and bf16 operands; plain forward (no loss) through check_step"""
+    out = _emu_subprocess("big = cfg_dict(192, 3, 32, 1)\n"
+                          "parity.check_step('emu', big, 2, 0.1)\n"
+                          "parity.check_train_step('emu', big, 2, 0.1)\n"
+                          "parity.check_train_step('emu', cfg_dict(128, 2, 32, 1, 1), 1, 0.0)\n"
+                          "parity.check_train_step_bf16('emu', big, 2, 0.1)\n", dict(GT_TRACE_HEADS="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    tr = [ln for ln in out.stderr.splitlines() if ln.startswith("[heads]")]
+    assert any("loss 1" in ln and "precision 0" in ln for ln in tr) and any("loss 1" in ln and "precision 1" in ln for ln in tr)
+    assert any("loss 0" in ln for ln in tr) and any("M 32 d 128" in ln for ln in tr)
+
+
 # ---- 64x64 tiles on the ring body (gt_gemm64.h, round 5): problems of 192 .. 2047 tiles otherwise -- the tile rule is lowered through
 # the environment (GT_T64R_MIN=1, read once per process: a subprocess) and GT_TRACE_GEMM64=1 proves which launches took the kernel
 def test_tile64_ring_kernel():

@@ -1094,6 +1094,7 @@ static bool use_seq(const gt_config& c) {
 // gt_train_step hands its loss over to the sequence-resident forward (one launch less): set around its gt_forward call
 struct SeqLoss { const float* y; float penalty; float* stats; unsigned* ticket; };
 static thread_local SeqLoss g_seq_loss = {nullptr, 0.f, nullptr, nullptr};
+static thread_local bool g_heads_loss_done = false;   // one-kernel-per-op path: the OutputLayer launch of this fused step computed the loss too (heads_fwd_kernel)
 // flops of backward phase 0 of the SPLIT / QUAD schedule: the dgrads of the output layer and of the last layer's FFN2, FFN1, out-proj
 static double seq_b0_flops(const Ctx& x) { return 2.0 * x.M * (27.0 * x.d + 2.0 * x.d * x.F + (double)x.d * x.d); }
 static thread_local bool g_seq_b0_fused = false;     // the forward of this fused step already ran backward phase 0 (seq_fb_kernel): gt_train_step's backward skips it
@@ -1306,9 +1307,17 @@ static void output_layer_fwd(const Ctx& x, float* hvo_out) {
   const float* fin = x.ws + (x.c.n_dec_layers > 0 ? x.W.dec_final : x.W.memory);
   static const bool skinny = [] { const char* e = getenv("GT_HEADS_KERNEL"); return !(e && e[0] == '0'); }();     // (A/B switch: 0 = the generic GEMM)
   if (skinny && heads_fwd_ok(x.M, x.d, x.d, fin, x.prm + x.P.out_w)) {
+    // the fused train step hands the loss over as well (g_seq_loss, as for the sequence-resident launches): one launch for OutputLayer + loss
+    HeadsLoss hl = {nullptr, 0.f, nullptr, nullptr, nullptr, nullptr};
+    if (g_seq_loss.y != nullptr) {
+      hl = HeadsLoss{g_seq_loss.y, g_seq_loss.penalty, g_seq_loss.stats, x.ws + x.W.loss_part, g_seq_loss.ticket, x.ws + x.W.dlogits};
+      g_heads_loss_done = true;
+    }
+    static const bool trace = [] { const char* e = getenv("GT_TRACE_HEADS"); return e && e[0] == '1'; }();     // (tests: which launches took the kernel)
+    if (trace) fprintf(stderr, "[heads] M %d d %d precision %d loss %d\n", x.M, x.d, x.c.precision, hl.y != nullptr);
     gt_prof_tag("gemm_fwd_heads", 2.0 * x.M * GT_TGT * x.d, 4.0 * ((double)x.M * x.d + (double)GT_TGT * x.d + (double)x.M * GT_TGT));
-    if (x.c.precision) gt_launch(heads_fwd_kernel<1>, dim3(x.M / 16), dim3(256), x.s, fin, (const float*)(x.prm + x.P.out_w), (const float*)(x.prm + x.P.out_b), hvo_out, x.M, x.d);
-    else               gt_launch(heads_fwd_kernel<0>, dim3(x.M / 16), dim3(256), x.s, fin, (const float*)(x.prm + x.P.out_w), (const float*)(x.prm + x.P.out_b), hvo_out, x.M, x.d);
+    if (x.c.precision) gt_launch(heads_fwd_kernel<1>, dim3(x.M / 16), dim3(256), x.s, fin, (const float*)(x.prm + x.P.out_w), (const float*)(x.prm + x.P.out_b), hvo_out, x.M, x.d, hl);
+    else               gt_launch(heads_fwd_kernel<0>, dim3(x.M / 16), dim3(256), x.s, fin, (const float*)(x.prm + x.P.out_w), (const float*)(x.prm + x.P.out_b), hvo_out, x.M, x.d, hl);
     return;
   }
   GemmArgs g = mk_gemm(fin, x.d, x.prm + x.P.out_w, x.d, hvo_out, GT_TGT, x.M, GT_TGT, x.d);
@@ -1781,7 +1790,7 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
   const bool packs_current = (skip_update & GT_STEP_PACKS_CURRENT) != 0;
   skip_update &= 3;
   // the hand-offs to the sequence-resident forward / backward travel in thread-locals: whatever path leaves this function, they are cleared
-  struct Handoffs { ~Handoffs() { g_seq_loss.y = nullptr; g_seq_packs_current = false; g_seq_b0_fused = false; } } handoffs_guard;
+  struct Handoffs { ~Handoffs() { g_seq_loss.y = nullptr; g_seq_packs_current = false; g_seq_b0_fused = false; g_heads_loss_done = false; } } handoffs_guard;
   const int M = cfg->batch * 32;
   hipStream_t s = (hipStream_t)stream;
   const float* tgt_in = nullptr;
@@ -1793,12 +1802,16 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
     return backward_impl(cfg, params, grads, xin, tgt_in, hvo_out, nullptr, ws, state, 1, 1, stream, 2);
   if (tgt_in) gt_launch(shift_right_kernel, dim3((M * GT_TGT + 255) / 256), dim3(256), s, y, tgt_scratch, M * GT_TGT);
   // sequence-resident path: the launch that runs the output layer computes the loss as well (one launch less)
-  const bool fuse_loss = use_seq(*cfg) && stats != nullptr && hvo_out != nullptr;
-  if (fuse_loss) g_seq_loss = SeqLoss{y, hit_loss_penalty, stats, reinterpret_cast<unsigned*>(&state->pad2[0])};
+  // (one kernel per op: the OutputLayer launch takes the loss along where it runs on heads_fwd_kernel -- it says so through g_heads_loss_done)
+  bool fuse_loss = use_seq(*cfg) && stats != nullptr && hvo_out != nullptr;
+  g_heads_loss_done = false;
+  if (stats != nullptr && hvo_out != nullptr && y != nullptr) g_seq_loss = SeqLoss{y, hit_loss_penalty, stats, reinterpret_cast<unsigned*>(&state->pad2[0])};
   g_seq_packs_current = packs_current && use_seq(*cfg);
   const int frc = gt_forward(cfg, params, pe, xin, tgt_in, hvo_out, ws, state, 1, stream);
   g_seq_loss.y = nullptr;
   g_seq_packs_current = false;
+  fuse_loss = fuse_loss || g_heads_loss_done;
+  g_heads_loss_done = false;
   if (frc) return -1;
   // loss + head-activation backward in one kernel: d loss / d logits straight into ws.dlogits; workgroup partials are
   // combined by the last-arriving workgroup (ticket in the step state), so there is no memset node and the stats are

@@ -743,10 +743,16 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(WShadowArgs a) {
 // partial 16 x 32 tiles meet in LDS, in a fixed order.  PREC 1: both operands rounded to bf16 (the numbers gt_config.precision >= 1 defines for
 // every Linear), products and sums in fp32.  Needs d % 64 == 0, 128 <= d <= 512, M % 16 == 0, dense rows of X (ldx = d).
 #define GT_HEADS_MAX_D 512
+// L.y != nullptr (the fused train step): the loss of the 16 rows as well -- d loss / d logits to L.dlogits, this workgroup's four partial sums to
+// L.partials, the last workgroup to arrive (ticket) adds all partials in a fixed order: loss_kernel<true, true>'s arithmetic and hand-off, one launch less.
+struct HeadsLoss { const float* y; float penalty; float* stats; float* partials; unsigned* ticket; float* dlogits; };
 template <int PREC>
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-                                                        float* __restrict__ hvo, const int M, const int d) {
+                                                        float* __restrict__ hvo, const int M, const int d, const HeadsLoss L) {
   __shared__ __attribute__((aligned(16))) float part[4][16][36];
+  __shared__ float outs[16][28];
+  __shared__ float red[4][4];
+  __shared__ int is_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * 16;
   const int kw = d >> 2, k0 = wave * kw;                      // this wave's slice of the contraction
@@ -788,6 +794,45 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
     if (c >= 2 * GT_VOICES) v = 0.5f * tanhf(v);
     else if (c >= GT_VOICES) v = gt_sigmoid(v);
     hvo[(size_t)(m0 + r) * GT_TGT + c] = v;
+    outs[r][c] = v;
+  }
+  if (L.y == nullptr) return;                                // (uniform)
+  __syncthreads();
+  const float invM = 1.0f / (float)M;
+  float bce = 0.f, mv = 0.f, mo = 0.f, ok = 0.f;
+  if (tid < 16 * GT_VOICES) {
+    const int r = tid / GT_VOICES, j = tid % GT_VOICES;
+    const size_t base = (size_t)(m0 + r) * GT_TGT + j;
+    float gh, gv, go;
+    gt_loss_elem<true>(outs[r][j], outs[r][j + GT_VOICES], outs[r][j + 2 * GT_VOICES], L.y[base], L.y[base + GT_VOICES], L.y[base + 2 * GT_VOICES],
+                       L.penalty, invM, bce, mv, mo, ok, gh, gv, go);
+    L.dlogits[base] = gh; L.dlogits[base + GT_VOICES] = gv; L.dlogits[base + 2 * GT_VOICES] = go;
+  }
+  bce = gt_wave_sum(bce); mv = gt_wave_sum(mv); mo = gt_wave_sum(mo); ok = gt_wave_sum(ok);
+  if (lane == 0) { red[wave][0] = bce; red[wave][1] = mv; red[wave][2] = mo; red[wave][3] = ok; }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gt_pub_store(L.partials + blockIdx.x * 4 + q, (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]));
+    const unsigned t = gt_pub_ticket(L.ticket);               // (write-through partials, drained; no fences: gt_common.h)
+    is_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  {                                                          // fixed-order sum: wave q sums quantity q over the workgroups (loss_kernel)
+    float acc = 0.f;
+    for (unsigned bk = lane; bk < gridDim.x; bk += 64) acc += gt_pub_load(L.partials + bk * 4 + wave);
+    acc = gt_wave_sum(acc);
+    if (lane == 0) red[0][wave] = acc * invM;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float b_ = red[0][0], v_ = red[0][1], o_ = red[0][2];
+    L.stats[0] = b_ + v_ + o_;
+    L.stats[1] = red[0][3] * (1.0f / GT_VOICES);
+    L.stats[2] = 0.f;
+    L.stats[3] = b_; L.stats[4] = v_; L.stats[5] = o_; L.stats[6] = 0.f; L.stats[7] = 0.f;
+    *L.ticket = 0u;                                          // re-arm for the next step
   }
 }
 static inline bool heads_fwd_ok(int M, int d, int ldx, const void* X, const void* W) {
