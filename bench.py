@@ -8,8 +8,9 @@ set, one per GPU) before anything touches a GPU, relays rank 0's JSON line as th
 worst child's code.  Nothing is ever exec'ed from a process that has initialised the GPU.
 
 A step = one pass of the hot path over one batch of synthetic 32x16 MSO inputs / 32x27 HVO targets already resident in HBM:
-forward, BCE+MSE loss, backward, (N>1: RCCL all-reduce of the flat gradient buffer), SGD update -- gt_train_step of
-libgroove_hip.so, replayed as one hipGraph.  Workload (N=1 and per GPU for N>1, weak scaling): BASELINE configs[1] --
+forward, BCE+MSE loss, backward, (N>1: RCCL all-reduce of the flat gradient buffer), SGD update -- ONE call of gt_train_step of
+libgroove_hip.so per step, which enqueues the step's 8 launches directly (the engine replays a captured hipGraph only for steps of more
+than 24 launches; `config.hipgraph` in the JSON line says which it was).  Workload (N=1 and per GPU for N>1, weak scaling): BASELINE configs[1] --
 InfillingClosedHH_training.yaml hyper-parameters with the BASELINE shape overrides d_model=128 / 4 heads / 3 layers, bs=64,
 fp32.  `oracle/` is imported by the cpu_baseline leg only.
 """
@@ -246,6 +247,7 @@ def run_rank(args):
         ev = e0.elapsed_time(e1) * 1e-3 if not emu else dt
         # a pair exchange of the four-workgroups-per-sequence schedule that timed out inside the block (its updates were skipped on the
         # device, the engine has fallen back to two workgroups per sequence): the block does not count -- on any rank
+        # (world > 1: check_exchange is itself collective -- every rank is here, every rank recovers or none does)
         bad = 1.0 if eng.check_exchange(eng.slot(batch), "a timed block of bench.py") else 0.0
         if world > 1:
             t = torch.tensor([dt, ev, bad], device=dev, dtype=torch.float64)
@@ -298,6 +300,28 @@ def run_rank(args):
         fused_dt = sorted(timed_block(e1.train_step, args.steps)[0] for _ in range(3))[1]
         del e1
 
+    # what the first multi-GPU record needs to explain itself: every rank's exchange time-outs and skipped updates, and the gradient
+    # all-reduce timed ALONE (20 back-to-back all-reduces of the flat gradient buffer, max over ranks)
+    per_rank, ar_alone_us = None, None
+    if (world > 1 or args.force_dp) and dist.is_initialized():
+        rep = eng.exchange_report()
+        mine = torch.tensor([float(rep["exchange_timeouts"]), float(rep["skipped_updates"])], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "exchange_timeouts": int(t[0].item()), "skipped_updates": int(t[1].item())} for r, t in enumerate(allr)]
+        buf = torch.zeros(eng.total, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        sync(); t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        if not emu:
+            torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t0) / 20 * 1e6], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ar_alone_us = float(tt.item())
+        del buf
+
     out = None
     if rank == 0:
         seq_s = world * batch * args.steps / dt
@@ -320,9 +344,12 @@ def run_rank(args):
                             "grad_buckets": len(eng.lib.grad_buckets(eng.slot(batch).cfg)),
                             "grad_bytes": 4 * eng.total,
                             "dp_graph": bool(eng.dp_graph and not eng.dp_graph_failed) if (world > 1 or args.force_dp) else None,
-                            "dp_tune": dp_tune},
-            # QUAD pair exchanges that timed out (0 on a GPU this process has to itself); blocks in which one did are not in `value`
-            "exchange_timeouts": eng.exchange_timeouts, "blocks_discarded": discarded,
+                            "dp_tune": dp_tune,
+                            "allreduce_alone_us": ar_alone_us,       # the gradient all-reduce by itself (grad_bytes, 20 reps, max over ranks)
+                            "per_rank": per_rank},
+            # in-launch exchanges that timed out (0 on a GPU this process has to itself) and the updates the device skipped because of them;
+            # blocks in which one did are not in `value`
+            "exchange_timeouts": eng.exchange_timeouts, "skipped_updates": eng.exchange_report()["skipped_updates"], "blocks_discarded": discarded,
             "step_roofline": {"f_train_mflop_per_seq": ftrain / 1e6, "achieved_tflops": seq_s * ftrain / 1e12,
                               "frac_of_fp32_mfma_peak": seq_s * ftrain / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world)},
             "final_loss": loss,

@@ -58,7 +58,14 @@ typedef struct gt_config {
                            * dgrad outputs ahead of a LayerNorm backward, dctx.  Residual stream, LayerNorm statistics, softmax, loss,
                            * master weights and optimizer stay fp32.  In force where the bf16 operand shadows apply at level 2 and
                            * the heads are 64 / 128 wide (gt_precision_in_force); elsewhere it runs as precision 1. */
+  int32_t flags;          /* per-CALLER schedule switches (round 6; 0 = the library's defaults).  They select among schedules that give the same
+                           * numbers, never change the workspace layout, and -- unlike gt_set_seq_quad / gt_set_ln_exchange, which are
+                           * process-wide -- bind only the calls made with this gt_config: two engines in one process can differ.
+                           * GT_CFG_NO_QUAD: no four-workgroups-per-sequence schedule (no in-launch pair exchange);
+                           * GT_CFG_NO_LN_XCHG: no LayerNorm inside the Linears (no in-launch row exchange). */
 } gt_config;
+#define GT_CFG_NO_QUAD 1
+#define GT_CFG_NO_LN_XCHG 2
 
 /* device-resident per-step state, so that a captured hipGraph replays with fresh dropout masks,
  * Adam bias correction and learning rate without host-side kernel-argument changes */
@@ -132,13 +139,21 @@ int gt_backward(const gt_config* cfg, const float* params, float* grads, const f
 /* Replaces optimizer.step() of torch.optim.SGD(lr, momentum=0) (ckpt: optimizer param_groups) /
  * torch.optim.Adam(lr) (ref:train.py:40-42).  algo 0 = sgd, 1 = adam (m, v: flat moment buffers).
  * Reads lr/grad_scale/betas from *state and increments state->step / opt_step.  zero_grads != 0 also
- * zeroes the consumed gradient buffer (what opt.zero_grad() does before the next batch). */
+ * zeroes the consumed gradient buffer (what opt.zero_grad() does before the next batch).
+ * PLAIN: every one of the n elements is updated, for any n (a sub-range, an unpadded buffer); no error word and no guard
+ * element are looked at -- the fail-safe of the in-launch exchanges belongs to gt_train_step / gt_optimizer_step_ws, which
+ * know the configuration and its workspace. */
 int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n,
                       gt_step_state* state, int zero_grads, gt_stream_t stream);
 
 /* gt_optimizer_step for the data-parallel step sequence (gt_train_step(skip_update = 1..3), all-reduce, update): with the
  * configuration and its workspace at hand the update on the sequence-resident path also writes the next step's fragment-ordered
- * weight copies (see GT_STEP_PACKS_CURRENT below); on other paths, or with zero_grads == 0, identical to gt_optimizer_step. */
+ * weight copies (see GT_STEP_PACKS_CURRENT below).  The buffers are the WHOLE flat buffers of the configuration (gt_param_count
+ * n_floats elements).  This entry point -- like the update inside gt_train_step -- carries the fail-safe of the in-launch exchanges:
+ * with the workspace's error word set ("xchg_err"), or with a non-zero GUARD element grads[n_floats - 1] (padding behind the 27-float
+ * output bias; gt_dp_guard writes it, the gradient all-reduce sums it), NOTHING is applied: parameters and moments stay, consumed
+ * gradients are cleared (zero_grads), state->step advances (the batch was consumed: fresh dropout masks) but state->opt_step (Adam's t)
+ * does not, and word 1 of the "xchg_err" header counts the skipped update.  The guard element itself is neither updated nor cleared. */
 int gt_optimizer_step_ws(const gt_config* cfg, int algo, float* params, float* grads, float* m, float* v, float* ws,
                          gt_step_state* state, int zero_grads, gt_stream_t stream);
 
@@ -234,7 +249,9 @@ int gt_set_seq_quad(int on);
  * 27-float output bias; a data-parallel host writes its error flag there before the all-reduce) is non-zero, so every rank skips
  * together.  gt_set_xchg_spin_max: polls before giving up (<= 0: the default, 2^22 = seconds; tests lower it). */
 int gt_set_xchg_spin_max(int polls);
-/* Data-parallel hosts: grads[n_floats - 1] = 1 if this workspace's exchange error word is set, else 0 -- enqueue between the backward
+/* "xchg_err" (gt_ws_find) = two 32-bit words at the head of whichever exchange region a shape has: [0] the error word, [1] the number of
+ * updates skipped because of it (or of a data-parallel guard) since the last gt_workspace_init.
+ * Data-parallel hosts: grads[n_floats - 1] = 1 if this workspace's exchange error word is set, else 0 -- enqueue between the backward
  * (gt_train_step(skip_update = 1 / 2)) and the gradient all-reduce; a no-op for shapes without an exchange region. */
 int gt_dp_guard(const gt_config* cfg, float* grads, const float* ws, gt_stream_t stream);
 /* LayerNorm inside the producing Linear / dgrad (csrc/gt_gemm64.h, round 5): at d_model 256 / 512, where the 64 x 64-tile kernels apply and

@@ -31,10 +31,15 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(_lib.GtConfig) == 36          # 8 x int32/float + precision
+    assert ctypes.sizeof(_lib.GtConfig) == 40          # 8 x int32/float + precision + flags
     assert ctypes.sizeof(_lib.GtStepState) == 48
     assert [f[0] for f in _lib.GtConfig._fields_] == ["batch", "src_dim", "d_model", "n_heads", "dim_ff", "n_enc_layers",
-                                                      "n_dec_layers", "dropout", "precision"]
+                                                      "n_dec_layers", "dropout", "precision", "flags"]
+    hdr = open(os.path.join(ROOT, "include", "groove_hip.h")).read()
+    body = hdr[hdr.index("typedef struct gt_config {"):hdr.index("} gt_config;")]
+    assert re.findall(r"^\s*(?:int32_t|float)\s+(\w+);", body, re.M) == [f[0] for f in _lib.GtConfig._fields_]
+    assert int(re.search(r"#define GT_CFG_NO_QUAD (\d+)", hdr).group(1)) == _lib.CFG_NO_QUAD
+    assert int(re.search(r"#define GT_CFG_NO_LN_XCHG (\d+)", hdr).group(1)) == _lib.CFG_NO_LN_XCHG
 
 
 def test_config_validation(lib):
@@ -44,6 +49,7 @@ def test_config_validation(lib):
     unknown_precision = _lib.make_config(2, 16, 32, 4, 16, 2)
     unknown_precision.precision = 7
     bad.append(unknown_precision)
+    bad.append(_lib.make_config(2, 16, 32, 4, 16, 2, flags=64))
     for c in bad:
         with pytest.raises(_lib.GrooveLibError):
             lib.param_layout(c)

@@ -138,6 +138,41 @@ def test_big_tile_kernel_variant():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
 
 
+def test_layernorm_fused_into_the_big_tile_linears():
+    """gt_gemm64.h gemm32_ln_epilogue (round 6): EPI_RES_LN / EPI_RES_LNBWD on the 128x128 kernels -- a wave owns 64 x 64, parts of 64 columns,
+    two rows per lane, granules [part][4 row quarters][2 values][32 rows].  The big-tile emulator library (every eligible problem on the
+    128x128 kernels, operand shadows from one tile) with the shape rule's lower bound at its build-time 1: fp32 NT forward + NN dgrad, bf16
+    fragments from fp32 sources, both operands as bf16 shadows (gemm32h_kernel), precision 2, N = 256 (2 column tiles) and 512 (4), one and two
+    128-row blocks, with and without dropout; a train step (dgamma / dbeta partials per 128-row block through the reduce); the trace proves
+    which launches took the path.  GT_LN_XCHG128=0 keeps the shape on the LayerNorm row pass."""
+    import os
+    import subprocess
+    from harness import ROOT
+    so = os.path.join(ROOT, "tests", "emu", "libgroove_emu_big.so")
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh"), "-DGT_T128_BIG_MIN=1", "-DGT_T128H_MIN=1", "-DGT_WGRAD_T128_MIN=1", "-DGT_ROW32_MIN_M=64", "-DGT_ROW_FUSE_MIN_M=64", "-DGT_ATTN_BWD_LDS_MIN=1"],
+                          env=dict(os.environ, GT_EMU_OUT=so), stdout=subprocess.DEVNULL)
+    out = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 4, 128, 2), 4, 0.2)\n"           # M = 128: one row block, two column tiles
+                          "parity.check_step('emu', cfg_dict(256, 2, 64, 1), 8, 0.0)\n"            # M = 256: two row blocks, no dropout
+                          "parity.check_step('emu', cfg_dict(512, 8, 128, 1), 4, 0.1)\n"           # N = 512: four column tiles, 8 parts
+                          "parity.check_train_step('emu', cfg_dict(256, 2, 128, 1), 4, 0.1, seq=False)\n"
+                          "parity.check_step_bf16('emu', cfg_dict(256, 4, 128, 2), 4, 0.2)\n"      # both operands as bf16 shadows
+                          "parity.check_step_bf16('emu', cfg_dict(512, 8, 128, 1), 4, 0.0)\n"
+                          "harness.emu_lib().cdll.gt_set_operand_shadows(0)\n"
+                          "parity.check_step_bf16('emu', cfg_dict(256, 4, 128, 1), 4, 0.2)\n"      # bf16 fragments from fp32 sources (PREC 1 body)
+                          "harness.emu_lib().cdll.gt_set_operand_shadows(-1)\n"
+                          "r, P, G = parity.check_step_bf16('emu', cfg_dict(256, 4, 128, 2), 4, 0.2, precision=2)\n"
+                          "assert r.precision_in_force() == 2\n"
+                          "parity.check_train_step_bf16('emu', cfg_dict(256, 4, 128, 1), 4, 0.1, precision=2)\n",
+                          dict(GT_EMU_LIB_PATH=so, GT_TRACE_GEMM64="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    tr = [ln for ln in out.stderr.splitlines() if ln.startswith("[gemm64] ln128")]
+    for want in ("fp32-source M 128 N 256 K 256 NT epi 7 prec 0", "fp32-source M 128 N 256 K 128 NT epi 7 prec 0", "NN epi 8 prec 0", "M 256 N 256",
+                 "M 128 N 512", "bf16-source M 128 N 256 K 256 NT epi 7", "bf16-source M 128 N 256 K 128 NT epi 8", "epi 7 prec 1", "bf16-source M 128 N 512"):
+        assert any(want in ln for ln in tr), (want, tr[:8])
+    off = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 4, 128, 1), 4, 0.2)\n", dict(GT_EMU_LIB_PATH=so, GT_TRACE_GEMM64="1", GT_LN_XCHG128="0"))
+    assert off.returncode == 0 and "ok" in off.stdout and "ln128" not in off.stderr, off.stderr[-3000:]
+
+
 def _emu_subprocess(code, env):
     import os
     import subprocess

@@ -396,6 +396,8 @@ def test_quad_pair_exchange_fails_safe_under_contention_and_on_timeout():
             torch.cuda.synchronize()
         assert eng.exchange_timeouts == 1 and any("pair exchange" in str(w.message) for w in rec)
         assert torch.equal(eng.params, before)                  # every step in between was a skipped one
+        assert eng.skipped_updates >= 2 and eng.cfg_flags == eng.FALLBACK_FLAGS      # ... counted by the device; the fall-back is this engine's own
+        assert ref.cfg_flags == 0 and lib.cdll.gt_step_launches(ctypes.byref(ref.slot(B).cfg)) != lib.cdll.gt_step_launches(ctypes.byref(eng.slot(B).cfg))
         # ... and from there on it trains on two workgroups per sequence, with the numbers of an undisturbed engine (fp32 rounding)
         lib.cdll.gt_set_xchg_spin_max(0)
         st = eng.state_struct()
@@ -409,11 +411,11 @@ def test_quad_pair_exchange_fails_safe_under_contention_and_on_timeout():
         e2 = make()
         want = e2.predict(torch.from_numpy(x)).clone()
         cfg2, ws2, _ = e2._predict_ws[B]
-        e2._xchg_word(ws2, cfg2).fill_(1)
+        e2._xchg_word(ws2, cfg2)[0] = 1
         with warnings.catch_warnings(record=True):
             warnings.simplefilter("always")
             got = e2.predict(torch.from_numpy(x))
-        assert e2.exchange_timeouts == 1 and int(e2._xchg_word(ws2, cfg2).item()) == 0
+        assert e2.exchange_timeouts == 1 and int(e2._xchg_word(ws2, cfg2)[0].item()) == 0
         assert torch.equal(got[..., :9], want[..., :9]) and (got - want).abs().max() < 1e-5
     finally:
         lib.cdll.gt_set_xchg_spin_max(0)

@@ -18,7 +18,12 @@ GT_VOICES = 9
 class GtConfig(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int32), ("src_dim", ctypes.c_int32), ("d_model", ctypes.c_int32),
                 ("n_heads", ctypes.c_int32), ("dim_ff", ctypes.c_int32), ("n_enc_layers", ctypes.c_int32),
-                ("n_dec_layers", ctypes.c_int32), ("dropout", ctypes.c_float), ("precision", ctypes.c_int32)]
+                ("n_dec_layers", ctypes.c_int32), ("dropout", ctypes.c_float), ("precision", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
+
+
+CFG_NO_QUAD = 1          # gt_config.flags (include/groove_hip.h): per-caller schedule switches
+CFG_NO_LN_XCHG = 2
 
 
 class GtStepState(ctypes.Structure):
@@ -159,6 +164,6 @@ def get_lib():
 PRECISION = {"fp32": 0, "f32": 0, "float32": 0, 0: 0, None: 0, "bf16": 1, "bfloat16": 1, 1: 1, "bf16_storage": 2, "bf16s": 2, "autocast": 2, 2: 2}
 
 
-def make_config(batch, src_dim, d_model, n_heads, dim_ff, n_enc_layers, n_dec_layers=0, dropout=0.0, precision=0):
+def make_config(batch, src_dim, d_model, n_heads, dim_ff, n_enc_layers, n_dec_layers=0, dropout=0.0, precision=0, flags=0):
     return GtConfig(int(batch), int(src_dim), int(d_model), int(n_heads), int(dim_ff), int(n_enc_layers),
-                    int(n_dec_layers), float(dropout), PRECISION[precision])
+                    int(n_dec_layers), float(dropout), PRECISION[precision], int(flags))

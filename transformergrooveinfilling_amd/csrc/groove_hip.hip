@@ -99,6 +99,7 @@ static int check_cfg(const gt_config* c) {
   if (c->n_enc_layers <= 0 || c->n_enc_layers > 64 || c->n_dec_layers < 0 || c->n_dec_layers > 64)
     return gt_fail("layer counts out of range (enc %d, dec %d)", c->n_enc_layers, c->n_dec_layers);
   if (!(c->dropout >= 0.f && c->dropout < 1.f)) return gt_fail("dropout %f outside [0,1)", (double)c->dropout);
+  if (c->flags & ~(GT_CFG_NO_QUAD | GT_CFG_NO_LN_XCHG)) return gt_fail("gt_config.flags %d has unknown bits", c->flags);
   if (c->precision < 0 || c->precision > 2) return gt_fail("precision %d unknown (0 = fp32, 1 = bf16 GEMM operands, 2 = ... and bf16 storage of the Linear outputs)", c->precision);
   if ((int64_t)c->batch * 32 * (c->dim_ff > 3 * c->d_model ? c->dim_ff : 3 * c->d_model) >= (1ll << 31))
     return gt_fail("batch %d too large for 32-bit element indices", c->batch);
@@ -406,7 +407,7 @@ extern "C" int gt_ws_find(const gt_config* cfg, const char* name, int layer, int
   else if (n == "dmem") set(W.dmem, M * d); else if (n == "dctx") set(W.dctx, M * d);
   else if (n == "seq_xchg") set(W.seq_xchg, W.seq_xchg_n);
   else if (n == "rowx") set(W.rowx, W.rowx_n);
-  else if (n == "xchg_err") { if (W.seq_xchg >= 0) set(W.seq_xchg, 1); else if (W.rowx >= 0) set(W.rowx, 1); }      // the error word of whichever in-launch exchange this shape has
+  else if (n == "xchg_err") { if (W.seq_xchg >= 0) set(W.seq_xchg, 2); else if (W.rowx >= 0) set(W.rowx, 2); }      // the error word of whichever in-launch exchange this shape has
   else if (n == "amask" && W.seq_amask >= 0) set(W.seq_amask, W.seq_amask_stride * c.n_enc_layers);
   else if (n == "pack_f" && W.pack_f >= 0) set(W.pack_f, W.pack_stride * c.n_enc_layers);
   else if (n == "pack_b" && W.pack_b >= 0) set(W.pack_b, W.pack_stride * c.n_enc_layers);
@@ -682,15 +683,31 @@ static int ln_xchg_mode() {
 }
 // (never beside the side-stream weight gradients, GT_OVERLAP=1: their workgroups hold the LDS the rest of a row block's workgroups wait for -- measured:
 //  the exchange then runs into its polling bound, seconds per step)
-static bool ln_xchg(const Ctx& x) { return ln_xchg_mode() != 0 && x.W.rowx >= 0 && x.side == nullptr; }
+static bool ln_xchg(const Ctx& x) { return ln_xchg_mode() != 0 && !(x.c.flags & GT_CFG_NO_LN_XCHG) && x.W.rowx >= 0 && x.side == nullptr; }
 static void ln_xchg_args(const Ctx& x, GemmArgs& g) {
   g.rowx = reinterpret_cast<unsigned*>(x.ws + x.W.rowx);
   g.spin_max = g_xchg_spin_max > 0 ? g_xchg_spin_max : GT_ROWX_SPIN_MAX;
 }
 // the fused launch on whichever 64x64 kernel the operands allow (both bf16 shadows -> gemm64h; a bf16-ONLY input needs that one); false: not taken
+// which geometry the row exchange runs on for this (M, N): 64 = the 64x64 kernels of gt_gemm64.h, 128 = the big tile (round 6), 0 = none
+static int ln_xchg_tile(const GemmArgs& g) {
+  if (gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2)) return 64;
+  static const bool off128 = [] { const char* e = getenv("GT_LN_XCHG128"); return e && e[0] == '0'; }();     // (A/B switch)
+  return (!off128 && gemm32_ln_shape(g, seq_cu_count())) ? 128 : 0;
+}
 template <bool BKM, int EPI>
 static bool ln_xchg_launch(const Ctx& x, const GemmArgs& g, bool in_only16) {
-  if (!gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2)) return false;
+  const int tile = ln_xchg_tile(g);
+  if (tile == 128) {
+    if (!gemm32_ln_ok(g, EPI)) return false;
+    if (g.bf16 && g.A16 && g.B16 && gemm32h_ok(g, EPI)) { gemm64_trace("ln128 bf16-source", g, false, EPI); gemm32h_launch<false, EPI>(g, x.s); return true; }
+    if (in_only16 || (g.bf16 && g.A16 && g.B16)) return false;
+    if (!gemm32_ok(g, EPI, BKM)) return false;
+    gemm64_trace("ln128 fp32-source", g, BKM, EPI);
+    gemm32_launch<BKM, EPI>(g, x.s);
+    return true;
+  }
+  if (tile != 64) return false;
   if (g.bf16 && g.A16 && g.B16 && gemm64h_ok(g, EPI)) { gemm64h_launch<false, EPI>(g, x.s); return true; }
   if (in_only16 || (g.bf16 && g.A16 && g.B16)) return false;
   if (!gemm64_ok(g, EPI)) return false;
@@ -702,7 +719,7 @@ static bool ln_xchg_rows(const Ctx& x) {
   if (!ln_xchg(x) || x.M % 64 != 0) return false;
   GemmArgs g{};
   g.M = x.M; g.N = x.d;
-  return gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2);
+  return ln_xchg_tile(g) != 0;
 }
 // Round 5: where the row exchange applies the 64x64 ring tiles + the norm in their epilogue beat the row-owning tiles too (d_model 256 at 8192 tokens,
 // C3: 5.20 ms with the row-owning tiles, 5.06 with 64x64 tiles + exchange -- 5.29 with 64x64 tiles and the norm as a row pass); GT_ROW_FUSE_XCHG=0
@@ -731,10 +748,13 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
       g.drop = mk_drop(x, site);
       float dummy; g.ln_part = &dummy;                          // (eligibility first: a registered job cannot be taken back)
       ln_xchg_args(x, g);
-      const bool h16 = g.bf16 && g.A16 && g.B16 && gemm64h_ok(g, EPI_RES_LNBWD);
-      const bool f32 = !only16(x, dY) && !(g.bf16 && g.A16 && g.B16) && gemm64_ok(g, EPI_RES_LNBWD);
-      if (gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2) && (h16 || f32)) {
-        g.ln_part = ln_job(x, gamma_off, x.M / 64);
+      const int tile = ln_xchg_tile(g);
+      const bool both16 = g.bf16 && g.A16 && g.B16;
+      const bool h16 = both16 && (tile == 128 ? gemm32_ln_ok(g, EPI_RES_LNBWD) && gemm32h_ok(g, EPI_RES_LNBWD) : gemm64h_ok(g, EPI_RES_LNBWD));
+      const bool f32 = !only16(x, dY) && !both16 &&
+                       (tile == 128 ? gemm32_ln_ok(g, EPI_RES_LNBWD) && gemm32_ok(g, EPI_RES_LNBWD, wt == nullptr) : gemm64_ok(g, EPI_RES_LNBWD));
+      if (tile != 0 && (h16 || f32)) {
+        g.ln_part = ln_job(x, gamma_off, x.M / tile);
         if (wt) { if (ln_xchg_launch<false, EPI_RES_LNBWD>(x, g, only16(x, dY))) return 0; }
         else if (ln_xchg_launch<true, EPI_RES_LNBWD>(x, g, only16(x, dY))) return 0;
         return gt_fail("dgrad + LayerNorm backward: the fused launch was refused after its job was registered");
@@ -812,7 +832,22 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
     // precision = 2: the Linear output ahead of the norm lives in bf16 alone -- in the region that then receives the bf16 copy of the norm's
     // result (the row pass reads a row into registers before it writes any of it)
     uint16_t* t16 = p2(x.c) ? sh_act(x, out) : nullptr;
+    // ONE launch: the Linear with dropout + residual + LayerNorm in its epilogue (row statistics through the in-launch exchange: 64x64 tiles at
+    // a GPU's share of a data-parallel batch, the big tile from 8192 tokens at d_model 512 -- round 6)
+    auto try_fused = [&]() -> bool {
+      if (second || !ln_xchg(x)) return false;
+      GemmArgs f = g;
+      f.res = res; f.ldres = x.d; f.gamma = x.prm + gamma_off; f.beta = x.prm + gamma_off + bo;
+      f.aux = xhat; f.aux2 = rstd; f.drop = mk_drop(x, site);
+      f.C16 = sh_act(x, out); f.ldc16 = x.d;
+      f.round16 = t16 != nullptr;
+      ln_xchg_args(x, f);
+      return ln_xchg_launch<false, EPI_RES_LN>(x, f, only16(x, in));
+    };
     if (t16 != nullptr) {
+      // (precision 2 on the big tile: the pre-norm output never leaves the registers -- better than its bf16 round trip; the 2048-token regime
+      //  keeps the bf16-stored form its parity bars were written for)
+      if (ln_xchg_tile(g) == 128 && try_fused()) return 0;
       g.C = nullptr; g.C16 = t16; g.ldc16 = x.d;
       need16(gemm_on_big_kernel<false, EPI_STORE>(g), "Linear (+ LayerNorm) with a bf16-only output (precision 2)");
       gemm_launch<false, false, EPI_STORE>(g, x.s);
@@ -828,15 +863,7 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
                 x.prm + gamma_off + bo, out, xhat, rstd, x.M, x.d, x.d, x.d, x.d, t16, (const uint16_t*)t16);
       return 0;
     }
-    if (!second && ln_xchg(x)) {
-      // ONE launch: the Linear on 64x64 tiles, dropout + residual + LayerNorm in its epilogue (row statistics through the in-launch exchange)
-      GemmArgs f = g;
-      f.res = res; f.ldres = x.d; f.gamma = x.prm + gamma_off; f.beta = x.prm + gamma_off + bo;
-      f.aux = xhat; f.aux2 = rstd; f.drop = mk_drop(x, site);
-      f.C16 = sh_act(x, out); f.ldc16 = x.d;
-      ln_xchg_args(x, f);
-      if (ln_xchg_launch<false, EPI_RES_LN>(x, f, only16(x, in))) return 0;
-    }
+    if (try_fused()) return 0;
     gemm_launch<false, false, EPI_STORE>(g, x.s);
     if (second) {
       gt_prof_tag("ln_fwd", 0, 24.0 * x.M * x.d);
@@ -1028,18 +1055,20 @@ extern "C" int gt_set_seq(int on) { g_seq = on != 0; return 0; }
 // the MFMA rate idle.
 static int g_seq_split = -1;
 extern "C" int gt_set_seq_split(int on) { g_seq_split = on < 0 ? -1 : on != 0; return 0; }
+// CUs of the CURRENT device (the caller's torch device; cached per device ordinal: a process may drive several GPUs)
 static int seq_cu_count() {
-  static int n = 0;
-  if (n == 0) {
 #ifdef GT_EMU
-    n = 256;
+  return 256;
 #else
-    int dev = 0;
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
     hipDeviceProp_t prop;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-#endif
+    cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  return n;
+  return cached[dev];
+#endif
 }
 static bool seq_split(const gt_config& c) {
   if (c.d_model != 128 && c.d_model != 32) return false;
@@ -1074,7 +1103,7 @@ static bool seq_ride(const gt_config& c) {
 static int g_seq_quad = -1;
 extern "C" int gt_set_seq_quad(int on) { g_seq_quad = on < 0 ? -1 : on != 0; return 0; }
 static bool seq_quad(const gt_config& c) {
-  if (c.d_model != 128 || c.dim_ff % 32 != 0 || !seq_split(c) || 4 * c.batch > seq_cu_count()) return false;
+  if (c.d_model != 128 || c.dim_ff % 32 != 0 || !seq_split(c) || 4 * c.batch > seq_cu_count() || (c.flags & GT_CFG_NO_QUAD)) return false;
   if (g_seq_quad < 0) { const char* e = getenv("GT_SEQ_QUAD"); if (e) g_seq_quad = e[0] != '0'; }
   return g_seq_quad != 0;
 }
@@ -1469,6 +1498,7 @@ static int backward_impl(const gt_config* cfg, const float* params, float* grads
   x.side = side_stream();
   LnJobs lnjobs;
   lnjobs.n = 0; lnjobs.N = d; lnjobs.bump = nullptr;
+  { const int64_t eo = x.W.rowx >= 0 ? x.W.rowx : x.W.seq_xchg; lnjobs.err = eo >= 0 ? reinterpret_cast<unsigned*>(ws + eo) : nullptr; }
   x.ln = &lnjobs;
   const int top = L + Ld - 1;                       // global index of the last layer
   const GradSplit split = grad_split(*cfg, P);
@@ -1732,22 +1762,24 @@ extern "C" int gt_backward(const gt_config* cfg, const float* params, float* gra
 
 // ------------------------------------------------------------------------------------ optimizer
 // step_advanced: the caller's previous launch already advanced step / opt_step (fused train step, see LnJobs::bump)
+// err / guard: the fail-safe of the in-launch exchanges (gt_misc.h, sgd_kernel) -- only callers that hold the configuration's WHOLE flat buffers
+// and its workspace pass them (gt_train_step, gt_optimizer_step_ws); the public gt_optimizer_step is a plain update of n elements
 static int optimizer_step_impl(int algo, float* params, float* grads, float* m, float* v, int64_t n, gt_step_state* state,
-                               int zero_grads, gt_stream_t stream, int step_advanced, const unsigned* err = nullptr) {
+                               int zero_grads, gt_stream_t stream, int step_advanced, unsigned* err = nullptr, int guard = 0) {
   if (!params || !grads || !state || n <= 0) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 1023) / 1024);
   if (algo == 0) {
     gt_prof_tag("optimizer", 0, 12.0 * n);
-    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, (const gt_step_state*)state, zero_grads, err);
+    gt_launch(sgd_kernel, dim3(blocks), dim3(256), s, params, grads, n, (const gt_step_state*)state, zero_grads, (const unsigned*)err, guard);
   } else if (algo == 1) {
     if (!m || !v) return gt_fail("gt_optimizer_step: adam needs m and v");
     gt_prof_tag("optimizer", 0, 28.0 * n);
-    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state, zero_grads, step_advanced, err);
+    gt_launch(adam_kernel, dim3(blocks), dim3(256), s, params, grads, m, v, n, (const gt_step_state*)state, zero_grads, step_advanced, (const unsigned*)err, guard);
   } else {
     return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
   }
-  if (!step_advanced) gt_launch(step_inc_kernel, dim3(1), dim3(64), s, state);
+  if (!step_advanced) gt_launch(step_inc_kernel, dim3(1), dim3(64), s, state, err, guard ? (const float*)(grads + n - 1) : (const float*)nullptr);
   return launch_status("gt_optimizer_step");
 }
 extern "C" int gt_optimizer_step(int algo, float* params, float* grads, float* m, float* v, int64_t n, gt_step_state* state,
@@ -1765,8 +1797,8 @@ extern "C" int gt_optimizer_step_ws(const gt_config* cfg, int algo, float* param
   if (!use_seq(*cfg) || !zero_grads || !ws) {
     const WLayout W0 = ws ? ws_layout(*cfg) : WLayout();
     const int64_t eo = W0.rowx >= 0 ? W0.rowx : W0.seq_xchg;                                                  // (the error word of whichever exchange region the shape has)
-    const unsigned* err = (ws && eo >= 0) ? reinterpret_cast<const unsigned*>(ws + eo) : nullptr;
-    return optimizer_step_impl(algo, params, grads, m, v, P.total, state, zero_grads, stream, 0, err);
+    unsigned* err = (ws && eo >= 0) ? reinterpret_cast<unsigned*>(ws + eo) : nullptr;
+    return optimizer_step_impl(algo, params, grads, m, v, P.total, state, zero_grads, stream, 0, err, 1);
   }
   if (!params || !grads || !state) return gt_fail("gt_optimizer_step: params / grads / state must not be NULL");
   if (algo != 0 && algo != 1) return gt_fail("optimizer algo %d unknown (0 = sgd, 1 = adam)", algo);
@@ -1776,7 +1808,8 @@ extern "C" int gt_optimizer_step_ws(const gt_config* cfg, int algo, float* param
   const SeqArgs a = mk_seq(x, nullptr, nullptr, nullptr);
   gt_prof_tag("optimizer", 0, (algo ? 28.0 : 12.0) * P.total + 8.0 * cfg->n_enc_layers * x.W.pack_stride);
   gt_seq_launch_update_pack(a, algo, params, grads, m, v, P.total, state, 0, (hipStream_t)stream);
-  gt_launch(step_inc_kernel, dim3(1), dim3(64), (hipStream_t)stream, state);
+  gt_launch(step_inc_kernel, dim3(1), dim3(64), (hipStream_t)stream, state, x.W.seq_xchg >= 0 ? reinterpret_cast<unsigned*>(ws + x.W.seq_xchg) : (unsigned*)nullptr,
+            (const float*)(grads + P.total - 1));
   return launch_status("gt_optimizer_step_ws");
 }
 
@@ -1845,7 +1878,7 @@ extern "C" int gt_train_step(const gt_config* cfg, int algo, float* params, floa
     }
     const int64_t eo = W.rowx >= 0 ? W.rowx : W.seq_xchg;
     if (optimizer_step_impl(algo, params, grads, m, v, P.total, state, 1, stream, 1,
-                            eo >= 0 ? reinterpret_cast<const unsigned*>(ws + eo) : nullptr)) return -1;
+                            eo >= 0 ? reinterpret_cast<unsigned*>(ws + eo) : nullptr, 1)) return -1;
   }
   return 0;
 }

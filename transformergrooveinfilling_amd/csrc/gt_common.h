@@ -190,3 +190,13 @@ __device__ __forceinline__ void gt_loss_elem(const float h, const float v, const
   if (WRT_LOGITS) { dv *= v * (1.0f - v); dO *= (0.5f - 2.0f * o * o); }
   dh = (gt_sigmoid(h) - yh) * pen * invM;
 }
+
+// The counters after an update: the dropout stream always moves on (the batch was consumed); Adam's t only when the update was APPLIED --
+// with the exchange region's error word set (err[0]; nullptr: the caller has none) or a non-zero data-parallel guard element the update kernels
+// apply nothing, and err[1] counts the skipped update instead (read by the host beside the word: StepEngine.skipped_updates).
+__device__ __forceinline__ void gt_bump_counters(gt_step_state* st, unsigned* err, const float* guard) {
+  const bool skip = (err != nullptr && err[0] != 0u) || (guard != nullptr && *guard != 0.f);
+  st->step += 1u;
+  if (!skip) st->opt_step += 1u;
+  else if (err != nullptr) err[1] += 1u;
+}

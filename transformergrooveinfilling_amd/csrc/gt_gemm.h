@@ -77,6 +77,8 @@ struct GemmArgs {
   // gt_gemm64.h, LayerNorm-fused epilogues on 64x64 tiles: the row exchange region of the workspace (header: error word, launch serial,
   // ticket; then [M][N / 32 parts][2] tagged 8-byte granules) and the bound of its polling loop
   unsigned* rowx; int spin_max;
+  int round16;               // EPI_RES_LN on the big tile at precision 2: the Linear output (acc + bias) is rounded to bf16 before dropout / residual / norm --
+                             // the value the un-fused form stores in bf16 ahead of its LayerNorm pass (what torch.autocast hands on)
 };
 
 template <int ROWS, int COLS, int NT>

@@ -100,6 +100,12 @@ __device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f
   }
 }
 
+// LayerNorm epilogues on this tile through the in-launch row exchange (round 6; defined in gt_gemm64.h beside the 64x64 form)
+template <int EPI, int NPH>
+__device__ __forceinline__ void gemm32_ln_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
+                                                   const int r32, const int h, const uint32_t (&seq)[2], float* smem);
+__device__ __forceinline__ void g128_seq(const GemmArgs& g, const int m0, const int n0, const int wm, const int wn, const int r32, const int h, uint32_t (&seq)[2]);
+
 // One 128x128 output tile: rows m0.., columns n0.., contraction range [kbeg, kbeg + nk * 32) (nk even, >= 2).
 // AKM / BKM as in gt_gemm.h: operand stored with the contraction index as its ROW index (weight gradients: both; dgrad: B).
 // PREC = 1 (gt_config.precision = 1): the same staging, fp32 LDS images in source orientation; the operands are rounded to bf16
@@ -119,6 +125,8 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
   constexpr int SA_STR = Cfg::str<AKM>(), SA_SZ = Cfg::sz<AKM>(), SB_STR = Cfg::str<BKM>(), SB_SZ = Cfg::sz<BKM>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
+  uint32_t xtag[2] = {0u, 0u};   // LayerNorm epilogues: this launch's sequence numbers = the lane's OWN granules' + 1 (read before anything is published)
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) g128_seq(g, m0, n0, wm, wn, r32, h, xtag);
 
   // staging: 4 float4 per thread and operand per slab.  A: chunk (row, 4 k);  B: chunk (n, 4 k) or, BKM, (k, 4 n)
   constexpr int PER = 4;
@@ -303,7 +311,12 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
         }
     return;
   }
-  gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h);
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) {
+    if (g.N == 512) gemm32_ln_epilogue<EPI, 4>(g, acc, m0, n0, wm, wn, r32, h, xtag, smem);
+    else            gemm32_ln_epilogue<EPI, 2>(g, acc, m0, n0, wm, wn, r32, h, xtag, smem);
+  } else {
+    gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h);
+  }
 #undef G32_LD
 #undef G32_ST
 #undef G32_RD
@@ -337,6 +350,8 @@ __global__ __launch_bounds__(256, 2) void gemm32h_kernel(GemmArgs g) {
   const int m0 = (bid / gx) * 128, n0 = (bid % gx) * 128, nk = g.K / BK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
+  uint32_t xtag[2] = {0u, 0u};
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) g128_seq(g, m0, n0, wm, wn, r32, h, xtag);
   G32hRegs a0[PER], b0[PER], a1[PER], b1[PER], a2[PER], b2[PER];
   const uint16_t* pa[PER];
   const uint16_t* pb[PER];
@@ -398,7 +413,13 @@ __global__ __launch_bounds__(256, 2) void gemm32h_kernel(GemmArgs g) {
 #undef G32H_SLAB
 #undef G32H_LD
 #undef G32H_ST
-  gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h);
+  if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) {
+    float* const fsm = reinterpret_cast<float*>(sm);             // (4 x 128 x 72 bf16 = 73728 bytes: room for the partials' 34 KB)
+    if (g.N == 512) gemm32_ln_epilogue<EPI, 4>(g, acc, m0, n0, wm, wn, r32, h, xtag, fsm);
+    else            gemm32_ln_epilogue<EPI, 2>(g, acc, m0, n0, wm, wn, r32, h, xtag, fsm);
+  } else {
+    gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h);
+  }
 }
 // host side: shadows present, interior tiles, 16-byte rows
 static inline bool gemm32h_ok(const GemmArgs& g, int epi) {

@@ -138,10 +138,13 @@ __device__ __forceinline__ bool g64_collect(const unsigned long long* base, cons
 #ifdef GT_EMU
   load_all();                                                    // (missing: G64_EMU_AGREE re-runs the workgroup after the others)
 #else
+  // (a word raised by an EARLIER launch -- the host has not fallen back yet -- means this launch's partners may be as absent as that one's:
+  //  one look, no spin; every update is skipped anyway until the host has seen the word)
   int spins = 0;
   for (;;) {
     load_all();
     if (__all(ok)) break;                                        // (wave-uniform exit)
+    if (spins == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spins = spin_max;       // (looked at only once the first poll failed)
     if (++spins > spin_max) { if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     __builtin_amdgcn_s_sleep(2);
   }
@@ -302,6 +305,277 @@ __device__ __forceinline__ void gemm64_ln_epilogue(const GemmArgs& g, const f32x
     }
   }
 }
+// ================================================================================================================ the same on 128x128 tiles
+// Round 6: the LayerNorm epilogues on the BIG tile (gemm32_kernel / gemm32h_kernel of gt_gemm32.h).  At d_model 512 / 16384 tokens (bs 512 on one
+// GPU) an N = 512 Linear is 128 x 4 = 512 tiles of 128x128 -- exactly the two workgroups per CU the kernels keep resident, so the whole grid is
+// co-resident there too -- and the norm was still a row pass of its own: 24 passes per step, 7.7 % of the fp32 step and 21 % of the bf16 one
+// (3.7 GB of HBM traffic).  Same protocol as above, other geometry: a wave owns 64 rows x 64 columns (2 x 2 blocks of 32x32), so a PART is 64
+// columns (N / 64 parts per row), a lane publishes one granule per row block ta (half 0: mean / sum g, half 1: M2 / sum g xhat of the wave's
+// 64 columns) and combines N / 64 parts x 2 values per row, two rows per lane.  Granules of a 128-row block: [part][4 row quarters][2 values]
+// [32 rows] -- a wave publishes 512 contiguous bytes per ta; the region is the one gt_rowx_floats sizes (this layout takes half of it).
+// A shape takes ONE of the two geometries for good (by its tile count), so every granule in use still advances by exactly one per launch.
+__device__ __forceinline__ unsigned long long* g128_rowx(const GemmArgs& g, const int m0) {
+  return reinterpret_cast<unsigned long long*>(g.rowx + GT_ROWX_HDR) + (size_t)(m0 >> 7) * (g.N / 64) * 256;
+}
+// this wave's sequence numbers (one per ta), from the lane's OWN granules
+__device__ __forceinline__ void g128_seq(const GemmArgs& g, const int m0, const int n0, const int wm, const int wn, const int r32, const int h, uint32_t (&seq)[2]) {
+  const unsigned long long* q = g128_rowx(g, m0) + (size_t)((n0 >> 6) + wn) * 256 + (wm * 2) * 64 + h * 32 + r32;
+  seq[0] = g64_seq(q); seq[1] = g64_seq(q + 64);
+}
+// both rows of a lane in ONE polling loop: parts [h NG / 2, (h + 1) NG / 2) of rows (quarter 2 wm + ta), (value 0, value 1) each
+template <int NG>
+__device__ __forceinline__ bool g128_collect(const unsigned long long* base, const int h, const uint32_t (&seq)[2], float (&v)[2][NG], unsigned* err, const int spin_max) {
+  unsigned long long w[2][NG];
+  bool ok = true;
+  auto load_all = [&]() {
+    ok = true;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+      for (int i = 0; i < NG / 2; ++i) {
+        const unsigned long long* src = base + (size_t)(h * (NG / 2) + i) * 256 + ta * 64;      // part stride: [4 quarters][2 values][32 rows]
+        w[ta][2 * i] = g64_ld(src); w[ta][2 * i + 1] = g64_ld(src + 32);
+        ok = ok && (uint32_t)(w[ta][2 * i] >> 32) == seq[ta] && (uint32_t)(w[ta][2 * i + 1] >> 32) == seq[ta];
+      }
+  };
+#ifdef GT_EMU
+  load_all();
+#else
+  int spins = 0;
+  for (;;) {
+    load_all();
+    if (__all(ok)) break;
+    if (spins == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spins = spin_max;
+    if (++spins > spin_max) { if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+#endif
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int j = 0; j < NG; ++j) v[ta][j] = gt_u2f((uint32_t)w[ta][j]);
+  return ok;
+}
+// NPH = N / 128 column tiles per row block (2: d_model 256, 4: d_model 512).  acc: the wave's 2 x 2 blocks in the store epilogue's lane map
+// (lane (r32, h): row 32 ta + r32 of the wave's 64, registers 4 q + j of block tb = column 32 tb + 8 q + 4 h + j of its 64).
+// smem: the operand buffers, free behind the main loop (>= 4 x 2080 + 256 floats: one [32][64 + 1] transpose area per wave + the meeting point).
+template <int EPI, int NPH>
+__device__ __forceinline__ void gemm32_ln_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
+                                                   const int r32, const int h, const uint32_t (&seq)[2], float* smem) {
+  constexpr int N = 128 * NPH, NG = 2 * NPH;                  // NG: granules per lane and row = N / 64 parts, half of them per lane half, x 2 values
+  const int row0 = m0 + wm * 64 + r32, cb = n0 + wn * 64 + 4 * h;          // rows row0 + 32 ta; columns cb + 32 tb + 8 q + j
+  unsigned* const xerr = g.rowx;
+  unsigned long long* const xrb = g128_rowx(g, m0);
+  unsigned long long* const mine = xrb + (size_t)((n0 >> 6) + wn) * 256 + (wm * 2) * 64 + h * 32 + r32;       // + 64 ta
+  const unsigned long long* const theirs = xrb + (wm * 2) * 64 + r32;                                          // + part * 256 + 64 ta (+ 32: value 1)
+  const uint32_t dkey = gt_drop_key(g.drop);
+  const float invN = 1.0f / (float)N;
+  f32x4 ga[2][4];
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ga[tb][q] = *reinterpret_cast<const f32x4*>(g.gamma + cb + 32 * tb + 8 * q);
+  if constexpr (EPI == EPI_RES_LN) {
+    // z = drop(acc + bias) + res (left in acc);  y = LN(z) gamma + beta;  aux = xhat, aux2 = rstd, C16 = bf16(y)
+    {
+      f32x4 bi[2][4];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bi[tb][q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + cb + 32 * tb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta) {
+        const int row = row0 + 32 * ta;
+        f32x4 re[2][4];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            re[tb][q] = g.res ? *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + cb + 32 * tb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float s = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float lin = acc[ta][tb][4 * q + j] + bi[tb][q][j];
+              if (g.round16) lin = gt_bf2f(gt_f2bf(lin));
+              const float v = lin * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + cb + 32 * tb + 8 * q + j)) + re[tb][q][j];
+              acc[ta][tb][4 * q + j] = v; s += v;
+            }
+        s += __shfl_xor(s, 32);
+        const float mw = s * (1.0f / 64.0f);
+        float qq = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { const float d = acc[ta][tb][e] - mw; qq += d * d; }
+        qq += __shfl_xor(qq, 32);
+        g64_publish(mine + 64 * ta, h ? qq : mw, seq[ta]);          // (lane half 0: the means, half 1: M2)
+      }
+    }
+    G64_EMU_PUBLISHED();
+    float pv[2][NG];
+    const bool gotf = g128_collect<NG>(theirs, h, seq, pv, xerr, g.spin_max);
+    G64_EMU_AGREE(gotf)
+    f32x4 be[2][4];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) be[tb][q] = *reinterpret_cast<const f32x4*>(g.beta + cb + 32 * tb + 8 * q);
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta) {
+      const int row = row0 + 32 * ta;
+      // Chan's merge over this half's parts, in order (64 columns each), then the two halves, lower columns first on both lanes
+      float mean = pv[ta][0], m2 = pv[ta][1], cnt = 64.f;
+#pragma unroll
+      for (int i = 1; i < NG / 2; ++i) {
+        const float d = pv[ta][2 * i] - mean, n = cnt + 64.f;
+        mean += d * (64.f / n);
+        m2 += pv[ta][2 * i + 1] + d * d * (cnt * 64.f / n);
+        cnt = n;
+      }
+      const float om = __shfl_xor(mean, 32), o2 = __shfl_xor(m2, 32);
+      const float ma = h ? om : mean, a2 = h ? o2 : m2, mb = h ? mean : om, b2 = h ? m2 : o2;
+      const float d = mb - ma;
+      mean = ma + d * 0.5f;
+      m2 = a2 + b2 + d * d * (cnt * 0.5f);
+      const float rstd = 1.0f / sqrtf(m2 * invN + GT_LN_EPS);
+      if (n0 == 0 && wn == 0 && h == 0) g.aux2[row] = rstd;
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = cb + 32 * tb + 8 * q;
+          f32x4 xh, yv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { xh[j] = (acc[ta][tb][4 * q + j] - mean) * rstd; yv[j] = xh[j] * ga[tb][q][j] + be[tb][q][j]; }
+          *reinterpret_cast<f32x4*>(g.aux + (size_t)row * N + col) = xh;
+          *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = yv;
+          if (g.C16 != nullptr) {
+            uint2 pk;
+            pk.x = (uint32_t)gt_f2bf(yv[0]) | ((uint32_t)gt_f2bf(yv[1]) << 16); pk.y = (uint32_t)gt_f2bf(yv[2]) | ((uint32_t)gt_f2bf(yv[3]) << 16);
+            *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = pk;
+          }
+        }
+    }
+  } else {
+    // d = acc (+ res) (left in acc);  dz = LNbwd(d) with (xhat, rstd, gamma);  C2 = dz dropmask;  C16 = bf16 of the masked copy (or of dz);
+    // ln_part[128-row block][2][N]: this tile's column sums of d xhat and d
+    f32x4 xh[2][2][4];
+    float rs[2];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta) {
+      const int row = row0 + 32 * ta;
+      f32x4 re[2][4];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          re[tb][q] = g.res ? *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + cb + 32 * tb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+          xh[ta][tb][q] = *reinterpret_cast<const f32x4*>(g.xhat + (size_t)row * N + cb + 32 * tb + 8 * q);
+        }
+      rs[ta] = g.rstd[row];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float dv = acc[ta][tb][4 * q + j] + re[tb][q][j], gd = dv * ga[tb][q][j];
+            acc[ta][tb][4 * q + j] = dv; s1 += gd; s2 += gd * xh[ta][tb][q][j];
+          }
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      g64_publish(mine + 64 * ta, h ? s2 : s1, seq[ta]);
+    }
+    G64_EMU_PUBLISHED();
+    float pv[2][NG];
+    const bool gotb = g128_collect<NG>(theirs, h, seq, pv, xerr, g.spin_max);
+    G64_EMU_AGREE(gotb)
+    const bool masked = g.C2 != nullptr || (g.C16 != nullptr && g.drop.thr != 0u && g.drop.st != nullptr);
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta) {
+      const int row = row0 + 32 * ta;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NG / 2; ++i) { t1 += pv[ta][2 * i]; t2 += pv[ta][2 * i + 1]; }
+      const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+      const float m1 = (h ? o1 + t1 : t1 + o1) * invN, m2 = (h ? o2 + t2 : t2 + o2) * invN;       // (lower columns first on both lanes)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = cb + 32 * tb + 8 * q;
+          f32x4 v, vm;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = rs[ta] * (acc[ta][tb][4 * q + j] * ga[tb][q][j] - m1 - xh[ta][tb][q][j] * m2);
+            vm[j] = masked ? v[j] * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + col + j)) : v[j];
+          }
+          *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
+          if (g.C2 != nullptr) *reinterpret_cast<f32x4*>(g.C2 + (size_t)row * g.ldc + col) = vm;
+          if (g.C16 != nullptr) {
+            uint2 pk;
+            pk.x = (uint32_t)gt_f2bf(vm[0]) | ((uint32_t)gt_f2bf(vm[1]) << 16); pk.y = (uint32_t)gt_f2bf(vm[2]) | ((uint32_t)gt_f2bf(vm[3]) << 16);
+            *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = pk;
+          }
+        }
+    }
+    // dgamma / dbeta partials of this 128 x 128 tile: per wave, (d xhat, d) of its 64 x 64 block go through a [32 rows][64 + 1] area of its own
+    // (4 passes: 2 quantities x 2 row blocks; lane c then sums column c over the 32 rows), the two row-waves of a column half meet in LDS
+    __syncthreads();                                             // (every wave is past its last operand read)
+    constexpr int TS = 65, WSZ = 32 * TS;
+    float* const sw = smem + (wm * 2 + wn) * WSZ;
+    const int lane = h * 32 + r32;
+    float cg = 0.f, cbt = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int ta = pass >> 1, which = pass & 1;               // which 0: d xhat (dgamma), 1: d (dbeta)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            sw[r32 * TS + 32 * tb + 8 * q + 4 * h + j] = which ? acc[ta][tb][4 * q + j] : acc[ta][tb][4 * q + j] * xh[ta][tb][q][j];
+      GT_WAVE_SYNC();
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) a += sw[r * TS + lane];
+      if (which) cbt += a; else cg += a;
+      GT_WAVE_SYNC();
+    }
+    __syncthreads();
+    float* const sp = smem + 4 * WSZ;                           // [2 column halves][2][64]: the lower row-wave's sums
+    if (wm == 1) { sp[(wn * 2) * 64 + lane] = cg; sp[(wn * 2 + 1) * 64 + lane] = cbt; }
+    __syncthreads();
+    if (wm == 0) {
+      g.ln_part[((size_t)(m0 >> 7) * 2) * N + n0 + wn * 64 + lane] = cg + sp[(wn * 2) * 64 + lane];
+      g.ln_part[((size_t)(m0 >> 7) * 2 + 1) * N + n0 + wn * 64 + lane] = cbt + sp[(wn * 2 + 1) * 64 + lane];
+    }
+  }
+}
+// host side: N = d_model 256 / 512 and the whole grid of 128x128 tiles resident at once (two workgroups per CU), from the tile count at which the
+// big tile is the Linear's kernel anyway (GT_T128_BIG_MIN; d_model 512: 8192 .. 16384 tokens, d_model 256: 12288 .. 32768)
+#ifndef GT_LN128_MIN
+#define GT_LN128_MIN GT_T128_BIG_MIN
+#endif
+static inline bool gemm32_ln_shape(const GemmArgs& g, int cus) {
+  static const long lo = gt_env_long("GT_LN128_MIN", GT_LN128_MIN);
+  const long tiles = (long)(g.M / 128) * (g.N / 128);
+  return (g.N == 256 || g.N == 512) && g.M % 128 == 0 && tiles <= 2l * cus && tiles >= lo;
+}
+static inline bool gemm32_ln_ok(const GemmArgs& g, int epi) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!g.rowx || !g.gamma || !al16(g.gamma) || (g.res && ((g.ldres & 3) || !al16(g.res))) || !g.C || (g.ldc & 3) || !al16(g.C) || g.accumulate) return false;
+  if (g.C16 && ((g.ldc16 & 3) || (reinterpret_cast<uintptr_t>(g.C16) & 7))) return false;
+  if (epi == EPI_RES_LN && (!g.beta || !al16(g.beta) || !g.aux || !al16(g.aux) || !g.aux2 || (g.bias && !al16(g.bias)))) return false;
+  if (epi == EPI_RES_LNBWD && (!g.xhat || !al16(g.xhat) || !g.rstd || !g.ln_part || (g.C2 && !al16(g.C2)))) return false;
+  return true;
+}
+
 // host side: the fused LayerNorm epilogues apply when the Linear itself can take the 64x64 kernels, N = d_model is 256 or 512 and the
 // WHOLE grid is resident at once (two workgroups per CU)
 // (forced: gt_set_ln_exchange(1) -- tests on small shapes: no lower bound on the tile count)

@@ -393,13 +393,14 @@ struct LnJobs {
   int n, N;
   gt_step_state* bump;       // fused train step: this launch (the last of backward; nothing after it regenerates a dropout mask) also
                              // advances step / opt_step -- the optimizer that follows is told so -- saving the step_inc launch
+  unsigned* err;             // ... looking at the exchange region's error word (nullptr: none) as the update will: gt_bump_counters
   LnJob j[GT_LN_JOBS_MAX];
 };
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnJobs jobs) {
   // 16 waves split the partial rows; every lane has 8 independent loads in flight per trip (a 4-wave version walking 16
   // dependent trips took 8.4 us for 3.7 MB of partials: latency, not bandwidth).  Fixed summation order -> deterministic.
   __shared__ float s[16][64];
-  if (jobs.bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { jobs.bump->step += 1u; jobs.bump->opt_step += 1u; }
+  if (jobs.bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) gt_bump_counters(jobs.bump, jobs.err, nullptr);
   const LnJob jb = jobs.j[blockIdx.y];
   const float* const zp = gt_zero_ptr();
   const int N = jobs.N, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -521,34 +522,38 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
 // zero_grads: the gradient is consumed and left zeroed (the next backward accumulates into it: no memset node).
 // (step / opt_step advance in step_inc_kernel: a last-workgroup ticket inside these kernels was measured SLOWER --
 // ~600 arrivals on one counter serialise for longer than the ~4 us a separate launch costs.)
-__global__ void step_inc_kernel(gt_step_state* st) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1u; st->opt_step += 1u; }
+// (gt_bump_counters: gt_common.h)
+__global__ void step_inc_kernel(gt_step_state* st, unsigned* err, const float* guard) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) gt_bump_counters(st, err, guard);
 }
 
 // Fail-safe of the in-launch exchanges (QUAD pair exchange of gt_seq.h, row exchange of gt_gemm64.h): with the region's error word set
 // (err; nullptr: this caller has none), or with a non-zero GUARD element g[n - 1] -- padding behind the 27-float output bias, zero in a
 // single process; a data-parallel host writes its error flag there before the gradient all-reduce, so every rank sees the sum -- the
 // update applies NOTHING: parameters and moments stay, the consumed gradients are cleared.  n - 1 itself is neither updated nor cleared.
+// guard = 0 (the public gt_optimizer_step: any n, a sub-range, an unpadded buffer): a plain update of all n elements, no guard, no word.
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n, const gt_step_state* st,
-                                                  int zero_grads, const unsigned* err = nullptr) {
-  const bool skip = (err != nullptr && *err != 0u) || g[n - 1] != 0.f;
+                                                  int zero_grads, const unsigned* err = nullptr, int guard = 0) {
+  const bool skip = (err != nullptr && *err != 0u) || (guard && g[n - 1] != 0.f);
   const float k = skip ? 0.f : st->lr * st->grad_scale;
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i + 4 < n) {
+  const int64_t nu = guard ? n - 1 : n;                  // elements this update owns
+  if (i + 4 <= nu) {
     float4 pv = *reinterpret_cast<float4*>(p + i);
     const float4 gv = *reinterpret_cast<const float4*>(g + i);
     if (!skip) { pv.x -= k * gv.x; pv.y -= k * gv.y; pv.z -= k * gv.z; pv.w -= k * gv.w; }
     *reinterpret_cast<float4*>(p + i) = pv;
     if (zero_grads) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    for (int64_t j = i; j < n - 1; ++j) { if (!skip) p[j] -= k * g[j]; if (zero_grads) g[j] = 0.f; }
+    for (int64_t j = i; j < nu; ++j) { if (!skip) p[j] -= k * g[j]; if (zero_grads) g[j] = 0.f; }
   }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const gt_step_state* st, int zero_grads,
-                                                   int step_advanced, const unsigned* err = nullptr) {
-  const bool skip = (err != nullptr && *err != 0u) || g[n - 1] != 0.f;        // (see sgd_kernel)
+                                                   int step_advanced, const unsigned* err = nullptr, int guard = 0) {
+  const bool skip = (err != nullptr && *err != 0u) || (guard && g[n - 1] != 0.f);        // (see sgd_kernel)
+  const int64_t nu = guard ? n - 1 : n;
   const float b1 = st->beta1, b2 = st->beta2, t = (float)(st->opt_step + (step_advanced ? 0u : 1u));
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = st->lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int64_t i = i0 + u;
-    if (i < n - 1) {
+    if (i < nu) {
       if (!skip) {
         const float gi = g[i] * gs;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;

@@ -136,6 +136,7 @@ __device__ __forceinline__ f32x4 seq_xchg_get(unsigned long long* slot, const in
   for (int j = 0; j < 4; ++j) { w[j] = slot[j * GT_SEQ_NT + tid]; ok = ok && (uint32_t)(w[j] >> 32) == GT_XTAG_NOW; }
   if (!ok) emu::block_retry();                               // the partner has not run yet: this workgroup is run again after it
 #else
+  // (a word raised by an EARLIER launch: one look, no spin -- gt_gemm64.h, g64_collect)
   int spins = 0;
   for (;;) {
     bool ok = true;
@@ -145,6 +146,7 @@ __device__ __forceinline__ f32x4 seq_xchg_get(unsigned long long* slot, const in
       ok = ok && (uint32_t)(w[j] >> 32) == GT_XTAG;
     }
     if (__all(ok)) break;                                      // (wave-uniform exit: the lanes of a wave leave together)
+    if (spins == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spins = spin_max;       // (looked at only once the first poll failed)
     if (++spins > spin_max) { if ((tid & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     __builtin_amdgcn_s_sleep(1);
   }

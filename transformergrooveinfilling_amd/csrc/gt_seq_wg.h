@@ -376,7 +376,7 @@ __global__ __launch_bounds__(GT_SEQ_NT_WG) void seq_tail_kernel(SeqArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[GT_WG_LDS];
   __shared__ float sb[8 * 64];
   const int tid = threadIdx.x;
-  if (a.bump != nullptr && blockIdx.x == 0 && tid == 0) { a.bump->step += 1u; a.bump->opt_step += 1u; }
+  if (a.bump != nullptr && blockIdx.x == 0 && tid == 0) gt_bump_counters(a.bump, a.xchg >= 0 ? reinterpret_cast<unsigned*>(a.ws + a.xchg) : nullptr, nullptr);
   const int M = a.B * 32, ks = a.tail_ksplit;
   int blk = blockIdx.x;
   if (a.tail_phase <= a.L) {       // (a debug launch names one phase's list: its matrix tiles alone, over all tokens)

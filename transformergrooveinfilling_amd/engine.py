@@ -29,7 +29,8 @@ PREDICT_WS_BYTES = 32 << 30            # ... the chunk grows (x2) while its work
 PREDICT_WS_KEEP = 4 << 30              # predict() keeps a workspace between calls only up to this size (a per-epoch evaluation must not pin tens of GiB)
 MAX_GRAPHS = 4                         # captured step graphs kept per slot (least recently used dropped first)
 MAX_SLOTS = 6                          # per-batch-size step slots kept (least recently created dropped first; the engine's own batch size stays)
-XCHG_POLL_EVERY = 32                   # train steps between two asynchronous reads of the QUAD pair exchange's error word (see poll_exchange)
+XCHG_POLL_EVERY = 16                   # train steps between two asynchronous reads of the in-launch exchanges' error word (see poll_exchange; the first
+                                       # read starts with the slot's first step)
 
 
 def _ptr(t):
@@ -44,7 +45,7 @@ class _Slot:
         d = eng.dims
         self.B = B
         self.cfg = _lib.make_config(B, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
-                                    d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
+                                    d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"], eng.cfg_flags)
         self.layout_epoch = eng.lib.cdll.gt_layout_epoch()      # (the workspace below is laid out for the switches in force NOW: StepEngine.slot)
         self.ws = torch.empty(eng.lib.workspace_floats(self.cfg), **f32)
         eng.lib.call("gt_workspace_init", ctypes.byref(self.cfg), _ptr(self.ws), eng.stream)   # (zeroes the regions whose protocol relies on it)
@@ -60,9 +61,10 @@ class _Slot:
         self.fwd_id = 0                # bumped by every call that overwrites the saved activations (see StepEngine.forward)
         self.pack_epoch = -1           # StepEngine._pepoch at which this workspace's fragment-ordered weight copies were written
         self.xchg_off = None           # workspace offset of the QUAD pair-exchange region's error word (-1: none; looked up lazily)
-        self.xchg_host = None          # pinned int32 the error word is copied into, asynchronously, every XCHG_POLL_EVERY-th train step
-        self.xchg_event = None         # ... the event behind that copy
+        self.xchg_host = None          # pinned [error word, skipped updates] (data-parallel: the all-reduced guard element) copied asynchronously,
+        self.xchg_event = None         # every XCHG_POLL_EVERY-th train step ... and the event behind that copy
         self.xchg_count = 0
+        self.xchg_skipped_seen = 0     # value of the region's skipped-update counter at the last look (the counter restarts with the region)
 
 
 class _LossSlot:
@@ -143,12 +145,32 @@ class StepEngine:
         self._train_B = None           # batch size of the most recent train step (its slot is never evicted)
         self._predict_ws = {}          # chunk size -> (cfg, workspace, tgt scratch) of predict()
         self._predict_epoch = None     # gt_layout_epoch() those were sized at
-        self._ln_xchg_off = False      # the bucketed-overlap data-parallel recipe switched the LayerNorm row exchange off (see train_step)
-        self.exchange_timeouts = 0     # QUAD pair exchanges that timed out (each: updates skipped until noticed, then SPLIT schedule)
+        # gt_config.flags of every configuration this engine hands to the library (per ENGINE, not per process: train.py's evaluation engines and
+        # bench.py's second engine keep their own).  _flags_fallback: set for good once an in-launch exchange timed out (no QUAD, no row exchange);
+        # _flags_recipe: what the data-parallel recipe in force asks for (bucketed overlap: no row exchange beside a collective's workgroups)
+        self._flags_fallback, self._flags_recipe = 0, 0
+        self.exchange_timeouts = 0     # in-launch exchanges that timed out (each: updates skipped until noticed, then the exchange-free schedule)
+        self.skipped_updates = 0       # updates the device refused because of them (its own count: word 1 of the region's header), as far as seen
+        self._ar_plan, self._ar_issued = [], 0      # data-parallel: the gradient all-reduces of the step in flight, and how many were issued (autotune_dp)
+        self._bwd_slot = None          # module API: the slot of the last backward() (its workspace's error word guards the optimizer step)
+        self._fused_opt = False        # ... a GrooveSGD / GrooveAdam is bound (training._FusedMixin): the update kernel itself honours the word
         self.xchg_strict = os.environ.get("GT_XCHG_STRICT", "0") == "1"       # raise instead of recovering
         self.B = int(batch_size) if batch_size else None
         if self.B:
             self.slot(self.B)
+
+    cfg_flags = property(lambda self: self._flags_fallback | self._flags_recipe)
+
+    def _apply_flags(self):
+        """Push cfg_flags into every configuration the engine keeps; schedules change with them, so captured graphs and the per-slot
+        graph decision go (the workspace layout does not depend on them)."""
+        f = self.cfg_flags
+        for t in self._slots.values():
+            if t.cfg.flags != f:
+                t.cfg.flags = f
+                t.graphs.clear(); t.keep.clear(); t.use_graph = None
+        for cfg, _, _ in self._predict_ws.values():
+            cfg.flags = f
 
     # ---- buffers ---------------------------------------------------------------------------------
     def slot(self, B):
@@ -261,10 +283,15 @@ class StepEngine:
         the torch.optim-style front keeps them until zero_grad() like torch does.  slot: the step's slot -- its workspace then
         receives the next step's weight copies (gt_optimizer_step_ws)."""
         self._pepoch += 1
-        if slot is not None and zero_grads and self.fold_pack:
-            slot.pack_epoch, self._pver = self._pepoch, self.params._version
+        if slot is None:
+            slot = self._bwd_slot          # module API (loss.backward(); opt.step()): the slot backward() ran on
+        if slot is not None and slot.B in self._slots and self._slots[slot.B] is slot:
+            # with the configuration and its workspace at hand the update honours the exchange region's error word and the data-parallel
+            # guard element (gt_optimizer_step_ws: a timed-out exchange never reaches the parameters, Adam's t does not advance)
+            if zero_grads and self.fold_pack:
+                slot.pack_epoch, self._pver = self._pepoch, self.params._version
             self.lib.call("gt_optimizer_step_ws", ctypes.byref(slot.cfg), self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m),
-                          _ptr(self.v), _ptr(slot.ws), _ptr(self.state), 1, self.stream)
+                          _ptr(self.v), _ptr(slot.ws), _ptr(self.state), int(zero_grads), self.stream)
             return
         self.lib.call("gt_optimizer_step", self.algo, _ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v),
                       ctypes.c_int64(self.total), _ptr(self.state), int(zero_grads), self.stream)
@@ -294,15 +321,21 @@ class StepEngine:
             snap = (self.params.clone(), self.state.clone(), None if self.m is None else (self.m.clone(), self.v.clone()),
                     self.grads.clone())
             self._capturing = True                # (no GT_STEP_PACKS_CURRENT in a recorded recipe: a replay would pass it blindly)
-            try:
-                with torch.cuda.stream(side):
-                    fn()
+
+            def restore():
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 torch.cuda.synchronize(self.device)
                 self.params.copy_(snap[0]); self.state.copy_(snap[1])
                 if snap[2] is not None:
                     self.m.copy_(snap[2][0]); self.v.copy_(snap[2][1])
                 self.grads.copy_(snap[3])         # zeros for a whole-step graph (gt_train_step's precondition), else what the first half left
+            try:
+                try:
+                    with torch.cuda.stream(side):
+                        fn()
+                finally:
+                    restore()                     # (also when the warm-up raised half-way: a caller that falls back to the eager sequence
+                                                  #  must not apply part of this step twice)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     fn()
@@ -316,8 +349,10 @@ class StepEngine:
     def _dp_whole(self, s, key, whole):
         """The data-parallel step as ONE captured hipGraph (collectives included) -- with a way back: a capture that fails (a collective
         that cannot be recorded on this stack, an allocator call inside the capture) is logged once and the step, like every later one,
-        runs as the eager sequence in this same process.  Every rank issues the same collectives in the same order either way (the
-        warm-up pass and the eager sequence call exactly what the graph records), so ranks need not agree on the outcome."""
+        runs as the eager sequence in this same process.  A FIRST capture runs one real warm-up step (collectives included) before it records,
+        so it must happen on the same step on every rank: it does at the first step, and again after a recovery from an exchange time-out --
+        which is collective in a multi-rank run for exactly this reason (_recover_exchange).  When the capture itself fails on one rank, that
+        rank's eager step stands in for the replay the others run: the same collectives in the same order."""
         if not self.dp_graph_failed:
             try:
                 self._replay(s, key, whole, force=True)
@@ -333,11 +368,32 @@ class StepEngine:
                               (type(e).__name__, e), RuntimeWarning)
         whole()
 
+    def _ar(self, t, async_op=False):
+        """A gradient all-reduce of the data-parallel step (counted: autotune_dp keeps a failing rank in step with the others)."""
+        import torch.distributed as dist
+        self._ar_issued += 1
+        return dist.all_reduce(t, async_op=async_op)
+
+    def _dp_recipe(self, overlap, graph):
+        """Select a data-parallel recipe: {one all-reduce after backward | two buckets, the first under the rest of backward} x {eager
+        sequence | one hipGraph per step}.  The bucketed recipe runs a collective's workgroups beside the backward's launches, whose
+        LayerNorm row exchange needs its whole grid resident: this ENGINE's configurations then carry GT_CFG_NO_LN_XCHG (the norm as a row pass
+        of its own); captured graphs of another recipe are dropped with the flag change."""
+        self.overlap_allreduce, self.dp_graph, self.dp_graph_failed = bool(overlap), bool(graph), False
+        two = bool(overlap) and self.B is not None and len(self.lib.grad_buckets(self.slot(self.B).cfg)) == 2
+        self._flags_recipe = _lib.CFG_NO_LN_XCHG if two else 0
+        self._apply_flags()
+
     def autotune_dp(self, steps=30, warmup=3, modes=None):
         """world > 1: time `steps` steps of every data-parallel recipe -- {single all-reduce, two overlapped buckets} x {eager sequence,
         one hipGraph per step} -- on the engine's static batch, keep the fastest.  Every rank takes the MAX over ranks of each time (one
         tiny all-reduce per recipe), so all ranks keep the same recipe.  Parameters, optimizer state and step counters are restored:
-        the run that follows is the run that would have been.  -> {"modes": {name: ms}, "chosen": name}"""
+        the run that follows is the run that would have been.  -> {"modes": {name: ms}, "chosen": name}
+
+        A rank on which a recipe RAISES must not leave the others inside that recipe's collectives: it completes the gradient all-reduces
+        of the step it failed in (those of the step's plan not yet issued), then issues the plan of every remaining step of the recipe --
+        garbage sums, thrown away with the snapshot restore -- and reports +inf, so the MAX all-reduce that closes the recipe is reached by
+        every rank after the same number of collectives and the recipe is simply not chosen (tests/test_exchange_failsafe.py)."""
         import time
         import torch.distributed as dist
         s = self.slot(self.B)
@@ -353,22 +409,36 @@ class StepEngine:
         name = lambda c: ("buckets" if c[0] else "plain") + ("_graph" if c[1] else "_eager")
         snap = (self.params.clone(), self.state.clone(), None if self.m is None else (self.m.clone(), self.v.clone()))
         sync = (lambda: None) if self.on_host else (lambda: torch.cuda.synchronize(self.device))
-        table = {}
+        table, errors = {}, {}
         for c in cand:
-            self.overlap_allreduce, self.dp_graph = c
-            self.dp_graph_failed = False
-            t = float("inf")
-            try:
-                for _ in range(warmup):
-                    self.train_step()
-                sync(); dist.barrier(); t0 = time.perf_counter()
-                for _ in range(steps):
-                    self.train_step()
-                sync(); t = (time.perf_counter() - t0) / steps * 1e3
+            self._dp_recipe(*c)                    # (flags and graphs are this candidate's own: like is compared with like)
+            t, t0, failed = float("inf"), None, None
+            for i in range(warmup + steps):
+                if i == warmup and failed is None:
+                    sync(); dist.barrier(); t0 = time.perf_counter()
+                elif i == warmup:
+                    dist.barrier()                 # (a failed rank still joins the barrier the others time from)
+                if failed is None:
+                    try:
+                        self.train_step()
+                        continue
+                    except Exception as e:         # noqa: BLE001 -- a recipe that cannot run on this stack is simply not chosen
+                        failed = e
+                        errors[name(c)] = "%s: %s" % (type(e).__name__, e)
+                        plan = list(self._ar_plan)
+                        done = self._ar_issued % len(plan) if plan else 0
+                        self.grads[self.total - 1:].zero_()       # (the guard element: this rank's garbage must not read as an exchange time-out)
+                        if not (plan and self._ar_issued and done == 0):       # (all of the step's collectives were out already)
+                            for o, n in plan[done:]:
+                                dist.all_reduce(self.grads[o:o + n])
+                        continue
+                for o, n in self._ar_plan:         # a failed rank: the collectives of the steps the others still run
+                    dist.all_reduce(self.grads[o:o + n])
+            sync()
+            if failed is None:
+                t = (time.perf_counter() - t0) / steps * 1e3
                 if c[1] and self.dp_graph_failed:
                     t = float("inf")               # (it ran, but as the eager sequence)
-            except Exception:                      # noqa: BLE001 -- a recipe that cannot run on this stack is simply not chosen
-                sync()
             tt = torch.tensor([t if t != float("inf") else 1e30], dtype=torch.float64, device=self.device if not self.on_host else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             table[name(c)] = float(tt)
@@ -376,13 +446,13 @@ class StepEngine:
             if snap[2] is not None:
                 self.m.copy_(snap[2][0]); self.v.copy_(snap[2][1])
             self._pepoch += 1                      # (the parameters were rewritten: every slot's weight copies are stale)
+            for t_ in self._slots.values():        # (graphs of this candidate go: the next one -- and the run -- record their own)
+                t_.graphs.clear(); t_.keep.clear()
         best = min(cand, key=lambda c: table[name(c)])
-        self.overlap_allreduce, self.dp_graph = best
-        self.dp_graph_failed = False
-        if not best[0] and self._ln_xchg_off:      # (trying the bucketed recipe switched the LayerNorm row exchange off: back on for the single all-reduce)
-            self.lib.cdll.gt_set_ln_exchange(-1)
-            self._ln_xchg_off = False
+        self._dp_recipe(*best)
         self.dp_tune = {"modes": {k: (None if v >= 1e29 else round(v, 5)) for k, v in table.items()}, "chosen": name(best), "steps": steps}
+        if errors:
+            self.dp_tune["errors"] = errors
         return self.dp_tune
 
     def _watched_step(self, s, on_grads):
@@ -412,51 +482,55 @@ class StepEngine:
                 self._note_fused_step(s)          # (a replay updates the parameters without running _enqueue_step)
             self._replay(s, ("fused", self.algo, self.penalty), lambda: self._enqueue_step(s, 0))
         else:
-            import torch.distributed as dist
             buckets = self.lib.grad_buckets(s.cfg) if self.overlap_allreduce else []
-            if len(buckets) == 2 and not self._ln_xchg_off:
+            two = len(buckets) == 2
+            if two != bool(self._flags_recipe & _lib.CFG_NO_LN_XCHG):
                 # bucket 0's all-reduce runs UNDER the rest of backward: a collective's workgroups beside launches whose workgroups wait for each
-                # other (the LayerNorm row exchange needs its whole grid resident) -- the norm runs as a row pass of its own in this recipe
-                self.lib.cdll.gt_set_ln_exchange(0)
-                self._ln_xchg_off = True
+                # other (the LayerNorm row exchange needs its whole grid resident) -- the norm runs as a row pass of its own in this recipe.
+                # A flag of THIS engine's configurations (gt_config.flags), not a process-wide switch.
+                self._flags_recipe = _lib.CFG_NO_LN_XCHG if two else 0
+                self._apply_flags()
+            # the step's gradient all-reduces, in issue order (autotune_dp completes them on a rank whose step raised)
+            self._ar_plan = [tuple(b) for b in buckets] if two else [(0, self.total)]
+            self._ar_issued = 0
             guard = self._guard_fn(s)
             if self.dp_graph and on_grads is None and not self.on_host:
                 # ONE enqueue per step: forward + backward, the all-reduce(s) and the update captured in one hipGraph -- the collectives are
                 # nodes of the graph (RCCL enqueues on its own stream: fork / join edges), nothing returns to Python between the halves
                 def whole():
-                    if len(buckets) == 2:
+                    if two:
                         (o0, c0), (o1, c1) = buckets
                         self._enqueue_step(s, 2)
                         guard()
-                        w0 = dist.all_reduce(self.grads[o0:o0 + c0], async_op=True)
+                        w0 = self._ar(self.grads[o0:o0 + c0], async_op=True)
                         self._enqueue_step(s, 3)
-                        w1 = dist.all_reduce(self.grads[o1:o1 + c1], async_op=True)
+                        w1 = self._ar(self.grads[o1:o1 + c1], async_op=True)
                         w0.wait(); w1.wait()
                     else:
                         self._enqueue_step(s, 1)
                         guard()
-                        dist.all_reduce(self.grads)
+                        self._ar(self.grads)
                     self.enqueue_update(slot=s)
                 self._dp_whole(s, ("dp_whole", self.algo, self.penalty, len(buckets)), whole)
                 self.poll_exchange(s)
                 return s.stats
-            if len(buckets) == 2:
+            if two:
                 # bucketed overlap: graph A ends as soon as the upper bucket's gradients are final; its
                 # all-reduce (RCCL stream) runs under graph B, the rest of backward.  The collectives stay OUTSIDE the
                 # captured graphs.  Sums over ranks; averaged by grad_scale inside the optimizer kernel.
                 (o0, c0), (o1, c1) = buckets
                 self._replay(s, ("bwd_top", self.algo, self.penalty), lambda: self._enqueue_step(s, 2))
                 guard()
-                w0 = dist.all_reduce(self.grads[o0:o0 + c0], async_op=True)
+                w0 = self._ar(self.grads[o0:o0 + c0], async_op=True)
                 if self.graph_for(s) and ("bwd_rest", self.algo, self.penalty) not in s.graphs:
                     w0.wait()                     # first step only: the capture warm-up snapshots and restores the gradient buffer
                 self._replay(s, ("bwd_rest", self.algo, self.penalty), lambda: self._enqueue_step(s, 3), aux=True)
-                w1 = dist.all_reduce(self.grads[o1:o1 + c1], async_op=True)
+                w1 = self._ar(self.grads[o1:o1 + c1], async_op=True)
                 w0.wait(); w1.wait()
             else:
                 self._replay(s, ("fwdbwd", self.algo, self.penalty), lambda: self._enqueue_step(s, 1))
                 guard()
-                dist.all_reduce(self.grads)                  # RCCL sum over xGMI; averaged by grad_scale
+                self._ar(self.grads)                         # RCCL sum over xGMI; averaged by grad_scale
             if on_grads is not None:
                 on_grads()                        # (data-parallel: the all-reduced sums; the update averages them by grad_scale)
             self.enqueue_update(slot=s)
@@ -529,11 +603,12 @@ class StepEngine:
                           None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(s.ws), _ptr(self.state),
                           int(train), self.stream)
         run()
-        # evaluation forwards are consumed on the host right away: a timed-out pair exchange is noticed here and the forward repeated on
-        # the fallback schedule (a forward has no side effects).  Training forwards of the module API are covered by backward(): gradients
-        # computed through a raised word are zeroed on the device, so the optimizer step that follows changes nothing.
-        if not train and not self.on_host and self._xchg_word(s) is not None and self.check_exchange(s, "an evaluation forward"):
-            run()
+        # evaluation forwards are consumed on the host right away: a timed-out exchange is noticed here and the forward repeated on the
+        # exchange-free schedule (a forward has no side effects).  Rank-LOCAL by construction (an evaluation may run on one rank only): in a
+        # multi-rank run the repeat borrows the fallback flags for this call alone, see _local_retry.  Training forwards of the module API are
+        # covered by the optimizer step: the update kernel applies nothing while the word is set (backward() starts the asynchronous poll).
+        if not train and self._xchg_word(s) is not None and int(self._xchg_word(s)[0].item()) != 0:
+            self._local_retry(s.ws, s.cfg, "an evaluation forward", run)
         return s.hvo
 
     def loss(self, s, y, penalty, want_grad=True):
@@ -548,11 +623,17 @@ class StepEngine:
         self.lib.call("gt_backward", ctypes.byref(s.cfg), _ptr(self.params), _ptr(self.grads), _ptr(s.x),
                       None if self.encoder_only else _ptr(s.tgt), _ptr(s.hvo), _ptr(d_hvo), _ptr(s.ws), _ptr(self.state),
                       int(train), int(accumulate), self.stream)
-        # module API (loss.backward(); opt.step() -- any torch optimizer): gradients computed through a timed-out pair exchange are
-        # garbage; they are zeroed on the device (no synchronisation) so that the step that follows is a no-op instead of a corruption
+        # module API (loss.backward(); opt.step()): gradients computed through a timed-out exchange are garbage.  With the package's own
+        # optimizers (GrooveSGD / GrooveAdam: initialize_model's) the UPDATE KERNEL refuses them -- enqueue_update hands it this slot's error
+        # word: parameters, moments and Adam's t stay, the skip is counted -- and the asynchronous poll started here notices the word and
+        # falls back.  Only for a foreign torch optimizer stepping the Parameters directly are the gradients zeroed on the device (no
+        # synchronisation); that costs a pass over the gradient buffer and still lets weight decay / old moments move the weights.
+        self._bwd_slot = s
         w = self._xchg_word(s)
         if w is not None and not self.on_host:
-            self.grads.masked_fill_((w != 0).expand(self.total), 0.0)
+            if not self._fused_opt:
+                self.grads.masked_fill_((w[:1] != 0).expand(self.total), 0.0)
+            self.poll_exchange(s)
 
     def predict_chunk(self, n):
         """Sequences per gt_predict call for a set of n: as many as fit the workspace budget (greedy decoding is launch-bound --
@@ -572,15 +653,20 @@ class StepEngine:
 
     def predict(self, x, use_thres=True, thres=0.5, chunk=None, pd_seed=None):
         out = self._predict(x, use_thres, thres, chunk, pd_seed)
-        if not self.on_host:
+        if True:
             bad = False
             for m, (cfg, ws, _) in list(self._predict_ws.items()):
                 w = self._xchg_word(ws, cfg)
-                if w is not None and int(w.item()) != 0:
-                    self._recover_exchange(ws, cfg, "predict")
+                if w is not None and int(w[0].item()) != 0:
                     bad = True
-            if bad:                                 # (predict has no side effects: repeat on the fallback schedule)
-                out = self._predict(x, use_thres, thres, chunk, pd_seed)
+            if bad:                                 # (predict has no side effects: repeat on the exchange-free schedule; rank-local, see forward)
+                def again():
+                    nonlocal out
+                    out = self._predict(x, use_thres, thres, chunk, pd_seed)
+                for m, (cfg, ws, _) in list(self._predict_ws.items()):
+                    if self._xchg_word(ws, cfg) is not None:
+                        self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)
+                self._local_retry(None, None, "predict", again)
         self._trim_predict_ws()
         return out
 
@@ -621,17 +707,26 @@ class StepEngine:
         for m in [k for k, (_, ws, _) in self._predict_ws.items() if 4 * ws.numel() > PREDICT_WS_KEEP]:
             del self._predict_ws[m]               # (stream-ordered free: the caching allocator keeps the block until the launches ran)
 
-    # ---- QUAD pair exchange: what happens when partner workgroups were not co-resident ---------------------------------------
-    # The exchange polls with a bound (csrc/gt_seq.h, seq_xchg_get); a workgroup that gives its partner up raises the error word at the
-    # head of the slot's "seq_xchg" region and goes on with garbage.  Device side, the fused update refuses to apply anything while the
-    # word is set (parameters and moments untouched, gradients cleared) -- and, data-parallel, while the all-reduced guard element is
-    # non-zero, so every rank skips together.  Host side: the word is read (a) asynchronously every XCHG_POLL_EVERY-th train step
-    # (poll_exchange: a 4-byte copy into pinned memory, looked at one poll later -- no synchronisation on the step path), (b) wherever the
-    # host synchronises anyway: mean_stats (the logging path), eval forwards, predict.  On a set word the engine zeroes the region, falls
-    # back to two workgroups per sequence for the rest of the process (gt_set_seq_quad(0): same numbers, no in-launch exchange), drops
-    # the captured graphs and warns -- or raises, with GT_XCHG_STRICT=1.  The steps in between were skipped, never applied.
+    # ---- in-launch exchanges (QUAD pair exchange, LayerNorm row exchange): what happens when partner workgroups were not co-resident ------
+    # The exchanges poll with a bound (csrc/gt_seq.h seq_xchg_get, csrc/gt_gemm64.h g64_collect); a workgroup that gives its partner up raises
+    # the error word at the head of the slot's exchange region and goes on with garbage.  Device side, every update that knows the workspace
+    # refuses to apply anything while the word is set (parameters, moments and Adam's t untouched, gradients cleared, the skip COUNTED in word 1
+    # of the region's header) -- and, data-parallel, while the all-reduced guard element is non-zero, so every rank skips together.
+    # Host side, single process: the two words are read (a) asynchronously from the first train step of a slot on and then every
+    # XCHG_POLL_EVERY-th (poll_exchange: an 8-byte copy into pinned memory, looked at one poll later -- no synchronisation on the step path),
+    # (b) wherever the host synchronises anyway: mean_stats (the logging path), eval forwards, predict.  On a set word the engine zeroes the
+    # region, falls back to the exchange-free schedules for the rest of ITS life (gt_config.flags of its own configurations: same numbers, no
+    # in-launch exchange -- other engines of the process are not touched), drops its captured graphs and warns -- or raises, with
+    # GT_XCHG_STRICT=1.  The steps in between were skipped, never applied; exchange_timeouts / skipped_updates say how many.
+    # Multi-rank: a recovery changes the launch sequence and re-captures graphs -- the one-hipGraph recipe's capture runs a real warm-up step
+    # with collectives -- so it must happen on the SAME step on every rank: it is decided only from values every rank holds identically (the
+    # all-reduced guard element, read on the same step count and waited for; the flag inside mean_stats' / check_exchange's all-reduce).
+    # Rank-local observations (an evaluation forward or predict on one rank) repeat their own call on borrowed flags and change nothing else.
+    FALLBACK_FLAGS = _lib.CFG_NO_QUAD | _lib.CFG_NO_LN_XCHG
+
     def _xchg_word(self, s_or_ws, cfg=None):
-        """1-element int32 view of the error word of a slot (or of a (cfg, workspace) pair), None when the shape has no such region."""
+        """2-element int32 view [error word, skipped updates] of a slot (or of a (cfg, workspace) pair), None when the shape has no
+        exchange region."""
         if cfg is None:
             s = s_or_ws
             if s.xchg_off is None:
@@ -639,12 +734,12 @@ class StepEngine:
                     s.xchg_off = self.lib.ws_find(s.cfg, "xchg_err")[0]
                 except Exception:
                     s.xchg_off = -1
-            return s.ws[s.xchg_off:s.xchg_off + 1].view(torch.int32) if s.xchg_off >= 0 else None
+            return s.ws[s.xchg_off:s.xchg_off + 2].view(torch.int32) if s.xchg_off >= 0 else None
         try:
             off = self.lib.ws_find(cfg, "xchg_err")[0]
         except Exception:
             return None
-        return s_or_ws[off:off + 1].view(torch.int32) if off >= 0 else None
+        return s_or_ws[off:off + 2].view(torch.int32) if off >= 0 else None
 
     def _guard_fn(self, s):
         """Data-parallel: before the gradient all-reduce every rank writes its error flag into the guard element (the last float of the
@@ -653,72 +748,138 @@ class StepEngine:
             return lambda: None
         return lambda: self.lib.call("gt_dp_guard", ctypes.byref(s.cfg), _ptr(self.grads), _ptr(s.ws), self.stream)      # (one 1-thread launch)
 
-    def _recover_exchange(self, ws, cfg, what):
+    def _timeout_message(self, what):
+        return ("an in-launch exchange (four-workgroups-per-sequence pair exchange / LayerNorm row exchange) timed out during %s (partner "
+                "workgroups not co-resident: another stream / process holds CUs?)" % what)
+
+    def _local_retry(self, ws, cfg, what, again):
+        """A rank-local time-out in a call without side effects (evaluation forward, predict): zero the region, repeat the call on the
+        exchange-free schedule.  Single process: that schedule stays (a full recovery).  Multi-rank: the flags are borrowed for the repeat
+        alone -- the training schedule, its graphs and the other ranks are not touched."""
         self.exchange_timeouts += 1
-        msg = ("sequence kernels: a pair exchange of the four-workgroups-per-sequence schedule timed out during %s (partner workgroups "
-               "not co-resident: another stream / process holds CUs?)" % what)
         if self.xchg_strict:
-            raise RuntimeError(msg + "; GT_XCHG_STRICT=1")
-        import warnings
-        warnings.warn(msg + " -- the affected updates were skipped on the device; falling back to two workgroups per sequence "
-                      "(GT_SEQ_QUAD=0) for the rest of this process", RuntimeWarning)
-        self.lib.cdll.gt_set_seq_quad(0)
-        self.lib.cdll.gt_set_ln_exchange(0)        # (d_model 256 / 512: the LayerNorm as a row pass of its own again)
-        self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)      # (zeroes the region: stale granules, the word)
-        for t in self._slots.values():             # captured graphs hold QUAD launches; the launch count changes with the schedule
+            raise RuntimeError(self._timeout_message(what) + "; GT_XCHG_STRICT=1")
+        if self.world_size == 1:
+            self.exchange_timeouts -= 1            # (counted by _recover_exchange)
+            self._recover_exchange(ws, cfg, what)
+            again()
+            return
+        warnings.warn(self._timeout_message(what) + " -- repeated on the exchange-free schedule (this call only)", RuntimeWarning)
+        if ws is not None:
+            self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)
+        keep = (self._flags_fallback, [(t, dict(t.graphs), dict(t.keep), t.use_graph) for t in self._slots.values()])
+        self._flags_fallback = self.FALLBACK_FLAGS
+        try:
+            self._apply_flags()
+            again()
+        finally:
+            self._flags_fallback = keep[0]
+            self._apply_flags()
+            for t, g, k, u in keep[1]:             # (the training graphs were recorded under the flags now back in force)
+                t.graphs, t.keep, t.use_graph = g, k, u
+
+    def _recover_exchange(self, ws, cfg, what):
+        """Fall back to the exchange-free schedules for the rest of this engine's life.  Multi-rank: call it on EVERY rank on the same step."""
+        self.exchange_timeouts += 1
+        if self.xchg_strict:
+            raise RuntimeError(self._timeout_message(what) + "; GT_XCHG_STRICT=1")
+        for t in self._slots.values():             # the device's own count, before the regions are zeroed
+            w = self._xchg_word(t)
+            if w is not None:
+                self.skipped_updates += int(w[1].item()) - t.xchg_skipped_seen
+                t.xchg_skipped_seen = 0
+        warnings.warn(self._timeout_message(what) + " -- the affected updates were skipped on the device (%d so far); falling back to the "
+                      "exchange-free schedules for the rest of this engine's life" % self.skipped_updates, RuntimeWarning)
+        self._flags_fallback = self.FALLBACK_FLAGS
+        self._apply_flags()                        # (drops the captured graphs: they hold the exchanging launches)
+        if ws is not None:
+            self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)      # (zeroes the region: stale granules, the words)
+        for t in self._slots.values():
             t.graphs.clear(); t.keep.clear(); t.use_graph = None
+            t.xchg_host = None
             if t.ws is not ws and self._xchg_word(t) is not None:
                 self.lib.call("gt_workspace_init", ctypes.byref(t.cfg), _ptr(t.ws), self.stream)
-        if not self.on_host:
-            self.grads[self.total - 1:].zero_()
+        self.grads[self.total - 1:].zero_()
 
     def poll_exchange(self, s):
-        """Step path, no synchronisation: every XCHG_POLL_EVERY-th call looks at the PREVIOUS asynchronous copy of the error word (complete
-        by now, or left for the next poll) and starts the next one."""
+        """Step path, no host-side wait in a single process: the slot's first call and then every XCHG_POLL_EVERY-th look at the PREVIOUS
+        asynchronous copy of [error word, skipped updates] (complete by now, or left for the next poll) and start the next one.
+        Multi-rank: the copy is of the ALL-REDUCED guard element (identical on every rank) and the look WAITS for it, so every rank decides
+        on the same step from the same value (the copy is XCHG_POLL_EVERY steps old: the wait only bounds how far the host runs ahead)."""
         s.xchg_count += 1
-        if s.xchg_count % XCHG_POLL_EVERY or self.on_host:
+        if s.xchg_count != 1 and s.xchg_count % XCHG_POLL_EVERY:
             return
         w = self._xchg_word(s)
         if w is None:
             return
+        multi = self.world_size > 1
+        if self.on_host:                            # (host emulator: no streams -- read in place; multi-rank tests over gloo)
+            flag = float(self.grads[self.total - 1]) != 0.0 if multi else int(w[0]) != 0
+            if flag:
+                self._recover_exchange(s.ws, s.cfg, "a train step")
+            return
+        src = self.grads[self.total - 1:].view(torch.int32) if multi else w
         if s.xchg_host is None:
-            s.xchg_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            s.xchg_host = torch.zeros(src.numel(), dtype=torch.int32).pin_memory()
             s.xchg_event = torch.cuda.Event()
-        elif s.xchg_event.query():
+        else:
+            if multi:
+                s.xchg_event.synchronize()
+            elif not s.xchg_event.query():
+                return                              # (the last copy is still in flight: look again next time)
             if int(s.xchg_host[0]) != 0:
                 s.xchg_host.zero_()
                 self._recover_exchange(s.ws, s.cfg, "a train step")
                 return
-        else:
-            return                                  # (the last copy is still in flight: look again next time)
-        s.xchg_host.copy_(w, non_blocking=True)
+            if not multi:
+                seen = int(s.xchg_host[1])
+                self.skipped_updates += seen - s.xchg_skipped_seen
+                s.xchg_skipped_seen = seen
+        s.xchg_host.copy_(src, non_blocking=True)
         s.xchg_event.record(torch.cuda.current_stream(self.device))
 
     def check_exchange(self, s, what="a train step"):
         """Synchronising read of slot s's error word (call where the host waits for the device anyway).  -> True when a time-out was found
-        (and recovered from: the numbers of the launches since the last check are garbage, their updates were skipped)."""
+        (and recovered from: the numbers of the launches since the last check are garbage, their updates were skipped).  Multi-rank: a
+        COLLECTIVE -- every rank must call it at the same point (the flag is all-reduced, every rank recovers or none does)."""
         w = self._xchg_word(s)
-        if w is None or int(w.item()) == 0:
+        if self.world_size > 1:
+            import torch.distributed as dist
+            flag = torch.zeros(1, dtype=torch.float32, device=s.stats.device) if w is None else (w[:1] != 0).to(torch.float32)
+            dist.all_reduce(flag)
+            if float(flag) == 0.0:
+                return False
+            self._recover_exchange(s.ws, s.cfg, what + " (some rank)")
+            return True
+        if w is None or int(w[0].item()) == 0:
             return False
         self._recover_exchange(s.ws, s.cfg, what)
         return True
 
+    def exchange_report(self, s=None):
+        """{"exchange_timeouts", "skipped_updates"} up to now (synchronising: adds what the device counted since the last look)."""
+        n = self.skipped_updates
+        for t in ([s] if s is not None else list(self._slots.values())):
+            w = self._xchg_word(t)
+            if w is not None:
+                n += int(w[1].item()) - t.xchg_skipped_seen
+        return {"exchange_timeouts": self.exchange_timeouts, "skipped_updates": n}
+
     def mean_stats(self, s):
         """The slot's 8-float stats averaged over the data-parallel ranks (one tiny all-reduce; every rank must call it).
-        Single process: the stats tensor itself.  Also the synchronising check of the pair exchange: stats of a step whose exchange timed
+        Single process: the stats tensor itself.  Also the synchronising check of the exchanges: stats of a step whose exchange timed
         out come back as NaN (data-parallel: on every rank -- the flag travels with the stats all-reduce, so all ranks fall back together)."""
         if self.world_size == 1 or not self.reduce_stats:
-            if self.check_exchange(s):
+            if self.world_size == 1 and self.check_exchange(s):
                 return torch.full_like(s.stats, float("nan"))
             return s.stats
         import torch.distributed as dist
         w = self._xchg_word(s)
-        flag = torch.zeros(1, dtype=torch.float32, device=s.stats.device) if w is None else (w != 0).to(torch.float32)
+        flag = torch.zeros(1, dtype=torch.float32, device=s.stats.device) if w is None else (w[:1] != 0).to(torch.float32)
         t = torch.cat([s.stats, flag])
         dist.all_reduce(t)
         if float(t[8]) != 0.0:
-            if w is not None:                      # (ranks whose own word is clean fall back too: one schedule everywhere)
-                self._recover_exchange(s.ws, s.cfg, "a train step (some rank)")
+            self._recover_exchange(s.ws, s.cfg, "a train step (some rank)")     # (ranks whose own word is clean fall back too: one schedule everywhere)
             return torch.full_like(s.stats, float("nan"))
         return t[:8] / self.world_size
 

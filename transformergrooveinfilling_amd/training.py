@@ -34,6 +34,7 @@ class _FusedMixin:
         self.engine = engine
         self._algo = algo
         engine.algo = algo
+        engine._fused_opt = True           # (the update kernel honours the exchange error word: engine.backward need not zero gradients)
         self._lr_on_device = None
 
     def zero_grad(self, set_to_none=False):
