@@ -1,7 +1,7 @@
 # final measurements of a revision (run on the GPU box through gpurun): tools/gpu_final.sh TAG
 # (build first: csrc/build.sh, tools/build_variant.sh stamps groove_hip,groove_seq_fwd,groove_seq_bwd -DGT_SEQ_STAMPS, tools/ubench/gemm_bench)
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r05_final}
+TAG=${1:-r06_final}
 O=gpurun_out/final_$TAG
 L=$PWD/transformergrooveinfilling_amd/lib
 mkdir -p $O
@@ -21,19 +21,23 @@ for i in 6 9 12; do
   GT_T64R_MIN=100000000 python tools/shape_bench.py --only $i --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_T64R_MIN=inf (no 64x64 ring tiles: round 4 tile rules) /' >> $O/shapes.txt
   GT_LN_XCHG=0 python tools/shape_bench.py --only $i --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_LN_XCHG=0 (LayerNorm as a row pass of its own instead of the in-launch row exchange) /' >> $O/shapes.txt
 done
+# round 6: LayerNorm inside the 128x128-tile Linears (bs 512 on one GPU)
+for i in 7 11 13; do
+  GT_LN_XCHG128=0 python tools/shape_bench.py --only $i --steps 40 --warmup 5 2>/dev/null | tail -1 | sed 's/^/GT_LN_XCHG128=0 (LayerNorm row pass instead of the big-tile epilogue) /' >> $O/shapes.txt
+done
 GT_ROW_FUSE_XCHG=0 python tools/shape_bench.py --only 5 --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_ROW_FUSE_XCHG=0 (C3: row-owning LayerNorm tiles, the path until round 5) /' >> $O/shapes.txt
 GT_ROW_FUSE_BIG_MAX_D=0 GT_LN_XCHG=0 python tools/shape_bench.py --only 5 --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_ROW_FUSE_BIG_MAX_D=0 GT_LN_XCHG=0 (C3: 64x64 ring tiles + LayerNorm row pass) /' >> $O/shapes.txt
-python bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_style_1.json 2>/dev/null
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_style_2.json 2>/dev/null
-python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp.json 2>/dev/null
-GT_DP_GRAPH=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_graph.json 2>/dev/null
-GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_overlap.json 2>/dev/null
-GT_DP_GRAPH=1 GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp > $O/bench_force_dp_overlap_graph.json 2>/dev/null
+python bench.py --steps 300 --warmup 30 2> $O/bench.err | tail -1 > $O/bench.json
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1 > $O/bench_driver_style_1.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1 > $O/bench_driver_style_2.json 2>/dev/null
+python bench.py --no-cpu-baseline --force-dp | tail -1 > $O/bench_force_dp.json 2>/dev/null
+GT_DP_GRAPH=1 python bench.py --no-cpu-baseline --force-dp | tail -1 > $O/bench_force_dp_graph.json 2>/dev/null
+GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp | tail -1 > $O/bench_force_dp_overlap.json 2>/dev/null
+GT_DP_GRAPH=1 GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp | tail -1 > $O/bench_force_dp_overlap_graph.json 2>/dev/null
 for i in 0 1; do GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py $i > $O/seq_stamps_$i.txt 2>&1; done     # (the shipped path of these shapes: SPLIT)
 GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py 2 > $O/seq_stamps_c2.txt 2>&1
 python tools/wg_unit_bench.py 64 > $O/wg_unit_bench.txt 2>&1
-for i in 0 1 4 5 6 9 12 13; do python tools/class_profile.py $i > $O/class_profile_$i.txt 2>&1; done
+for i in 0 1 4 5 6 7 9 11 12 13 14 15; do python tools/class_profile.py $i > $O/class_profile_$i.txt 2>&1; done
 ./tools/ubench/gemm_bench > $O/gemm_bench.txt 2>&1
 for s in "2048 512 512" "2048 1536 512" "2048 512 1536" "8192 256 256" "8192 768 256"; do echo "== $s" >> $O/gemm_bench_mid.txt; ./tools/ubench/gemm_bench $s 2>&1 | grep -E "gemm64|gemm32.h|^NN|32x32   <|64x64   <2,2,2,2,BK32" >> $O/gemm_bench_mid.txt; done
 python tools/predict_bench.py > $O/predict.txt 2>&1
@@ -42,7 +46,7 @@ tail -3 $O/profile_rev.log
 cat $O/shapes.txt | tail -30
 # the bench lines again AFTER the PMC pass of this revision, so that roofline.traffic is this revision's own (bench.py refuses a traffic file of another csrc_sha)
 mkdir -p profiles && cp gpurun_out/profiles_$TAG/* profiles/ 2>/dev/null
-python bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
-python bench.py --steps 20 --warmup 5 > $O/bench_driver_style_full.json 2>/dev/null
+python bench.py --steps 300 --warmup 30 2> $O/bench.err | tail -1 > $O/bench.json
+python bench.py --steps 20 --warmup 5 | tail -1 > $O/bench_driver_style_full.json 2>/dev/null
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1
 tail -3 $O/pytest_gpu.txt

@@ -60,6 +60,14 @@ __shared__ long long* gt_sub_ptr;      // sub-stage stamps of ONE matmul stage (
 // Stage hand-overs inside these kernels go through LDS only (the global stores are copies for LATER kernels: saved activations,
 // weight-gradient operands), so the stage barrier is GT_BARRIER(): it waits for this wave's LDS traffic, not for its
 // outstanding global stores.
+// Byte accounting (diagnostic builds only, tools/acct_writes.sh; WRONG RESULTS, measured with rocprofv3 --pmc WRITE_SIZE): GT_SEQ_ACCT bit 0 = the
+// forward keeps only what the next launch reads (layer output, q / k / v) and skips the stores saved for the backward alone (P, ctx, x1, xhat1,
+// hact, xhat2); bit 1 = the pair exchange's consumer does not re-zero what it read; bit 2 = no pair-exchange stores at all.
+// Result (profiles/r06_c2_write_accounting.txt): of the 24.7 MB a forward launch of the headline step writes, 9.5 are saved activations, 4.2 the
+// exchange's granules, 4.2 their re-zeroing, 6.8 the hand-over to the next launch (layer output, q / k / v) and the rest.
+#ifndef GT_SEQ_ACCT
+#define GT_SEQ_ACCT 0
+#endif
 #define GT_SEQ_WAVES 8
 #define GT_SEQ_NT (GT_SEQ_WAVES * 64)
 #define GT_SEQ_NT_WG GT_SEQ_NT
@@ -125,7 +133,7 @@ __device__ __forceinline__ void seq_xchg_put(unsigned long long* slot, const f32
 #ifdef GT_EMU
     slot[j * GT_SEQ_NT + tid] = w;
 #else
-    __hip_atomic_store(slot + j * GT_SEQ_NT + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(GT_SEQ_ACCT & 4)) __hip_atomic_store(slot + j * GT_SEQ_NT + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
   }
 }
@@ -145,13 +153,15 @@ __device__ __forceinline__ f32x4 seq_xchg_get(unsigned long long* slot, const in
       w[j] = __hip_atomic_load(slot + j * GT_SEQ_NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ok = ok && (uint32_t)(w[j] >> 32) == GT_XTAG;
     }
-    if (__all(ok)) break;                                      // (wave-uniform exit: the lanes of a wave leave together)
+    if (__all(ok) || (GT_SEQ_ACCT & 4)) break;                 // (wave-uniform exit: the lanes of a wave leave together)
     if (spins == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spins = spin_max;       // (looked at only once the first poll failed)
     if (++spins > spin_max) { if ((tid & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     __builtin_amdgcn_s_sleep(1);
   }
+  if (!(GT_SEQ_ACCT & 6)) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) __hip_atomic_store(slot + j * GT_SEQ_NT + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < 4; ++j) __hip_atomic_store(slot + j * GT_SEQ_NT + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #endif
   return f32x4{gt_u2f((uint32_t)w[0]), gt_u2f((uint32_t)w[1]), gt_u2f((uint32_t)w[2]), gt_u2f((uint32_t)w[3])};
 }
@@ -634,7 +644,7 @@ __device__ __forceinline__ void seq_ln_fwd(ZFun zfun, float* sY, const int str, 
     SeqVec<CW>::st(sY + row * str + c0, y);
     if (gy != nullptr) {                                      // (wave-uniform; nullptr: another workgroup saves these rows -- QUAD)
       SeqVec<CW>::st(gy + o, y);
-      SeqVec<CW>::st(gxhat + o, xh);
+      if (!(GT_SEQ_ACCT & 1)) SeqVec<CW>::st(gxhat + o, xh);
     }
   }
   if (seg == 0 && gy != nullptr) grstd[row] = rs;
@@ -1411,7 +1421,7 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
         if (h < a.H) {
           SeqAttn at;
           at.q = sQ + h * a.hd; at.k = at.q + d; at.v = at.q + 2 * d; at.ldq = SQ; at.hd = a.hd; at.scale = ascale;
-          at.pidx = (uint32_t)((b * a.H + h) * 1024); at.P = sv0 ? wl + a.w0.P + (size_t)(b * a.H + h) * 1024 : nullptr;
+          at.pidx = (uint32_t)((b * a.H + h) * 1024); at.P = (sv0 && !(GT_SEQ_ACCT & 1)) ? wl + a.w0.P + (size_t)(b * a.H + h) * 1024 : nullptr;
           seq_attn_fwd<HD, PAD>(at, sC + h * a.hd, SX, dk, key, HALF ? (rb >> 4) : (wave & 1), lane);
         }
       }
@@ -1420,7 +1430,7 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
     GT_STAMP(sb + 2);
     // ---- out-proj (raw product -> sR part 0); the ctx tile also goes to global here (operand of the out-proj weight gradient)
     {
-      if (sv1) seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid, rb, NROW);
+      if (sv1 && !(GT_SEQ_ACCT & 1)) seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid, rb, NROW);
       if (DP <= 64 && !SPLIT) seq_mm_square(sC, SX, d, kf_out, sR, SRS, wave, lane);
       else
         seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kf_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
@@ -1439,7 +1449,7 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
         SeqVec<CW>::ld(z, &sR[row * SRS + c0]); SeqVec<CW>::ld(bi, bo + c0); SeqVec<CW>::ld(xr, &sX[row * SX + c0]);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, (sv1 || fzl) ? wl + a.w0.x1 + r0 * d : nullptr, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb);
+      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, ((sv1 || fzl) && !(GT_SEQ_ACCT & 1)) ? wl + a.w0.x1 + r0 * d : nullptr, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb);
     }
     GT_BARRIER();
     GT_STAMP(sb + 4);
@@ -1485,7 +1495,7 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
     if constexpr (QUAD) {
       // this partner's K half, one column tile per wave; its partial tile goes to the partner (and to sR part `cpart`), the partner's
       // arrives as part 1 - cpart: both sum part 0 + part 1, in that order, and continue on identical values
-      seq_tile_out_cols(wl + a.w0.hact + r0 * F, F, sH, SH, fc0, fcn, tid, rb, NROW);
+      if (!(GT_SEQ_ACCT & 1)) seq_tile_out_cols(wl + a.w0.hact + r0 * F, F, sH, SH, fc0, fcn, tid, rb, NROW);
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
       seq_mm_krange<true>(acc0, acc1, sH + rb * SH + l16 * SH + 4 * lg, SH, kf_w2, nkf, wave, kq0, kq0 + (nkf >> 1), lane, pre2, b2pre);
       GT_STAMP(300 + 4 * l);
