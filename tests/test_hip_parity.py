@@ -245,6 +245,56 @@ def test_layernorm_row_exchange_of_the_64_tile_linears():
         lib.cdll.gt_set_seq_quad(-1)
 
 
+def test_layernorm_row_exchange_of_the_big_tile_linears(capfd):
+    """Round 6: LayerNorm forward / backward inside the 128x128-tile Linears / dgrads (csrc/gt_gemm64.h gemm32_ln_epilogue) -- the default at
+    d_model 512 from 8192 tokens while the grid is resident (512 tiles = two per CU at 16384 tokens).  Oracle parity at bs 256 and bs 512
+    (fp32: NT forward, NN dgrad), both operands as bf16 shadows, precision 2 (the pre-norm output rounded to bf16 in registers), a train step;
+    the trace proves which launches took the path; a polling bound of one: the update applies nothing, the engine falls back to the row pass."""
+    import os
+    import warnings
+    import torch
+    os.environ["GT_TRACE_GEMM64"] = "1"
+    try:
+        capfd.readouterr()
+        parity.check_step("hip", cfg_dict(512, 8, 512, 1), 256, 0.1)
+        parity.check_step("hip", cfg_dict(512, 8, 512, 1), 512, 0.15)
+        parity.check_step_bf16("hip", cfg_dict(512, 8, 512, 1, embedding_size_src=27), 256, 0.24)
+        parity.check_step_bf16("hip", cfg_dict(512, 8, 512, 1), 256, 0.1, precision=2)
+        parity.check_train_step("hip", cfg_dict(512, 8, 512, 1), 256, 0.1)
+        err = capfd.readouterr().err
+    finally:
+        del os.environ["GT_TRACE_GEMM64"]
+    tr = [ln for ln in err.splitlines() if ln.startswith("[gemm64] ln128")]
+    for want in ("fp32-source M 8192 N 512 K 512 NT epi 7 prec 0", "fp32-source M 16384 N 512 K 512 NT epi 7 prec 0", "NN epi 8 prec 0",
+                 "bf16-source M 8192 N 512 K 512 NT epi 7 prec 1", "bf16-source M 8192 N 512 K 512 NT epi 8 prec 1"):
+        assert any(want in ln for ln in tr), (want, tr[:6])
+    # the fail-safe on this geometry: a polling bound of one -> error word -> nothing applied -> the engine's own fall-back (gt_config.flags)
+    from transformergrooveinfilling_amd import _lib
+    from transformergrooveinfilling_amd.engine import StepEngine
+    lib = _lib.get_lib()
+    dims = dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=1, num_decoder_layers=0, dropout=0.1, embedding_size_src=16)
+    eng = StepEngine(batch_size=256, optimizer="sgd", learning_rate=0.01, hit_loss_penalty=0.5, seed=3, use_graph=False, **dims)
+    eng.load_named(ng.init_params(dims, seed=1))
+    x, y = ng.synthetic_batch(256, 16, seed=4)
+    eng.x.copy_(torch.from_numpy(x)); eng.y.copy_(torch.from_numpy(y))
+    try:
+        eng.train_step(); torch.cuda.synchronize()
+        assert not eng.check_exchange(eng.slot(256))
+        before = eng.params.clone()
+        lib.cdll.gt_set_xchg_spin_max(1)
+        eng.train_step(); torch.cuda.synchronize()
+        lib.cdll.gt_set_xchg_spin_max(0)
+        assert torch.equal(eng.params, before) and float(eng.grads.abs().max()) == 0.0
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            assert eng.check_exchange(eng.slot(256))
+        assert eng.skipped_updates == 1 and eng.slot(256).cfg.flags == eng.FALLBACK_FLAGS
+        eng.train_step(); torch.cuda.synchronize()
+        assert not torch.equal(eng.params, before) and not eng.check_exchange(eng.slot(256))
+    finally:
+        lib.cdll.gt_set_xchg_spin_max(0)
+
+
 def test_train_step_bf16_operands():
     parity.check_train_step_bf16("hip", ENC, 4, 0.2)
     parity.check_train_step_bf16("hip", cfg_dict(128, 4, 512, 2), 8, 0.24)

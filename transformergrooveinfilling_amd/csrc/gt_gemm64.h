@@ -774,7 +774,8 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(GemmArgs g) {
 
 // GT_TRACE_GEMM64=1: one line on stderr per launch (tests assert that a shape really took this kernel)
 static inline void gemm64_trace(const char* what, const GemmArgs& g, bool bkm, int epi) {
-  static const int on = [] { const char* e = getenv("GT_TRACE_GEMM64"); return (e && e[0] == '1') ? 1 : 0; }();
+  const char* e = getenv("GT_TRACE_GEMM64");                   // (read per launch: a test switches it on for some calls of its process; host side, ~0.1 us)
+  const bool on = e && e[0] == '1';
   if (on) fprintf(stderr, "[gemm64] %s M %d N %d K %d %s epi %d prec %d\n", what, g.M, g.N, g.K, bkm ? "NN" : "NT", epi, g.bf16);
 }
 template <bool BKM, int EPI>
