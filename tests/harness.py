@@ -187,3 +187,22 @@ class Runner:
 
     def step_state(self):
         return _lib.GtStepState.from_buffer_copy(self.state.numpy().tobytes())
+
+
+def free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def run_ranks(fn, world, *args):
+    """mp.start_processes(fn, (world, port) + args) on a free rendezvous port -- once more on a fresh port when the first attempt dies (the
+    port is picked, released and re-bound by rank 0: two pytest-xdist workers running multi-rank tests at once can pick the same one)."""
+    import torch.multiprocessing as mp
+    for attempt in (0, 1):
+        try:
+            mp.start_processes(fn, args=(world, free_port()) + tuple(args), nprocs=world, join=True, start_method="spawn")
+            return
+        except Exception:
+            if attempt:
+                raise

@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from harness import run_ranks
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -59,7 +61,7 @@ def _worker(rank, world, port, out):
 def test_dp2_matches_single_process(tmp_path):
     world, port = 2, _free_port()
     out = str(tmp_path / "rank%d.pt")
-    mp.start_processes(_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    run_ranks(_worker, world, out)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from harness import Runner, cfg_dict
     from oracle import numpy_groove as ng
@@ -140,7 +142,7 @@ import pytest  # noqa: E402
 def test_engine_dp_matches_single_process(tmp_path, case, overlap, world):
     port = _free_port()
     out = str(tmp_path / "eng%d.pt")
-    mp.start_processes(_engine_worker, args=(world, port, out, overlap, case), nprocs=world, join=True, start_method="spawn")
+    run_ranks(_engine_worker, world, out, overlap, case)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from harness import emu_lib
     from transformergrooveinfilling_amd import layout

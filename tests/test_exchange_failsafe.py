@@ -12,6 +12,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from harness import run_ranks
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIMS = dict(d_model=128, n_heads=4, dim_feedforward=32, num_encoder_layers=1, num_decoder_layers=0, dropout=0.0, embedding_size_src=16)
 
@@ -175,7 +177,7 @@ def _dp_worker(rank, world, port, out):
 def test_data_parallel_ranks_skip_together(tmp_path):
     world, port = 2, _free_port()
     out = str(tmp_path / "r%d.pt")
-    mp.start_processes(_dp_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    run_ranks(_dp_worker, world, out)
     a, b = torch.load(out % 0), torch.load(out % 1)
     assert a["skipped"] and b["skipped"] and a["nan"] and b["nan"]
     assert a["timeouts"] == 1 and b["timeouts"] == 1
@@ -215,7 +217,7 @@ def _poll_worker(rank, world, port, out):
 def test_data_parallel_recovery_is_collective(tmp_path):
     world, port = 2, _free_port()
     out = str(tmp_path / "p%d.pt")
-    mp.start_processes(_poll_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    run_ranks(_poll_worker, world, out)
     a, b = torch.load(out % 0), torch.load(out % 1)
     F = 3                                                               # CFG_NO_QUAD | CFG_NO_LN_XCHG
     assert b["log"][0] == ("local", 1, 0)                               # the local retry counted a time-out and kept the training schedule
@@ -258,7 +260,7 @@ def _tune_fail_worker(rank, world, port, out):
 def test_data_parallel_autotune_survives_a_rank_that_raises(tmp_path):
     world, port = 2, _free_port()
     out = str(tmp_path / "f%d.pt")
-    mp.start_processes(_tune_fail_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    run_ranks(_tune_fail_worker, world, out)
     a, b = torch.load(out % 0), torch.load(out % 1)
     assert a["same"] and b["same"]
     assert a["tune"]["chosen"] == b["tune"]["chosen"] == "plain_eager"
@@ -288,7 +290,7 @@ def _tune_worker(rank, world, port, out):
 def test_data_parallel_autotune_agrees_across_ranks(tmp_path):
     world, port = 2, _free_port()
     out = str(tmp_path / "t%d.pt")
-    mp.start_processes(_tune_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    run_ranks(_tune_worker, world, out)
     a, b = torch.load(out % 0), torch.load(out % 1)
     assert a["same"] and b["same"]
     assert a["tune"]["chosen"] == b["tune"]["chosen"] and a["tune"]["modes"] == b["tune"]["modes"]      # (max over ranks: one table)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # after `gpurun -- bash tools/gpu_final.sh TAG`: copy what the collection wrote under gpurun_out/ into profiles/ (the judged, committed copies)
-TAG=${1:-r05_final}
+TAG=${1:-r06_final}
 cd "$(dirname "$0")/.."
 P=gpurun_out/profiles_$TAG; O=gpurun_out/final_$TAG
 cp $P/* profiles/

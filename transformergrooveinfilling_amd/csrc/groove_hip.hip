@@ -845,9 +845,11 @@ static int linear_res_ln(const Ctx& x, const float* in, int K, int64_t w_off, in
       return ln_xchg_launch<false, EPI_RES_LN>(x, f, only16(x, in));
     };
     if (t16 != nullptr) {
-      // (precision 2 on the big tile: the pre-norm output never leaves the registers -- better than its bf16 round trip; the 2048-token regime
-      //  keeps the bf16-stored form its parity bars were written for)
-      if (ln_xchg_tile(g) == 128 && try_fused()) return 0;
+      // (precision 2 on the big tile: the pre-norm output never leaves the registers -- rounded to bf16 there, round16: the numbers of the
+      //  bf16-stored form without its round trip.  At 2048 tokens the stored form + row pass stays: measured 0.866 / 0.867 ms against
+      //  0.870 / 0.870 fused (profiles/r06_ab_p2_fused_forward.txt); GT_P2_LN_FUSE=1 fuses there too)
+      static const bool p2fuse = [] { const char* e = getenv("GT_P2_LN_FUSE"); return e && e[0] == '1'; }();
+      if ((ln_xchg_tile(g) == 128 || p2fuse) && try_fused()) return 0;
       g.C = nullptr; g.C16 = t16; g.ldc16 = x.d;
       need16(gemm_on_big_kernel<false, EPI_STORE>(g), "Linear (+ LayerNorm) with a bf16-only output (precision 2)");
       gemm_launch<false, false, EPI_STORE>(g, x.s);

@@ -188,7 +188,9 @@ __device__ __forceinline__ void gemm64_ln_epilogue(const GemmArgs& g, const f32x
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float v = (acc[4 * q + j] + bi[q][j]) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + cb + 8 * q + j)) + re[q][j];
+        float lin = acc[4 * q + j] + bi[q][j];
+        if (g.round16) lin = gt_bf2f(gt_f2bf(lin));                // (precision 2: the value the un-fused form stores in bf16 ahead of its norm)
+        const float v = lin * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + cb + 8 * q + j)) + re[q][j];
         z[4 * q + j] = v; s += v;
       }
     s += __shfl_xor(s, 32);
