@@ -422,6 +422,43 @@ def test_quad_pair_exchange_fails_safe_under_contention_and_on_timeout():
         lib.cdll.gt_set_seq_quad(-1)
 
 
+@pytest.mark.parametrize("algo", ["sgd", "adam"])
+def test_module_api_optimizer_honours_the_exchange_error_word(algo):
+    """loss.backward(); opt.step() through a raised error word must change NOTHING -- the package's optimizers hand the update
+    kernel the workspace of the last backward (gt_optimizer_step_ws): parameters and moments stay, Adam's t does not advance, the device counts
+    the skipped update; after the region is cleared the same step applies."""
+    from BaseGrooveTransformers import calculate_loss, initialize_model
+    p = _params(algo=algo, d=128, H=4, F=64, L=1, dropout=0.1, lr=0.01)
+    model, opt, _ = initialize_model(p)
+    eng = model.engine
+    x, y = ng.synthetic_batch(8, 16, seed=3)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    bce, mse = torch.nn.BCEWithLogitsLoss(reduction="none"), torch.nn.MSELoss(reduction="none")
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        calculate_loss(model(xt), yt, bce, mse, 0.47)[0].backward()
+        opt.step()
+        torch.cuda.synchronize()
+    step()
+    s = eng._bwd_slot
+    assert s is not None and eng._xchg_word(s) is not None and eng._fused_opt      # d_model 128: the four-workgroups-per-sequence schedule, its region
+    before, t0 = eng.params.clone(), eng.state_struct().opt_step
+    m0 = None if eng.m is None else eng.m.clone()
+    eng._xchg_word(s)[0] = 1
+    step()
+    assert torch.equal(eng.params, before) and eng.state_struct().opt_step == t0
+    if m0 is not None:
+        assert torch.equal(eng.m, m0)
+    assert eng.exchange_report(s)["skipped_updates"] == 1
+    import ctypes
+    eng.lib.call("gt_workspace_init", ctypes.byref(s.cfg), ctypes.c_void_p(s.ws.data_ptr()), eng.stream)
+    s.xchg_skipped_seen = 0
+    step()
+    assert not torch.equal(eng.params, before) and eng.state_struct().opt_step == t0 + 1
+
+
 def test_encoder_decoder_graph_replays_separated_by_host_syncs_stay_finite():
     """Round 5 regression: the encoder-decoder step zeroed the memory gradient with a hipMemsetAsync -- a memset node inside the captured
     step graph -- and went non-finite intermittently (2 of 3 processes, from the second or third step) when the replays were separated by a
