@@ -653,20 +653,18 @@ class StepEngine:
 
     def predict(self, x, use_thres=True, thres=0.5, chunk=None, pd_seed=None):
         out = self._predict(x, use_thres, thres, chunk, pd_seed)
-        if True:
-            bad = False
-            for m, (cfg, ws, _) in list(self._predict_ws.items()):
-                w = self._xchg_word(ws, cfg)
-                if w is not None and int(w[0].item()) != 0:
-                    bad = True
-            if bad:                                 # (predict has no side effects: repeat on the exchange-free schedule; rank-local, see forward)
-                def again():
-                    nonlocal out
-                    out = self._predict(x, use_thres, thres, chunk, pd_seed)
-                for m, (cfg, ws, _) in list(self._predict_ws.items()):
-                    if self._xchg_word(ws, cfg) is not None:
-                        self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)
-                self._local_retry(None, None, "predict", again)
+        # a timed-out exchange inside the call (its own workspaces): noticed when the call ends, the call repeated on the exchange-free schedule
+        # (predict has no side effects; rank-local like an evaluation forward)
+        bad = [(cfg, ws) for cfg, ws, _ in self._predict_ws.values()
+               if self._xchg_word(ws, cfg) is not None and int(self._xchg_word(ws, cfg)[0].item()) != 0]
+        if bad:
+            for cfg, ws in bad:
+                self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)
+
+            def again():
+                nonlocal out
+                out = self._predict(x, use_thres, thres, chunk, pd_seed)
+            self._local_retry(None, None, "predict", again)
         self._trim_predict_ws()
         return out
 
@@ -689,7 +687,7 @@ class StepEngine:
                 if len(self._predict_ws) >= 2:             # the full chunk + one remainder size at most
                     self._predict_ws.pop(next(k for k in self._predict_ws if k != chunk), None)
                 cfg = _lib.make_config(m, d["embedding_size_src"], d["d_model"], d["n_heads"], d["dim_feedforward"],
-                                       d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"])
+                                       d["num_encoder_layers"], d["num_decoder_layers"], d["dropout"], d["precision"], self.cfg_flags)
                 ws = torch.empty(self.lib.workspace_floats(cfg), dtype=torch.float32, device=self.device)
                 self.lib.call("gt_workspace_init", ctypes.byref(cfg), _ptr(ws), self.stream)
                 tgt = torch.empty(m, 32, 27, dtype=torch.float32, device=self.device) if not self.encoder_only else None
