@@ -36,7 +36,10 @@ def test_bare_shell_launch_of_two_ranks():
     # the one kept are part of the record; no pair exchange timed out, no block was thrown away
     t = d["dp_tune"]
     assert t["chosen"] in t["modes"] and set(t["modes"]) <= {"plain_eager", "buckets_eager"} and all(v and v > 0 for v in t["modes"].values())
-    assert out["exchange_timeouts"] == 0 and out["blocks_discarded"] == 0
+    assert out["exchange_timeouts"] == 0 and out["blocks_discarded"] == 0 and out["skipped_updates"] == 0
+    # ... and what explains a scaling record: every rank's time-outs / skipped updates, the gradient all-reduce timed alone
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["exchange_timeouts"] == 0 and r["skipped_updates"] == 0 for r in d["per_rank"])
+    assert d["allreduce_alone_us"] > 0 and d["grad_bytes"] > 0
 
 
 def test_single_rank_and_two_ranks_compute_the_same_kind_of_step():
