@@ -173,6 +173,28 @@ def test_layernorm_fused_into_the_big_tile_linears():
     assert off.returncode == 0 and "ok" in off.stdout and "ln128" not in off.stderr, off.stderr[-3000:]
 
 
+def test_layernorm_fused_into_the_32_tile_linears():
+    """gt_gemm64.h gemm_xln32_epilogue (round 6): the row exchange under the generic kernel's 32x32 tiles -- the Linears of the reference's
+    d_model-256 YAMLs at 512 ... 2048 tokens.  The tile's accumulators are staged in LDS, ONE wave publishes its 64 granules, all four collect
+    into LDS, every 16-lane group merges the parts in order.  fp32 NT forward / NN dgrad, bf16 fragments (precision 1), an encoder-decoder
+    model (three norms per decoder layer), N = 256 and 512, one to four 32-row blocks, a train step; the shape rule's lower bound (half the
+    CUs get a tile) is lowered through the environment, the trace proves which launches took the path."""
+    out = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 2, 64, 2), 2, 0.2, seq=False)\n"
+                          "parity.check_step('emu', cfg_dict(256, 4, 128, 1), 4, 0.0, seq=False)\n"
+                          "parity.check_train_step('emu', cfg_dict(256, 2, 64, 1), 2, 0.1, seq=False)\n"
+                          "parity.check_step('emu', cfg_dict(512, 8, 64, 1), 2, 0.1)\n"
+                          "parity.check_step_bf16('emu', cfg_dict(256, 4, 64, 1), 2, 0.2)\n"
+                          "parity.check_step('emu', cfg_dict(256, 2, 64, 1, 1), 2, 0.1)\n",
+                          dict(GT_LN32_MIN="1", GT_TRACE_GEMM64="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+    tr = [ln for ln in out.stderr.splitlines() if ln.startswith("[gemm64] ln32")]
+    for want in ("M 64 N 256 K 256 NT epi 7 prec 0", "M 64 N 256 K 64 NN epi 8 prec 0", "M 64 N 256 K 768 NN epi 8 prec 0", "M 128 N 256",
+                 "M 64 N 512 K 512 NT epi 7 prec 0", "epi 7 prec 1", "epi 8 prec 1"):
+        assert any(want in ln for ln in tr), (want, tr[:8])
+    off = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 2, 64, 1), 2, 0.2, seq=False)\n", dict(GT_LN32_MIN="1", GT_TRACE_GEMM64="1", GT_LN_XCHG32="0"))
+    assert off.returncode == 0 and "ok" in off.stdout and "ln32" not in off.stderr, off.stderr[-3000:]
+
+
 def _emu_subprocess(code, env):
     import os
     import subprocess

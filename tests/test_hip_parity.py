@@ -295,6 +295,25 @@ def test_layernorm_row_exchange_of_the_big_tile_linears(capfd):
         lib.cdll.gt_set_xchg_spin_max(0)
 
 
+def test_layernorm_row_exchange_of_the_32_tile_linears(capfd):
+    """Round 6: the reference's d_model-256 YAML shape at its own batch size (K&S / Random: 1024 tokens) runs its LayerNorms inside the
+    generic kernel's 32x32-tile Linears / dgrads (csrc/gt_gemm64.h gemm_xln32_epilogue): oracle parity of the step and of three train steps,
+    the trace of the launches that took the path, 69 launches per step where there were 91."""
+    import os
+    os.environ["GT_TRACE_GEMM64"] = "1"
+    try:
+        capfd.readouterr()
+        parity.check_step("hip", YAML_KS, 32, 0.3)
+        parity.check_step("hip", cfg_dict(256, 16, 64, 2), 16, 0.15)          # Random_test_large's shape (128 tiles: half the CUs)
+        parity.check_train_step("hip", cfg_dict(256, 2, 512, 2), 32, 0.2)
+        err = capfd.readouterr().err
+    finally:
+        del os.environ["GT_TRACE_GEMM64"]
+    tr = [ln for ln in err.splitlines() if ln.startswith("[gemm64] ln32")]
+    for want in ("M 1024 N 256 K 256 NT epi 7 prec 0", "M 1024 N 256 K 512 NT epi 7 prec 0", "M 1024 N 256 K 768 NN epi 8 prec 0", "M 512 N 256"):
+        assert any(want in ln for ln in tr), (want, tr[:6])
+
+
 def test_train_step_bf16_operands():
     parity.check_train_step_bf16("hip", ENC, 4, 0.2)
     parity.check_train_step_bf16("hip", cfg_dict(128, 4, 512, 2), 8, 0.24)

@@ -692,8 +692,10 @@ static void ln_xchg_args(const Ctx& x, GemmArgs& g) {
 // which geometry the row exchange runs on for this (M, N): 64 = the 64x64 kernels of gt_gemm64.h, 128 = the big tile (round 6), 0 = none
 static int ln_xchg_tile(const GemmArgs& g) {
   if (gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2)) return 64;
-  static const bool off128 = [] { const char* e = getenv("GT_LN_XCHG128"); return e && e[0] == '0'; }();     // (A/B switch)
-  return (!off128 && gemm32_ln_shape(g, seq_cu_count())) ? 128 : 0;
+  static const bool off128 = [] { const char* e = getenv("GT_LN_XCHG128"); return e && e[0] == '0'; }();     // (A/B switches)
+  static const bool off32 = [] { const char* e = getenv("GT_LN_XCHG32"); return e && e[0] == '0'; }();
+  if (!off128 && gemm32_ln_shape(g, seq_cu_count())) return 128;
+  return (!off32 && gemm_xln32_shape(g, seq_cu_count())) ? 32 : 0;
 }
 template <bool BKM, int EPI>
 static bool ln_xchg_launch(const Ctx& x, const GemmArgs& g, bool in_only16) {
@@ -705,6 +707,17 @@ static bool ln_xchg_launch(const Ctx& x, const GemmArgs& g, bool in_only16) {
     if (!gemm32_ok(g, EPI, BKM)) return false;
     gemm64_trace("ln128 fp32-source", g, BKM, EPI);
     gemm32_launch<BKM, EPI>(g, x.s);
+    return true;
+  }
+  if (tile == 32) {
+    // the generic kernel's 32x32 tiles (the d_model-256 YAMLs at 512 ... 2048 tokens): fp32 sources; precision 1 rounds them on their way into LDS
+    constexpr int EPIX = EPI == EPI_RES_LN ? EPI_RES_LN_X : EPI_RES_LNBWD_X;
+    if (in_only16 || !gemm_xln32_ok(g, EPIX)) return false;
+    GemmArgs f = g;
+    f.k_chunk = (f.K + 63) / 64 * 64;
+    gemm64_trace("ln32 fp32-source", f, BKM, EPI);
+    if (f.bf16) gemm_launch_cfg<2, 2, 1, 1, 64, false, BKM, EPIX, 1>(f, 1, x.s);
+    else        gemm_launch_cfg<2, 2, 1, 1, 64, false, BKM, EPIX>(f, 1, x.s);
     return true;
   }
   if (tile != 64) return false;
@@ -750,8 +763,9 @@ static int dgrad_lnbwd(const Ctx& x, const float* dY, int ldy, const float* W, i
       ln_xchg_args(x, g);
       const int tile = ln_xchg_tile(g);
       const bool both16 = g.bf16 && g.A16 && g.B16;
-      const bool h16 = both16 && (tile == 128 ? gemm32_ln_ok(g, EPI_RES_LNBWD) && gemm32h_ok(g, EPI_RES_LNBWD) : gemm64h_ok(g, EPI_RES_LNBWD));
-      const bool f32 = !only16(x, dY) && !both16 &&
+      const bool h16 = tile != 32 && both16 && (tile == 128 ? gemm32_ln_ok(g, EPI_RES_LNBWD) && gemm32h_ok(g, EPI_RES_LNBWD) : gemm64h_ok(g, EPI_RES_LNBWD));
+      const bool f32 = tile == 32 ? (!only16(x, dY) && gemm_xln32_ok(g, EPI_RES_LNBWD_X))
+                     : !only16(x, dY) && !both16 &&
                        (tile == 128 ? gemm32_ln_ok(g, EPI_RES_LNBWD) && gemm32_ok(g, EPI_RES_LNBWD, wt == nullptr) : gemm64_ok(g, EPI_RES_LNBWD));
       if (tile != 0 && (h16 || f32)) {
         g.ln_part = ln_job(x, gamma_off, x.M / tile);

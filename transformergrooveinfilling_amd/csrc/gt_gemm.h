@@ -41,7 +41,9 @@ enum {
   EPI_MASK_NZ = 5,        // C = acc * (res != 0 ? mask_scale : 0)                  (FFN linear2 dgrad)
   EPI_ADD_RELUMASK_DROP = 6,  // C = (acc + res) * dropmask * (aux_in > 0)          (InputLayer backward)
   EPI_RES_LN = 7,         // z = drop(acc+bias) + res; C = LN(z); aux = xhat; aux2 = rstd
-  EPI_RES_LNBWD = 8       // g = acc (+ res); C = LNbwd(g); C2 = C*dropmask; dgamma/dbeta atomics
+  EPI_RES_LNBWD = 8,      // g = acc (+ res); C = LNbwd(g); C2 = C*dropmask; dgamma/dbeta atomics
+  EPI_RES_LN_X = 9,       // EPI_RES_LN / EPI_RES_LNBWD on 32x32 tiles that do NOT own their rows: the row partials of the N / 32 column tiles
+  EPI_RES_LNBWD_X = 10    // meet through the in-launch row exchange (gt_gemm64.h, gemm_xln32_epilogue; round 6)
 };
 
 struct GemmArgs {
@@ -334,6 +336,11 @@ __device__ __forceinline__ void gemm_row_epilogue(const GemmArgs& g, const int m
   }
 }
 
+// (round 6, defined in gt_gemm64.h beside the other geometries of the row exchange)
+__device__ __forceinline__ uint32_t gemm_xln32_tag(const GemmArgs& g, const int m0, const int n0);
+template <int EPI>
+__device__ __forceinline__ void gemm_xln32_epilogue(const GemmArgs& g, const int m0, const int n0, const uint32_t tag0, float* smem);
+
 template <int WM, int WN, int TM, int TN, int BK_, bool AKM, bool BKM, int EPI, int PREC = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, float* smem) {
   typedef GemmCfg<WM, WN, TM, TN, BK_, AKM, BKM, EPI, PREC> Cfg;
@@ -347,6 +354,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   const int kbeg = bz * g.k_chunk;
   const int kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
   const int nk = (kend - kbeg + BK - 1) / BK;
+  constexpr bool XLN = (EPI == EPI_RES_LN_X || EPI == EPI_RES_LNBWD_X);
+  static_assert(!XLN || (BM == 32 && BN == 32 && NT == 256 && !AKM), "row-exchange epilogue: the 32x32 tile of 256 threads");
+  uint32_t xtag = 0u;           // this launch's sequence number of the row exchange (read before anything is published)
+  if constexpr (XLN) xtag = gemm_xln32_tag(g, m0, n0);
 
   const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
   const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
@@ -530,6 +541,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     return;
   }
 #endif
+  if constexpr (XLN) {
+    // the tile's raw accumulators -> LDS [32][36] (the main loop's final barrier has passed), then the exchange epilogue
+    *reinterpret_cast<float4*>(&smem[(wm * 16 + l16) * 36 + wn * 16 + 4 * lg]) = make_float4(acc[0][0][0], acc[0][0][1], acc[0][0][2], acc[0][0][3]);
+    __syncthreads();
+    gemm_xln32_epilogue<EPI>(g, m0, n0, xtag, smem);
+    return;
+  }
   if (!Cfg::ROW) {
     if (EPI == EPI_ATOMIC && AKM) {
       if (g.dbias != nullptr && bx == 0 && tid < BM && m0 + tid < g.M) atomicAdd(&g.dbias[m0 + tid], bsum);
@@ -764,7 +782,7 @@ __global__ __launch_bounds__(256, TM == 4 ? GT_T128_WAVES : 1) void wgrad_group_
 // --------------------------------------------------------------------------------- host dispatch
 template <bool BKM, int EPI>
 static inline const char* gemm_label() {
-  return EPI == EPI_ATOMIC ? "gemm_wgrad" : EPI == EPI_RES_LN ? "gemm_fwd_res_ln" : EPI == EPI_RES_LNBWD ? "gemm_dgrad_lnbwd"
+  return EPI == EPI_ATOMIC ? "gemm_wgrad" : (EPI == EPI_RES_LN || EPI == EPI_RES_LN_X) ? "gemm_fwd_res_ln" : (EPI == EPI_RES_LNBWD || EPI == EPI_RES_LNBWD_X) ? "gemm_dgrad_lnbwd"
        : EPI == EPI_RELU_PE ? "gemm_fwd_input" : EPI == EPI_RELU_DROP ? "gemm_fwd_ffn1" : EPI == EPI_HEADS ? "gemm_fwd_heads"
        : EPI == EPI_MASK_NZ ? "gemm_dgrad_ffn2" : EPI == EPI_ADD_RELUMASK_DROP ? "gemm_dgrad_input"
        : BKM ? "gemm_dgrad" : "gemm_fwd_bias";

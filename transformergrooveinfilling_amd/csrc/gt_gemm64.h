@@ -578,6 +578,176 @@ static inline bool gemm32_ln_ok(const GemmArgs& g, int epi) {
   return true;
 }
 
+// ================================================================================================================ ... and on 32x32 tiles
+// Round 6: the same row exchange under the GENERIC kernel's 32x32 tiles (gemm_kernel<2, 2, 1, 1, BK64>, 256 threads) -- the tile the Linears of
+// the reference's d_model-256 YAMLs run on at 512 ... 2048 tokens, where every LayerNorm was a launch of its own at its 4.5 us floor (24 of
+// the 91 launches of the K&S / Random YAML step, 44 of Random_test_large's).  Round 5 forced the 64x64 form there and lost (a quarter of the
+// CUs got a tile); here the GEMM keeps its tiles and only the epilogue changes.  Geometry: a PART is the tile's 32 columns (N / 32 parts per
+// row), a 16-lane group owns two of the tile's rows (two columns per lane); the tile's raw accumulators are staged in LDS first, the row
+// partials meet in LDS, ONE wave publishes the tile's 64 granules ([part][2 values][32 rows]: 512 contiguous bytes), all four waves collect
+// (thread t: part t >> 5, row t & 31) into LDS, every group merges the parts in order.  Granules of a 32-row block: N / 32 x 64 -- the
+// region of gt_rowx_floats exactly.  A shape takes one geometry for good (ln_xchg_tile).
+__device__ __forceinline__ unsigned long long* g32_rowx(const GemmArgs& g, const int m0) {
+  return reinterpret_cast<unsigned long long*>(g.rowx + GT_ROWX_HDR) + (size_t)(m0 >> 5) * (g.N >> 5) * 64;
+}
+// this launch's sequence number: wave 0's lanes own the tile's granules (the others return 0 and take the number from LDS later)
+__device__ __forceinline__ uint32_t gemm_xln32_tag(const GemmArgs& g, const int m0, const int n0) {
+  const int tid = threadIdx.x;
+  return tid < 64 ? g64_seq(g32_rowx(g, m0) + (size_t)(n0 >> 5) * 64 + tid) : 0u;
+}
+// smem: [32][36] raw accumulators of the tile (staged by the caller, barrier passed) + 3200 floats of scratch behind them
+template <int EPI>
+__device__ __forceinline__ void gemm_xln32_epilogue(const GemmArgs& g, const int m0, const int n0, const uint32_t tag0, float* smem) {
+  constexpr int CSTR = 36;
+  float* const sC = smem;
+  float* const sS = smem + 32 * CSTR;            // [2 values][32 rows]: this tile's partials
+  float* const sP = sS + 64;                     // [16 parts][2 values][32 rows]: every part's
+  float* const sG = sP + 1024;                   // [16 groups][2][32 columns]: dgamma / dbeta partials of the groups
+  uint32_t* const sTag = reinterpret_cast<uint32_t*>(sG + 1024);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4, grp = wave * 4 + lg;
+  const int N = g.N, NP = N >> 5, part = n0 >> 5;
+  unsigned* const xerr = g.rowx;
+  unsigned long long* const xrb = g32_rowx(g, m0);
+  const uint32_t dkey = gt_drop_key(g.drop);
+  const float invN = 1.0f / (float)N;
+  if (tid == 0) *sTag = tag0;
+  const int c0 = n0 + l16, c1 = n0 + l16 + 16;                       // this lane's two columns
+  const float ga0 = g.gamma[c0], ga1 = g.gamma[c1];
+  float z[2][2], xh[2][2], rs[2] = {0.f, 0.f};
+  if constexpr (EPI == EPI_RES_LN_X) {
+    const float bi0 = g.bias ? g.bias[c0] : 0.f, bi1 = g.bias ? g.bias[c1] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int rl = grp + 16 * rr, row = m0 + rl;
+      const float r0 = g.res ? g.res[(size_t)row * g.ldres + c0] : 0.f, r1 = g.res ? g.res[(size_t)row * g.ldres + c1] : 0.f;
+      float l0 = sC[rl * CSTR + l16] + bi0, l1 = sC[rl * CSTR + l16 + 16] + bi1;
+      if (g.round16) { l0 = gt_bf2f(gt_f2bf(l0)); l1 = gt_bf2f(gt_f2bf(l1)); }
+      z[rr][0] = l0 * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + c0)) + r0;
+      z[rr][1] = l1 * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + c1)) + r1;
+      const float mw = gt_red16(z[rr][0] + z[rr][1]) * (1.0f / 32.0f);
+      const float d0 = z[rr][0] - mw, d1 = z[rr][1] - mw;
+      const float qq = gt_red16(d0 * d0 + d1 * d1);
+      if (l16 == 0) { sS[rl] = mw; sS[32 + rl] = qq; }
+    }
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int rl = grp + 16 * rr, row = m0 + rl;
+      const float r0 = g.res ? g.res[(size_t)row * g.ldres + c0] : 0.f, r1 = g.res ? g.res[(size_t)row * g.ldres + c1] : 0.f;
+      xh[rr][0] = g.xhat[(size_t)row * N + c0]; xh[rr][1] = g.xhat[(size_t)row * N + c1];
+      rs[rr] = g.rstd[row];
+      z[rr][0] = sC[rl * CSTR + l16] + r0; z[rr][1] = sC[rl * CSTR + l16 + 16] + r1;
+      const float g0 = z[rr][0] * ga0, g1 = z[rr][1] * ga1;
+      const float s1 = gt_red16(g0 + g1), s2 = gt_red16(g0 * xh[rr][0] + g1 * xh[rr][1]);
+      if (l16 == 0) { sS[rl] = s1; sS[32 + rl] = s2; }
+    }
+  }
+  __syncthreads();
+  const uint32_t seq = *sTag;
+  if (wave == 0) g64_publish(xrb + (size_t)part * 64 + lane, sS[lane], seq);      // lanes 0..31: value 0 of rows 0..31, lanes 32..63: value 1
+  G64_EMU_PUBLISHED();
+  {
+    // collect: thread t takes row t & 31 of parts t >> 5, (t >> 5) + 8, ... -- both values; the waves poll on their own
+    const int r = tid & 31;
+    unsigned long long w[2][2];
+    bool ok = true;
+    auto load_all = [&]() {
+      ok = true;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int pp = (tid >> 5) + 8 * k;
+        if (pp < NP) {
+          const unsigned long long* src = xrb + (size_t)pp * 64 + r;
+          w[k][0] = g64_ld(src); w[k][1] = g64_ld(src + 32);
+          ok = ok && (uint32_t)(w[k][0] >> 32) == seq && (uint32_t)(w[k][1] >> 32) == seq;
+        }
+      }
+    };
+#ifdef GT_EMU
+    load_all();
+#else
+    int spins = 0;
+    for (;;) {
+      load_all();
+      if (__all(ok)) break;
+      if (spins == 0 && __hip_atomic_load(xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spins = g.spin_max;
+      if (++spins > g.spin_max) { if (lane == 0) __hip_atomic_store(xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+#endif
+    G64_EMU_AGREE(ok)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pp = (tid >> 5) + 8 * k;
+      if (pp < NP) { sP[(pp * 2) * 32 + r] = gt_u2f((uint32_t)w[k][0]); sP[(pp * 2 + 1) * 32 + r] = gt_u2f((uint32_t)w[k][1]); }
+    }
+  }
+  __syncthreads();
+  if constexpr (EPI == EPI_RES_LN_X) {
+    const float be0 = g.beta[c0], be1 = g.beta[c1];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int rl = grp + 16 * rr, row = m0 + rl;
+      // Chan's merge over the parts, in order (32 columns each): identical statistics in every workgroup of the row
+      float mean = sP[rl], m2 = sP[32 + rl], cnt = 32.f;
+      for (int p = 1; p < NP; ++p) {
+        const float d = sP[(p * 2) * 32 + rl] - mean, n = cnt + 32.f;
+        mean += d * (32.f / n);
+        m2 += sP[(p * 2 + 1) * 32 + rl] + d * d * (cnt * 32.f / n);
+        cnt = n;
+      }
+      const float rstd = 1.0f / sqrtf(m2 * invN + GT_LN_EPS);
+      if (part == 0 && l16 == 0) g.aux2[row] = rstd;
+      const float x0 = (z[rr][0] - mean) * rstd, x1 = (z[rr][1] - mean) * rstd;
+      const float y0 = x0 * ga0 + be0, y1 = x1 * ga1 + be1;
+      g.aux[(size_t)row * N + c0] = x0; g.aux[(size_t)row * N + c1] = x1;
+      g.C[(size_t)row * g.ldc + c0] = y0; g.C[(size_t)row * g.ldc + c1] = y1;
+      if (g.C16 != nullptr) { g.C16[(size_t)row * g.ldc16 + c0] = gt_f2bf(y0); g.C16[(size_t)row * g.ldc16 + c1] = gt_f2bf(y1); }
+    }
+  } else {
+    const bool masked = g.C2 != nullptr || (g.C16 != nullptr && g.drop.thr != 0u && g.drop.st != nullptr);
+    float dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int rl = grp + 16 * rr, row = m0 + rl;
+      float t1 = 0.f, t2 = 0.f;
+      for (int p = 0; p < NP; ++p) { t1 += sP[(p * 2) * 32 + rl]; t2 += sP[(p * 2 + 1) * 32 + rl]; }
+      const float m1 = t1 * invN, m2 = t2 * invN;
+      const float v0 = rs[rr] * (z[rr][0] * ga0 - m1 - xh[rr][0] * m2), v1 = rs[rr] * (z[rr][1] * ga1 - m1 - xh[rr][1] * m2);
+      const float w0 = masked ? v0 * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + c0)) : v0;
+      const float w1 = masked ? v1 * gt_drop_mul(g.drop, dkey, (uint32_t)(row * N + c1)) : v1;
+      g.C[(size_t)row * g.ldc + c0] = v0; g.C[(size_t)row * g.ldc + c1] = v1;
+      if (g.C2 != nullptr) { g.C2[(size_t)row * g.ldc + c0] = w0; g.C2[(size_t)row * g.ldc + c1] = w1; }
+      if (g.C16 != nullptr) { g.C16[(size_t)row * g.ldc16 + c0] = gt_f2bf(w0); g.C16[(size_t)row * g.ldc16 + c1] = gt_f2bf(w1); }
+      dg[0] += z[rr][0] * xh[rr][0]; dg[1] += z[rr][1] * xh[rr][1]; db[0] += z[rr][0]; db[1] += z[rr][1];
+    }
+    // dgamma / dbeta partials of this tile: the 16 groups' sums over their two rows meet in LDS, in a fixed order
+    sG[(grp * 2) * 32 + l16] = dg[0]; sG[(grp * 2) * 32 + l16 + 16] = dg[1];
+    sG[(grp * 2 + 1) * 32 + l16] = db[0]; sG[(grp * 2 + 1) * 32 + l16 + 16] = db[1];
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a += sG[(q * 2 + which) * 32 + c];
+      g.ln_part[((size_t)(m0 >> 5) * 2 + which) * N + n0 + c] = a;
+    }
+  }
+}
+// host side: the 32x32-tile form applies where a d_model-wide Linear runs on the generic kernel's 32x32 tiles anyway (fewer than GT_T64_MIN
+// tiles of 64x64), N is a multiple of 32 up to 512, and the whole grid is resident with room to spare (<= 2 tiles per CU; at least half the CUs get one)
+static inline bool gemm_xln32_shape(const GemmArgs& g, int cus) {
+  static const long lo_env = gt_env_long("GT_LN32_MIN", -1);          // (tests lower the bound: the emulator runs small shapes)
+  const long tiles = (long)(g.M / 32) * (g.N / 32), t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), lo = lo_env >= 0 ? lo_env : cus / 2;
+  return g.N % 32 == 0 && g.N >= 64 && g.N <= 512 && g.M % 32 == 0 && t64 < GT_T64_MIN && tiles <= 2l * cus && tiles >= lo;
+}
+static inline bool gemm_xln32_ok(const GemmArgs& g, int epi) {
+  if (!g.rowx || !g.gamma || !g.C || g.accumulate) return false;
+  if (epi == EPI_RES_LN_X && (!g.beta || !g.aux || !g.aux2)) return false;
+  if (epi == EPI_RES_LNBWD_X && (!g.xhat || !g.rstd || !g.ln_part)) return false;
+  return true;
+}
+
 // host side: the fused LayerNorm epilogues apply when the Linear itself can take the 64x64 kernels, N = d_model is 256 or 512 and the
 // WHOLE grid is resident at once (two workgroups per CU)
 // (forced: gt_set_ln_exchange(1) -- tests on small shapes: no lower bound on the tile count)
