@@ -169,8 +169,14 @@ def test_layernorm_fused_into_the_big_tile_linears():
     for want in ("fp32-source M 128 N 256 K 256 NT epi 7 prec 0", "fp32-source M 128 N 256 K 128 NT epi 7 prec 0", "NN epi 8 prec 0", "M 256 N 256",
                  "M 128 N 512", "bf16-source M 128 N 256 K 256 NT epi 7", "bf16-source M 128 N 256 K 128 NT epi 8", "epi 7 prec 1", "bf16-source M 128 N 512"):
         assert any(want in ln for ln in tr), (want, tr[:8])
-    off = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 4, 128, 1), 4, 0.2)\n", dict(GT_EMU_LIB_PATH=so, GT_TRACE_GEMM64="1", GT_LN_XCHG128="0"))
-    assert off.returncode == 0 and "ok" in off.stdout and "ln128" not in off.stderr, off.stderr[-3000:]
+    # the keep bits of the FFN activation (gemm32_store_epilogue: EPI_RELU_DROP writes one bit per element, EPI_MASK_NZ reads them instead of hact):
+    # fp32 and bf16-only activations, both tile sizes' word layout is one function of (row, col)
+    kb = [ln for ln in out.stderr.splitlines() if ln.startswith("[gemm64] kbits")]
+    for want in ("kbits write M 128 N 128 K 256 NT epi 3 prec 0", "kbits read M 128 N 128 K 256 NN epi 5 prec 0", "kbits write M 128 N 128 K 256 NT epi 3 prec 1",
+                 "kbits read M 128 N 128 K 256 NN epi 5 prec 1", "kbits read M 128 N 128 K 512"):
+        assert any(want in ln for ln in kb), (want, kb[:8])
+    off = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 4, 128, 1), 4, 0.2)\n", dict(GT_EMU_LIB_PATH=so, GT_TRACE_GEMM64="1", GT_LN_XCHG128="0", GT_FFN_KBITS="0"))
+    assert off.returncode == 0 and "ok" in off.stdout and "ln128" not in off.stderr and "kbits" not in off.stderr, off.stderr[-3000:]
 
 
 def test_layernorm_fused_into_the_32_tile_linears():
@@ -193,6 +199,11 @@ def test_layernorm_fused_into_the_32_tile_linears():
         assert any(want in ln for ln in tr), (want, tr[:8])
     off = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 2, 64, 1), 2, 0.2, seq=False)\n", dict(GT_LN32_MIN="1", GT_TRACE_GEMM64="1", GT_LN_XCHG32="0"))
     assert off.returncode == 0 and "ok" in off.stdout and "ln32" not in off.stderr, off.stderr[-3000:]
+    # a CU mask in the environment: the device's CU count says nothing about co-residency any more -- no exchange schedule is chosen (xchg_cus)
+    masked = _emu_subprocess("parity.check_step('emu', cfg_dict(256, 2, 64, 1), 2, 0.2, seq=False)\n"
+                             "parity.check_step('emu', cfg_dict(128, 4, 64, 1), 4, 0.1)\n",       # (d_model 128: the QUAD schedule's rule reads the same count)
+                             dict(GT_LN32_MIN="1", GT_TRACE_GEMM64="1", ROC_GLOBAL_CU_MASK="0xffff"))
+    assert masked.returncode == 0 and "ok" in masked.stdout and "ln32" not in masked.stderr and "a CU mask is set" in masked.stderr, masked.stderr[-3000:]
 
 
 def _emu_subprocess(code, env):

@@ -314,6 +314,30 @@ def test_layernorm_row_exchange_of_the_32_tile_linears(capfd):
         assert any(want in ln for ln in tr), (want, tr[:6])
 
 
+def test_ffn_keep_bits(capfd):
+    """Round 6: FFN1's epilogue on the ring-tile kernels leaves one keep bit per element of the FFN activation (kept by the dropout and positive)
+    and the FFN2 dgrad selects on those instead of reading the activation (csrc/gt_gemm32.h gemm32_store_epilogue, groove_hip.hip ffn_kbits):
+    oracle parity of the step on the 64x64 tile (d_model 512 at 2048 tokens, fp32 and both bf16 modes) and the 128x128 tile (8192 tokens), of
+    three train steps, of an encoder-decoder model (bits per decoder layer too); the trace proves which launches wrote / read them."""
+    import os
+    os.environ["GT_TRACE_GEMM64"] = "1"
+    try:
+        capfd.readouterr()
+        parity.check_step("hip", cfg_dict(512, 8, 512, 1), 64, 0.3)
+        parity.check_step("hip", cfg_dict(512, 8, 512, 1), 256, 0.1)
+        parity.check_step("hip", cfg_dict(256, 2, 512, 1, 1), 64, 0.3)
+        parity.check_step_bf16("hip", cfg_dict(512, 8, 512, 1), 64, 0.3)
+        parity.check_step_bf16("hip", cfg_dict(512, 8, 512, 1), 64, 0.3, precision=2)
+        parity.check_train_step("hip", cfg_dict(512, 8, 512, 2), 64, 0.2)
+        err = capfd.readouterr().err
+    finally:
+        del os.environ["GT_TRACE_GEMM64"]
+    tr = [ln for ln in err.splitlines() if ln.startswith("[gemm64] kbits")]
+    for want in ("kbits write M 2048 N 512 K 512 NT epi 3 prec 0", "kbits read M 2048 N 512 K 512 NN epi 5 prec 0", "kbits write M 8192 N 512", "kbits read M 8192 N 512",
+                 "kbits read M 2048 N 512 K 256", "kbits write M 2048 N 512 K 512 NT epi 3 prec 1", "kbits read M 2048 N 512 K 512 NN epi 5 prec 1"):
+        assert any(want in ln for ln in tr), (want, tr[:8])
+
+
 def test_train_step_bf16_operands():
     parity.check_train_step_bf16("hip", ENC, 4, 0.2)
     parity.check_train_step_bf16("hip", cfg_dict(128, 4, 512, 2), 8, 0.24)

@@ -195,6 +195,7 @@ struct WLayout {
   std::vector<std::pair<int64_t, int64_t>> sh;
   std::vector<int64_t> sh_only;                        // level 2: fp32 offsets of the tensors stored in bf16 alone
   int64_t w16 = -1, w16t = -1, w16_stride = 0;
+  int64_t kbits = -1, kbits_stride = 0;                // keep bits of the FFN activation, [layer][M / 32][F / 32][64] 16-bit words (gt_gemm32.h; round 6)
   int64_t wT = -1, wT_stride = 0;                      // precision = 1 without shadows: fp32 transposes of the encoder layers' matrices (dgrads as NT)
   struct TmpSet { int64_t dzA, dzAm, dzB, dzBm, dzC, dzCm, dhid, dqkv, dqkvx; };
   std::vector<TmpSet> set;                           // 2 alternating sets, or one per layer (wgrad_deferred)
@@ -350,6 +351,8 @@ static WLayout ws_layout(const gt_config& c) {
     W.wT_stride = (int64_t)4 * d * d + (int64_t)2 * d * F;
     W.wT = add(W.wT_stride * c.n_enc_layers);
   }
+  // (behind everything else: no other offset moves.  One bit per element of hact: M F / 32 floats per layer)
+  if (!seq_supported(c) && F % 32 == 0) { W.kbits_stride = (M * F / 32 + 63) / 64 * 64; W.kbits = add(W.kbits_stride * nl); }
 #ifdef GT_SEQ_STAMPS
   W.stamps = add(2048 + 2 * 4 * 512);
 #endif
@@ -674,6 +677,7 @@ static void dgrad_store(const Ctx& x, const float* dY, int ldy, const float* W, 
 static int g_ln_xchg = -1;
 extern "C" int gt_set_ln_exchange(int on) { g_ln_xchg = on < 0 ? -1 : on != 0; return 0; }
 static int seq_cu_count();
+static int xchg_cus();
 static int g_xchg_spin_max = 0;
 // 0 = off, 1 = on where it applies (the default), 2 = forced (gt_set_ln_exchange(1) / GT_LN_XCHG=1: no lower bound on the tile count -- tests)
 static int ln_xchg_mode() {
@@ -691,11 +695,11 @@ static void ln_xchg_args(const Ctx& x, GemmArgs& g) {
 // the fused launch on whichever 64x64 kernel the operands allow (both bf16 shadows -> gemm64h; a bf16-ONLY input needs that one); false: not taken
 // which geometry the row exchange runs on for this (M, N): 64 = the 64x64 kernels of gt_gemm64.h, 128 = the big tile (round 6), 0 = none
 static int ln_xchg_tile(const GemmArgs& g) {
-  if (gemm64_ln_shape(g, seq_cu_count(), ln_xchg_mode() == 2)) return 64;
+  if (gemm64_ln_shape(g, xchg_cus(), ln_xchg_mode() == 2)) return 64;
   static const bool off128 = [] { const char* e = getenv("GT_LN_XCHG128"); return e && e[0] == '0'; }();     // (A/B switches)
   static const bool off32 = [] { const char* e = getenv("GT_LN_XCHG32"); return e && e[0] == '0'; }();
-  if (!off128 && gemm32_ln_shape(g, seq_cu_count())) return 128;
-  return (!off32 && gemm_xln32_shape(g, seq_cu_count())) ? 32 : 0;
+  if (!off128 && gemm32_ln_shape(g, xchg_cus())) return 128;
+  return (!off32 && gemm_xln32_shape(g, xchg_cus())) ? 32 : 0;
 }
 template <bool BKM, int EPI>
 static bool ln_xchg_launch(const Ctx& x, const GemmArgs& g, bool in_only16) {
@@ -1035,14 +1039,59 @@ static void input_layer_fwd(const Ctx& x, const float* in, int S, int64_t w, int
   gemm_launch<false, false, EPI_RELU_PE>(g, x.s);
 }
 // FFN block + last norm of a layer:  xout = LN(xin + drop(W2 drop(relu(W1 xin + b1)) + b2))
-static int ffn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int64_t norm_w, int gl,
-                   const SecondNorm* second = nullptr) {
+// The two launches around the FFN activation, as their argument blocks: FFN1 (hact = drop(relu(xin W1^T + b1))) and the FFN2 dgrad
+// (dhid = (dzm W2) * [hact != 0] / (1 - p)).  `ok`: false when a tensor stored in bf16 alone meets a kernel that cannot take it (need16).
+static GemmArgs ffn1_args(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int gl, bool* ok) {
   float* ws = x.ws;
   GemmArgs g = mk_gemm(xin, x.d, x.prm + p.w1, x.d, ws + w.hact, x.F, x.M, x.F, x.d);
   g.bias = x.prm + p.b1; g.drop = mk_drop(x, lsite(gl, GT_SITE_FFN));
   g.A16 = sh_act(x, xin); g.B16 = sh_w(x, x.prm + p.w1, false); g.lda16 = g.ldb16 = x.d;
   if (g.A16 && g.B16) { g.C16 = sh_act(x, ws + w.hact); g.ldc16 = x.F; }      // (written by the bf16-source kernel's epilogue only)
-  if (only16(x, ws + w.hact)) { need16(g.C16 && gemm32h_ok(g, EPI_RELU_DROP), "FFN activation stored in bf16 alone"); if (g.C16) g.C = nullptr; }
+  *ok = true;
+  if (only16(x, ws + w.hact)) { *ok = g.C16 && gemm32h_ok(g, EPI_RELU_DROP); if (g.C16) g.C = nullptr; }
+  return g;
+}
+// (*nt: the product runs in its NT form on a transposed fp32 copy of W2 -- precision 1 without shadows)
+static GemmArgs ffn2d_args(const Ctx& x, const LayerP& p, const LayerW& w, const Tmp& t, const float* dzm, bool* nt, bool* ok) {
+  float* ws = x.ws;
+  const float* w2t = wT_of(x, x.prm + p.w2);
+  GemmArgs g = w2t ? mk_gemm(dzm, x.d, w2t, x.d, t.dhid, x.F, x.M, x.F, x.d) : mk_gemm(dzm, x.d, x.prm + p.w2, x.F, t.dhid, x.F, x.M, x.F, x.d);
+  g.res = ws + w.hact; g.ldres = x.F;
+  g.mask_scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
+  *nt = w2t != nullptr; *ok = true;
+  if (w2t) return g;
+  g.A16 = sh_act(x, dzm); g.B16 = sh_w(x, x.prm + p.w2, true); g.lda16 = g.ldb16 = x.d;
+  if (g.A16 && g.B16) { g.C16 = sh_act(x, t.dhid); g.ldc16 = x.F; }
+  if (only16(x, ws + w.hact)) g.res16 = sh_act(x, ws + w.hact);
+  if (only16(x, t.dhid) || only16(x, dzm) || g.res16) {
+    *ok = g.C16 && gemm32h_ok(g, EPI_MASK_NZ);
+    if (g.C16 && only16(x, t.dhid)) g.C = nullptr;
+  }
+  return g;
+}
+// Keep bits of layer gl's FFN activation (round 6): FFN1's epilogue leaves one bit per element of hact -- kept by the dropout AND positive --
+// and the FFN2 dgrad reads those instead of hact itself (32 x / 16 x fewer bytes: C5 bs 512 3.15 -> 3.10 ms).  Only the ring-tile kernels
+// write / read them (gemm32_store_epilogue), so BOTH launches must be on one: decided here, from the two argument blocks, for the
+// forward and the backward alike.  GT_FFN_KBITS=0: off.
+static uint16_t* ffn_kbits(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int gl) {
+  static const bool on = [] { const char* e = getenv("GT_FFN_KBITS"); return !(e && e[0] == '0'); }();
+  if (!on || x.W.kbits < 0 || x.M % 32 != 0) return nullptr;
+  bool ok1, ok2, nt;
+  const GemmArgs a = ffn1_args(x, p, w, xin, gl, &ok1);
+  const Tmp t = tmp_set(x, gl);
+  const GemmArgs b = ffn2d_args(x, p, w, t, t.dzAm, &nt, &ok2);
+  if (!ok1 || !ok2 || !gemm_on_big_kernel<false, EPI_RELU_DROP>(a)) return nullptr;
+  if (!(nt ? gemm_on_big_kernel<false, EPI_MASK_NZ>(b) : gemm_on_big_kernel<true, EPI_MASK_NZ>(b))) return nullptr;
+  return reinterpret_cast<uint16_t*>(x.ws + x.W.kbits + x.W.kbits_stride * gl);
+}
+static int ffn_fwd(const Ctx& x, const LayerP& p, const LayerW& w, const float* xin, int64_t norm_w, int gl,
+                   const SecondNorm* second = nullptr) {
+  float* ws = x.ws;
+  bool ok;
+  GemmArgs g = ffn1_args(x, p, w, xin, gl, &ok);
+  need16(ok, "FFN activation stored in bf16 alone");
+  g.kbits = ffn_kbits(x, p, w, xin, gl);
+  if (g.kbits) gemm64_trace("kbits write", g, false, EPI_RELU_DROP);
   gemm_launch<false, false, EPI_RELU_DROP>(g, x.s);
   return linear_res_ln(x, ws + w.hact, x.F, p.w2, p.b2, xin, norm_w, ws + w.xout, ws + w.xhat2, ws + w.rstd2,
                        lsite(gl, GT_SITE_DROPF), second);
@@ -1086,6 +1135,18 @@ static int seq_cu_count() {
   return cached[dev];
 #endif
 }
+// CUs the in-launch exchanges may count on for CO-RESIDENCY (QUAD pair exchange, LayerNorm row exchange: every partner of a meeting must hold a CU
+// at the same time).  multiProcessorCount does not see a CU mask: with HSA_CU_MASK / ROC_GLOBAL_CU_MASK in the environment the answer is "unknown",
+// reported as 0 -- the exchange schedules are not chosen at all, instead of timing out into their fallback on the first step (one note on stderr).
+static int xchg_cus() {
+  static const bool masked = [] {
+    const char* a = getenv("HSA_CU_MASK"); const char* b = getenv("ROC_GLOBAL_CU_MASK");
+    const bool m = (a && a[0]) || (b && b[0]);
+    if (m) fprintf(stderr, "[groove_hip] a CU mask is set (HSA_CU_MASK / ROC_GLOBAL_CU_MASK): the in-launch exchange schedules stay off\n");
+    return m;
+  }();
+  return masked ? 0 : seq_cu_count();
+}
 static bool seq_split(const gt_config& c) {
   if (c.d_model != 128 && c.d_model != 32) return false;
   if (g_seq_split < 0) { const char* e = getenv("GT_SEQ_SPLIT"); if (e) g_seq_split = e[0] != '0'; }
@@ -1119,7 +1180,7 @@ static bool seq_ride(const gt_config& c) {
 static int g_seq_quad = -1;
 extern "C" int gt_set_seq_quad(int on) { g_seq_quad = on < 0 ? -1 : on != 0; return 0; }
 static bool seq_quad(const gt_config& c) {
-  if (c.d_model != 128 || c.dim_ff % 32 != 0 || !seq_split(c) || 4 * c.batch > seq_cu_count() || (c.flags & GT_CFG_NO_QUAD)) return false;
+  if (c.d_model != 128 || c.dim_ff % 32 != 0 || !seq_split(c) || 4 * c.batch > xchg_cus() || (c.flags & GT_CFG_NO_QUAD)) return false;
   if (g_seq_quad < 0) { const char* e = getenv("GT_SEQ_QUAD"); if (e) g_seq_quad = e[0] != '0'; }
   return g_seq_quad != 0;
 }
@@ -1407,23 +1468,15 @@ static int ffn_bwd(const Ctx& x, const LayerP& p, const LayerW& w, const Tmp& t,
                    const float* xhat_prev, const float* rstd_prev, int64_t gamma_prev, float* dzo, float* dzom, int site_prev) {
   float* ws = x.ws;
   wgrad(x, dzm, x.d, ws + w.hact, x.F, x.grd + p.w2, x.grd + p.b2, x.d, x.F);
-  const float* w2t = wT_of(x, x.prm + p.w2);
-  GemmArgs g = w2t ? mk_gemm(dzm, x.d, w2t, x.d, t.dhid, x.F, x.M, x.F, x.d) : mk_gemm(dzm, x.d, x.prm + p.w2, x.F, t.dhid, x.F, x.M, x.F, x.d);
-  g.res = ws + w.hact; g.ldres = x.F;
-  g.mask_scale = x.drop ? 1.0f / (1.0f - x.c.dropout) : 1.0f;
-  if (w2t) {
-    gemm_launch<false, false, EPI_MASK_NZ>(g, x.s);
-    wgrad(x, t.dhid, x.F, xin, x.d, x.grd + p.w1, x.grd + p.b1, x.F, x.d);
-    return dgrad_lnbwd(x, t.dhid, x.F, x.prm + p.w1, x.F, dz, xhat_prev, rstd_prev, gamma_prev, dzo, dzom, site_prev);
-  }
-  g.A16 = sh_act(x, dzm); g.B16 = sh_w(x, x.prm + p.w2, true); g.lda16 = g.ldb16 = x.d;
-  if (g.A16 && g.B16) { g.C16 = sh_act(x, t.dhid); g.ldc16 = x.F; }
-  if (only16(x, ws + w.hact)) g.res16 = sh_act(x, ws + w.hact);
-  if (only16(x, t.dhid) || only16(x, dzm) || g.res16) {
-    need16(g.C16 && gemm32h_ok(g, EPI_MASK_NZ), "FFN2 dgrad over bf16-only tensors");
-    if (g.C16 && only16(x, t.dhid)) g.C = nullptr;
-  }
-  gemm_launch<false, true, EPI_MASK_NZ>(g, x.s);
+  bool nt, ok;
+  GemmArgs g = ffn2d_args(x, p, w, t, dzm, &nt, &ok);
+  need16(ok, "FFN2 dgrad over bf16-only tensors");
+  int gl = 0;                                                  // (the layer's index in the workspace: the keep bits are per layer)
+  while (gl + 1 < (int)x.W.layers.size() && x.W.layers[gl].hact != w.hact) ++gl;
+  if (dzm == tmp_set(x, gl).dzAm) g.kbits = ffn_kbits(x, p, w, xin, gl);       // (the set the forward's decision looked at -- always, today)
+  if (g.kbits) gemm64_trace("kbits read", g, !nt, EPI_MASK_NZ);
+  if (nt) gemm_launch<false, false, EPI_MASK_NZ>(g, x.s);
+  else    gemm_launch<false, true, EPI_MASK_NZ>(g, x.s);
   wgrad(x, t.dhid, x.F, xin, x.d, x.grd + p.w1, x.grd + p.b1, x.F, x.d);
   return dgrad_lnbwd(x, t.dhid, x.F, x.prm + p.w1, x.F, dz, xhat_prev, rstd_prev, gamma_prev, dzo, dzom, site_prev);
 }

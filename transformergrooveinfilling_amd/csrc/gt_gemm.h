@@ -75,6 +75,8 @@ struct GemmArgs {
   const uint16_t* A16; const uint16_t* B16; int lda16, ldb16;
   uint16_t* C16; int ldc16;
   const uint16_t* res16;     // EPI_MASK_NZ: the mask source as bf16 (row stride ldres), when its fp32 tensor is not stored
+  uint16_t* kbits;           // the FFN activation's keep bits (gt_gemm32.h, gemm32_store_epilogue): written by EPI_RELU_DROP, read by EPI_MASK_NZ in
+                             // place of res / res16 -- ring-tile kernels only (the host sets it when BOTH launches are on them: ffn_kbits)
   int as_dgrad;              // profiling label only: an NT product that IS a dgrad (B = a transposed weight copy)
   // gt_gemm64.h, LayerNorm-fused epilogues on 64x64 tiles: the row exchange region of the workspace (header: error word, launch serial,
   // ticket; then [M][N / 32 parts][2] tagged 8-byte granules) and the bound of its polling loop

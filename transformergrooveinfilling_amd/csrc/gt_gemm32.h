@@ -45,13 +45,47 @@ static inline bool gemm32_ok(const GemmArgs& g, int epi, bool bkm) {
 // The store epilogues of a tile of TA x TB 32x32 blocks per wave (128x128: 2 x 2; gt_gemm64.h: 1 x 1) (transposed product: lane (r32, h) holds ONE row of C per 32x32 tile and, in registers
 // 4 q .. 4 q + 3, the four consecutive columns 8 q + 4 h + 0..3): two-phase -- every global input first, then compute + 16-byte stores.
 // g.C16: a bf16 copy of the stored values as well (8-byte stores), for a consumer that takes this output as a GEMM operand.
+// EPI_MASK_NZ with keep bits: the lane's words of its TA x TB blocks, requested BEFORE the main loop (2 registers on the big tile) -- the
+// epilogue then starts on values that arrived long ago instead of on a round trip (72.6 -> 7x us per FFN2 dgrad at d_model 512 / 16384 tokens)
+template <int EPI, int TA, int TB>
+__device__ __forceinline__ void gemm32_kbits_pre(const GemmArgs& g, const int m0, const int n0, const int wm, const int wn, const int r32, const int h,
+                                                 uint32_t (&kbpre)[TA * TB]) {
+#pragma unroll
+  for (int i = 0; i < TA * TB; ++i) kbpre[i] = 0u;
+  if constexpr (EPI == EPI_MASK_NZ) {
+    if (g.kbits != nullptr) {
+#pragma unroll
+      for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+          const int bi = (m0 + wm * (32 * TA) + ta * 32) >> 5, bj = (n0 + wn * (32 * TB) + tb * 32) >> 5;
+          kbpre[ta * TB + tb] = g.kbits[((size_t)bi * (g.N >> 5) + bj) * 64 + 32 * h + r32];
+        }
+    }
+  }
+}
 template <int EPI, int TA = 2, int TB = 2>
 __device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f32x16 (&acc)[TA][TB], const int m0, const int n0, const int wm, const int wn,
-                                                      const int r32, const int h) {
+                                                      const int r32, const int h, const uint32_t* kbpre = nullptr) {
   const uint32_t dkey = gt_drop_key(g.drop);
 #pragma unroll
   for (int tb = 0; tb < TB; ++tb) {
     f32x4 bia[4], rin[TA][4], rin2[TA][4];
+    // keep bits of the FFN activation (g.kbits: EPI_RELU_DROP writes them, EPI_MASK_NZ reads them in place of the activation itself -- 1 bit
+    // for 32 or 16): one 16-bit word per (32x32 block of the [M][N] output, lane of this layout) -- block (row / 32, col / 32), word
+    // 32 h + r32 of the block's 64, bit 4 q4 + r <-> column 8 q4 + 4 h + r of the block: a function of (row, col) alone, so the 128x128
+    // and the 64x64 tile, fp32 and bf16 sources agree on it
+    uint32_t kb[TA];
+    uint16_t* kbp[TA];
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta) {
+      kb[ta] = 0u; kbp[ta] = nullptr;
+      if ((EPI == EPI_MASK_NZ || EPI == EPI_RELU_DROP) && g.kbits != nullptr) {
+        const int bi = (m0 + wm * (32 * TA) + ta * 32) >> 5, bj = (n0 + wn * (32 * TB) + tb * 32) >> 5;
+        kbp[ta] = g.kbits + ((size_t)bi * (g.N >> 5) + bj) * 64 + 32 * h + r32;
+        if (EPI == EPI_MASK_NZ) kb[ta] = kbpre != nullptr ? kbpre[ta * TB + tb] : (uint32_t)*kbp[ta];
+      }
+    }
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int col = n0 + wn * (32 * TB) + tb * 32 + 8 * q4 + 4 * h;
@@ -62,6 +96,10 @@ __device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f
         const int row = m0 + wm * (32 * TA) + ta * 32 + r32;
         rin[ta][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI == EPI_STORE && g.accumulate) rin[ta][q4] = *reinterpret_cast<const f32x4*>(g.C + (size_t)row * g.ldc + col);
+#if defined(GT_ACCT_NOMASK)
+        if (EPI == EPI_MASK_NZ) { rin[ta][q4] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }    // (measurement build, WRONG RESULTS: the FFN2 dgrad without its mask read)
+#endif
+        if (EPI == EPI_MASK_NZ && g.kbits != nullptr) continue;       // (the mask comes as bits: kb below)
         if (EPI == EPI_MASK_NZ && g.res16 != nullptr) {      // the mask source (hact) lives in bf16 only: zero / non-zero is all that is asked
           const uint2 hb = *reinterpret_cast<const uint2*>(g.res16 + (size_t)row * g.ldres + col);
           rin[ta][q4] = f32x4{gt_u2f(hb.x << 16), gt_u2f(hb.x & 0xFFFF0000u), gt_u2f(hb.y << 16), gt_u2f(hb.y & 0xFFFF0000u)};
@@ -82,12 +120,14 @@ __device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f
           float v = acc[ta][tb][4 * q4 + r];
           if (EPI == EPI_STORE) v = v + bia[q4][r] + rin[ta][q4][r];
           else if (EPI == EPI_RELU_DROP) v = fmaxf(v + bia[q4][r], 0.f) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
-          else if (EPI == EPI_MASK_NZ) v = (rin[ta][q4][r] != 0.f) ? v * g.mask_scale : 0.f;
+          else if (EPI == EPI_MASK_NZ) v = ((g.kbits != nullptr ? ((kb[ta] >> (4 * q4 + r)) & 1u) != 0u : rin[ta][q4][r] != 0.f)) ? v * g.mask_scale : 0.f;
           else if (EPI == EPI_ADD_RELUMASK_DROP) {
             v = (v + rin[ta][q4][r]) * gt_drop_mul(g.drop, dkey, (uint32_t)(row * g.N + col + r));
             v = (rin2[ta][q4][r] > 0.f) ? v : 0.f;
           }
           o[r] = v;
+          // (the bit a consumer would derive from the stored value: of the bf16 copy when that is the only one stored)
+          if (EPI == EPI_RELU_DROP && g.kbits != nullptr) kb[ta] |= (uint32_t)(g.C != nullptr ? v != 0.f : (gt_f2bf(v) & 0x7FFFu) != 0u) << (4 * q4 + r);
         }
 #if defined(GT_EPI_NOSTORE)
         asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));            // (measurement build: the main loop and the epilogue's arithmetic without its stores)
@@ -100,6 +140,10 @@ __device__ __forceinline__ void gemm32_store_epilogue(const GemmArgs& g, const f
           *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = pk;
         }
       }
+    }
+    if (EPI == EPI_RELU_DROP && g.kbits != nullptr) {
+#pragma unroll
+      for (int ta = 0; ta < TA; ++ta) *kbp[ta] = (uint16_t)kb[ta];
     }
   }
 }
@@ -131,6 +175,8 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
   const int r32 = lane & 31, h = lane >> 5;
   uint32_t xtag[2] = {0u, 0u};   // LayerNorm epilogues: this launch's sequence numbers = the lane's OWN granules' + 1 (read before anything is published)
   if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) g128_seq(g, m0, n0, wm, wn, r32, h, xtag);
+  uint32_t kbpre[4];
+  gemm32_kbits_pre<EPI, 2, 2>(g, m0, n0, wm, wn, r32, h, kbpre);
 
   // staging: 4 float4 per thread and operand per slab.  A: chunk (row, 4 k);  B: chunk (n, 4 k) or, BKM, (k, 4 n)
   constexpr int PER = 4;
@@ -319,7 +365,7 @@ __device__ __forceinline__ void gemm32_body(const GemmArgs& g, const int m0, con
     if (g.N == 512) gemm32_ln_epilogue<EPI, 4>(g, acc, m0, n0, wm, wn, r32, h, xtag, smem);
     else            gemm32_ln_epilogue<EPI, 2>(g, acc, m0, n0, wm, wn, r32, h, xtag, smem);
   } else {
-    gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h);
+    gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h, kbpre);
   }
 #undef G32_LD
 #undef G32_ST
@@ -356,6 +402,8 @@ __global__ __launch_bounds__(256, 2) void gemm32h_kernel(GemmArgs g) {
   const int r32 = lane & 31, h = lane >> 5;
   uint32_t xtag[2] = {0u, 0u};
   if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) g128_seq(g, m0, n0, wm, wn, r32, h, xtag);
+  uint32_t kbpre[4];
+  gemm32_kbits_pre<EPI, 2, 2>(g, m0, n0, wm, wn, r32, h, kbpre);
   G32hRegs a0[PER], b0[PER], a1[PER], b1[PER], a2[PER], b2[PER];
   const uint16_t* pa[PER];
   const uint16_t* pb[PER];
@@ -422,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void gemm32h_kernel(GemmArgs g) {
     if (g.N == 512) gemm32_ln_epilogue<EPI, 4>(g, acc, m0, n0, wm, wn, r32, h, xtag, fsm);
     else            gemm32_ln_epilogue<EPI, 2>(g, acc, m0, n0, wm, wn, r32, h, xtag, fsm);
   } else {
-    gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h);
+    gemm32_store_epilogue<EPI>(g, acc, m0, n0, wm, wn, r32, h, kbpre);
   }
 }
 // host side: shadows present, interior tiles, 16-byte rows

@@ -767,6 +767,8 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(GemmArgs g) {
   const int r32 = lane & 31, h = lane >> 5;
   uint32_t xtag = 0;            // LayerNorm epilogues: this launch's sequence number = the wave's OWN ready word + 1 (read before the wave publishes)
   if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) xtag = g64_seq(g64_rowx(g, m0) + (size_t)((n0 >> 5) + wn) * 128 + wm * 64 + h * 32 + r32);
+  uint32_t kbpre[1];
+  gemm32_kbits_pre<EPI, 1, 1>(g, m0, n0, wm, wn, r32, h, kbpre);
 
   f32x4 va[PER], vb[PER], wa[PER], wb[PER];
   const char* pa[PER];
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(GemmArgs g) {
     if (g.N == 512) gemm64_ln_epilogue<EPI, 8>(g, acc[0][0], m0, n0, wm, wn, r32, h, xtag, smem);
     else            gemm64_ln_epilogue<EPI, 4>(g, acc[0][0], m0, n0, wm, wn, r32, h, xtag, smem);
   } else {
-    gemm32_store_epilogue<EPI, 1, 1>(g, acc, m0, n0, wm, wn, r32, h);
+    gemm32_store_epilogue<EPI, 1, 1>(g, acc, m0, n0, wm, wn, r32, h, kbpre);
   }
 }
 
@@ -978,6 +980,8 @@ __global__ __launch_bounds__(256, 2) void gemm64h_kernel(GemmArgs g) {
   const int r32 = lane & 31, h = lane >> 5;
   uint32_t xtag = 0;
   if constexpr (EPI == EPI_RES_LN || EPI == EPI_RES_LNBWD) xtag = g64_seq(g64_rowx(g, m0) + (size_t)((n0 >> 5) + wn) * 128 + wm * 64 + h * 32 + r32);
+  uint32_t kbpre[1];
+  gemm32_kbits_pre<EPI, 1, 1>(g, m0, n0, wm, wn, r32, h, kbpre);
   G32hRegs a0[PER], b0[PER], a1[PER], b1[PER], a2[PER], b2[PER];
   const uint16_t* pa[PER];
   const uint16_t* pb[PER];
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(256, 2) void gemm64h_kernel(GemmArgs g) {
     if (g.N == 512) gemm64_ln_epilogue<EPI, 8>(g, acc[0][0], m0, n0, wm, wn, r32, h, xtag, fsm);
     else            gemm64_ln_epilogue<EPI, 4>(g, acc[0][0], m0, n0, wm, wn, r32, h, xtag, fsm);
   } else {
-    gemm32_store_epilogue<EPI, 1, 1>(g, acc, m0, n0, wm, wn, r32, h);
+    gemm32_store_epilogue<EPI, 1, 1>(g, acc, m0, n0, wm, wn, r32, h, kbpre);
   }
 }
 // host side: shadows present, interior tiles, whole 128-wide slabs, 16-byte rows
