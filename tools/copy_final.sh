@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 P=gpurun_out/profiles_$TAG; O=gpurun_out/final_$TAG
 cp $P/* profiles/
 for f in bench.json bench_driver_style_1.json bench_driver_style_2.json bench_driver_style_full.json bench_force_dp.json bench_force_dp_graph.json \
-         bench_force_dp_overlap.json bench_force_dp_overlap_graph.json shapes.txt gemm_bench.txt gemm_bench_mid.txt predict.txt wg_unit_bench.txt pytest_gpu.txt; do
+         bench_force_dp_overlap.json bench_force_dp_overlap_graph.json shapes.txt gemm_bench.txt gemm_bench_mid.txt predict.txt wg_unit_bench.txt pytest_gpu.txt kbits_check.txt; do
   [ -f $O/$f ] && cp $O/$f profiles/${TAG}_$f
 done
 for f in $O/class_profile_*.txt; do n=$(basename $f .txt); cp $f profiles/${TAG}_class_profile_shape${n#class_profile_}.txt; done

@@ -25,6 +25,10 @@ done
 for i in 7 11 13; do
   GT_LN_XCHG128=0 python tools/shape_bench.py --only $i --steps 40 --warmup 5 2>/dev/null | tail -1 | sed 's/^/GT_LN_XCHG128=0 (LayerNorm row pass instead of the big-tile epilogue) /' >> $O/shapes.txt
 done
+for i in 7 11 13 5; do
+  GT_FFN_KBITS=0 python tools/shape_bench.py --only $i --steps 40 --warmup 5 2>/dev/null | tail -1 | sed 's/^/GT_FFN_KBITS=0 (the FFN2 dgrad reads the activation instead of its keep bits) /' >> $O/shapes.txt
+done
+python tools/kbits_check.py > $O/kbits_check.txt 2>&1
 GT_ROW_FUSE_XCHG=0 python tools/shape_bench.py --only 5 --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_ROW_FUSE_XCHG=0 (C3: row-owning LayerNorm tiles, the path until round 5) /' >> $O/shapes.txt
 GT_ROW_FUSE_BIG_MAX_D=0 GT_LN_XCHG=0 python tools/shape_bench.py --only 5 --steps 100 2>/dev/null | tail -1 | sed 's/^/GT_ROW_FUSE_BIG_MAX_D=0 GT_LN_XCHG=0 (C3: 64x64 ring tiles + LayerNorm row pass) /' >> $O/shapes.txt
 python bench.py --steps 300 --warmup 30 2> $O/bench.err | tail -1 > $O/bench.json

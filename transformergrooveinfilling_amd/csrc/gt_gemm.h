@@ -868,7 +868,7 @@ struct WgradBatch {
 };
 static inline bool wgrad32_ok(const GemmArgs& g);
 template <int PREC, bool SA16, bool SB16> __global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(GemmGroup grp);
-__global__ __launch_bounds__(256, 2) void wgrad32t_group_kernel(GemmGroup grp);
+__global__ void wgrad32t_group_kernel(GemmGroup grp);
 #ifndef GT_WGRAD32T
 #define GT_WGRAD32T 1           /* class 4 (both operands bf16) on the transposed-LDS-read kernel; 0: widened into the fp32 image */
 #endif

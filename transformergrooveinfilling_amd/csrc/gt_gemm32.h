@@ -635,7 +635,13 @@ static inline bool wgrad32_ok(const GemmArgs& g) {
 // block, delivered column-major (cdna_hip_programming.md T10) -- which is exactly the 32x32x16 operand map: lane (r32, h), element j =
 // token 16 s + 8 h + j.  Same operand values, same instruction, same k order as the fp32-image body: the per-chunk sums are the same
 // numbers.  EXEC is all ones at every transposed read (no divergence above them).
-struct Wg32tCfg { static constexpr int BK = 32, STR = 160, SZ = BK * STR; };            // bf16 elements
+#ifndef GT_WG32T_BK
+#define GT_WG32T_BK 32
+#endif
+#ifndef GT_WG32T_STR
+#define GT_WG32T_STR 160
+#endif
+struct Wg32tCfg { static constexpr int BK = GT_WG32T_BK, STR = GT_WG32T_STR, SZ = BK * STR; };            // bf16 elements
 #ifdef GT_EMU
 struct __attribute__((may_alias, aligned(8))) Wg32tFrag { uint16_t v[4]; };
 __device__ __forceinline__ Wg32tFrag wg32t_tr(const uint16_t* p) { const emu::tr16x4 t = emu::lds_tr16(p); Wg32tFrag r; for (int j = 0; j < 4; ++j) r.v[j] = t.v[j]; return r; }
@@ -669,7 +675,7 @@ __device__ __forceinline__ float wg32t_sum(const Wg32tFrag& f) {
 __device__ __forceinline__ void wgrad32t_body(const GemmArgs& g, const int m0, const int n0, const int kbeg, const int nk, const bool want_dbias,
                                               uint16_t* sm) {
   typedef Wg32tCfg Cfg;
-  constexpr int BK = Cfg::BK, STR = Cfg::STR, SZ = Cfg::SZ, PER = 2;
+  constexpr int BK = Cfg::BK, STR = Cfg::STR, SZ = Cfg::SZ, PER = BK / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
   G32hRegs a0[PER], b0[PER], a1[PER], b1[PER], a2[PER], b2[PER];
@@ -717,7 +723,7 @@ __device__ __forceinline__ void wgrad32t_body(const GemmArgs& g, const int m0, c
   __syncthreads();
 #define W32T_SLAB(CUR, NA, NB, t)                                                              \
   if ((t) < nk) {                                                                              \
-  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                           \
+  _Pragma("unroll") for (int s_ = 0; s_ < BK / 16; ++s_) {                                     \
     bf16x8 a16[2], b16[2];                                                                     \
     _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) {                                         \
       const uint16_t* qa = &sm[(CUR) * 2 * SZ + fa + 32 * ti + 16 * s_ * STR];                 \
@@ -759,7 +765,10 @@ __device__ __forceinline__ void wgrad32t_body(const GemmArgs& g, const int m0, c
         atomicAdd(&g.C[(size_t)row * g.ldc + col], acc[ta][tb][e]);
       }
 }
-__global__ __launch_bounds__(256, 2) void wgrad32t_group_kernel(GemmGroup grp) {
+#ifndef GT_WG32T_OCC
+#define GT_WG32T_OCC 2
+#endif
+__global__ __launch_bounds__(256, GT_WG32T_OCC) void wgrad32t_group_kernel(GemmGroup grp) {
   __shared__ __attribute__((aligned(16))) uint16_t sm[4 * Wg32tCfg::SZ];        // [buffer][A | B]
   const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
   const int b = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
@@ -770,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void wgrad32t_group_kernel(GemmGroup grp) {
   const int bx = local % grp.gx[i], t = local / grp.gx[i], by = t % grp.gy[i], bz = t / grp.gy[i];
   const int kbeg = bz * g.k_chunk;
   const int kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
-  wgrad32t_body(g, by * 128, bx * 128, kbeg, (kend - kbeg) / 32, g.dbias != nullptr && bx == 0, sm);
+  wgrad32t_body(g, by * 128, bx * 128, kbeg, (kend - kbeg) / Wg32tCfg::BK, g.dbias != nullptr && bx == 0, sm);
 }
 
 template <int PREC, bool SA16, bool SB16>
