@@ -68,6 +68,12 @@ __shared__ long long* gt_sub_ptr;      // sub-stage stamps of ONE matmul stage (
 #ifndef GT_SEQ_ACCT
 #define GT_SEQ_ACCT 0
 #endif
+#ifndef GT_SEQ_PFB_LN
+#define GT_SEQ_PFB_LN 1    /* ... and the backward chain's LayerNorm operands at the phase's start (A/B switch) */
+#endif
+#ifndef GT_SEQ_PF32
+#define GT_SEQ_PF32 1      /* d_model 32, SPLIT kernels: every stage's global operands requested a stage ahead (round 6); 0: as before */
+#endif
 #define GT_SEQ_WAVES 8
 #define GT_SEQ_NT (GT_SEQ_WAVES * 64)
 #define GT_SEQ_NT_WG GT_SEQ_NT
@@ -399,10 +405,41 @@ __device__ __forceinline__ void seq_b_mma(f32x4& acc0, f32x4& acc1, const SeqB<N
 }
 // Short contraction (K % 16 == 0, <= 16 NK), N % 16 == 0: wave w owns tiles w, w + 8, ... (at most MAXT of them); the B fragment
 // of the wave's next tile is requested before the MFMAs of the current one.  epi(n0, acc0, acc1, bias float4).
+// ALL the fragments (and bias chunks) of a wave's tiles of a seq_mm_tiles stage in its all-at-once form, for a caller that requests them a
+// stage ahead (d_model 32, round 6: seq_tiles_all_load before the stage in front, seq_mm_tiles_all in place of seq_mm_tiles)
+template <int NK, int MAXT> struct SeqTilesAll { SeqB<NK> b[MAXT]; float4 bi[MAXT]; };
+template <int NK, int MAXT, bool BIAS = true>
+__device__ __forceinline__ void seq_tiles_all_load(SeqTilesAll<NK, MAXT>& f, const float* __restrict__ Wp, const int K, const int N,
+                                                   const float* __restrict__ bias, const int wave, const int lane) {
+  const int lg = lane >> 4, ntile = N >> 4, nk = K >> 4;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t = wave + i * GT_SEQ_WAVES, tc = t < ntile ? t : (wave < ntile ? wave : 0);     // (clamped: no branch around a load)
+    seq_b_load<NK, true>(f.b[i], Wp, nk, tc, 0, nk, lane);
+    if constexpr (BIAS) f.bi[i] = *reinterpret_cast<const float4*>(bias + 16 * tc + 4 * lg);     // (never a run-time test: a branch around this load cost a vmcnt(0) right behind it)
+    else f.bi[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int NK, int MAXT, bool HALF, typename Epi>
+__device__ __forceinline__ void seq_mm_tiles_all(const float* sA, const int lda, const int K, const int N, const int wave, const int lane,
+                                                 const SeqTilesAll<NK, MAXT>& f, Epi epi) {
+  const int l16 = lane & 15, lg = lane >> 4, ntile = N >> 4, nk = K >> 4;
+  if (wave >= ntile) return;                             // wave-uniform
+  const float* ap = sA + l16 * lda + 4 * lg;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t = wave + i * GT_SEQ_WAVES;
+    if (t < ntile) {
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      seq_b_mma<NK, true, HALF>(acc0, acc1, f.b[i], ap, lda, nk);
+      epi(16 * t, acc0, acc1, f.bi[i]);
+    }
+  }
+}
 template <int NK, int MAXT, bool FULL, bool HALF, typename Epi>
 __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
                                                   const float* __restrict__ bias, const int wave, const int lane, Epi& epi,
-                                                  const bool have_pre = false, const SeqB<NK> pre = SeqB<NK>()) {
+                                                  const bool have_pre = false, const SeqB<NK> pre = SeqB<NK>(), const float4* pre_bias = nullptr) {
   const int l16 = lane & 15, lg = lane >> 4, ntile = N >> 4, nk = K >> 4;
   if (wave >= ntile) return;                             // wave-uniform
   const float* ap = sA + l16 * lda + 4 * lg;
@@ -435,7 +472,8 @@ __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda
   GT_SUBSTAMP(0);
   if (have_pre) b[0] = pre;                               // (workgroup-uniform: the wave's first fragment was requested a stage ahead)
   else seq_b_load<NK, FULL>(b[0], Wp, nk, wave, 0, nk, lane);
-  bi[0] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * wave + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (have_pre && pre_bias != nullptr) bi[0] = *pre_bias;  // (the first tile's bias chunk came with its fragment)
+  else bi[0] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + 16 * wave + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
   GT_SUBSTAMP(1);
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
@@ -462,8 +500,8 @@ __device__ __forceinline__ void seq_mm_tiles_impl(const float* sA, const int lda
 template <int NK, int MAXT, bool FULL, bool HALF, typename Epi>
 __device__ __forceinline__ void seq_mm_tiles(const float* sA, const int lda, const int K, const float* __restrict__ Wp, const int N,
                                              const float* __restrict__ bias, const int wave, const int lane, Epi epi,
-                                             const bool have_pre = false, const SeqB<NK> pre = SeqB<NK>()) {
-  seq_mm_tiles_impl<NK, MAXT, FULL, HALF>(sA, lda, K, Wp, N, bias, wave, lane, epi, have_pre, pre);
+                                             const bool have_pre = false, const SeqB<NK> pre = SeqB<NK>(), const float4* pre_bias = nullptr) {
+  seq_mm_tiles_impl<NK, MAXT, FULL, HALF>(sA, lda, K, Wp, N, bias, wave, lane, epi, have_pre, pre, pre_bias);
 }
 // the wave's first B fragment of a seq_mm_tiles stage (tile `wave`, all k-steps), for a caller that requests it a stage ahead
 template <int NK>
@@ -615,9 +653,18 @@ __device__ __forceinline__ void seq_tile_out_cols(float* __restrict__ dst, const
 
 // LayerNorm forward: z (this thread's CW values, from zfun(row, c0, z)) -> y = LN(z) gamma + beta -> the LDS tile sY and the
 // global y / xhat / rstd rows of this sequence (gy, gxhat, grstd: wave-uniform bases of the sequence's first row)
+// gamma / beta / the Linear's bias of a thread's columns, requested a stage ahead of the LayerNorm pass that uses them (d_model 32, round 6)
+template <int CW> struct SeqLnPre { float ga[CW], be[CW], bi[CW]; };
+template <int CW>
+__device__ __forceinline__ void seq_ln_pre(SeqLnPre<CW>& p, const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                           const int tid) {
+  const int c0 = (tid & 15) * CW;
+  SeqVec<CW>::ld(p.ga, gamma + c0); SeqVec<CW>::ld(p.be, beta + c0); SeqVec<CW>::ld(p.bi, bias + c0);
+}
 template <int DP, bool HALF, typename ZFun>
 __device__ __forceinline__ void seq_ln_fwd(ZFun zfun, float* sY, const int str, const int d, const float* __restrict__ gamma,
-                                           const float* __restrict__ beta, float* gy, float* gxhat, float* grstd, const int tid, const int rb) {
+                                           const float* __restrict__ beta, float* gy, float* gxhat, float* grstd, const int tid, const int rb,
+                                           const SeqLnPre<DP / 16>* pre = nullptr) {
   constexpr int CW = DP / 16;
   if (HALF && tid >= 256) return;                            // 16 own rows: waves 0..3
   const int row = rb + (tid >> 4), seg = tid & 15, c0 = seg * CW;
@@ -625,7 +672,13 @@ __device__ __forceinline__ void seq_ln_fwd(ZFun zfun, float* sY, const int str, 
   float z[CW], ga[CW], be[CW];
 #pragma unroll
   for (int e = 0; e < CW; ++e) { z[e] = 0.f; ga[e] = 0.f; be[e] = 0.f; }
-  if (ok) { SeqVec<CW>::ld(ga, gamma + c0); SeqVec<CW>::ld(be, beta + c0); zfun(row, c0, z); }
+  if (ok) {
+    if (pre != nullptr) {
+#pragma unroll
+      for (int e = 0; e < CW; ++e) { ga[e] = pre->ga[e]; be[e] = pre->be[e]; }
+    } else { SeqVec<CW>::ld(ga, gamma + c0); SeqVec<CW>::ld(be, beta + c0); }
+    zfun(row, c0, z);
+  }
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < CW; ++e) s += z[e];
@@ -650,13 +703,24 @@ __device__ __forceinline__ void seq_ln_fwd(ZFun zfun, float* sY, const int str, 
   if (seg == 0 && gy != nullptr) grstd[row] = rs;
 }
 
+// the LayerNorm backward's saved operands of a thread -- x-hat of its columns, rstd of its row, gamma -- requested ahead (d_model 32, round 6:
+// at the start of the backward phase, two stages and an attention backward before their pass); 16 own rows: threads 0..255 (the others' copy is unused)
+template <int CW> struct SeqLnBwdPre { float xh[CW], ga[CW], rs; };
+template <int CW>
+__device__ __forceinline__ void seq_ln_bwd_pre(SeqLnBwdPre<CW>& p, const int d, const float* __restrict__ gxhat, const float* __restrict__ grstd,
+                                               const float* __restrict__ gamma, const int tid, const int rb) {
+  const int row = rb + ((tid >> 4) & 15), c0 = (tid & 15) * CW;
+  SeqVec<CW>::ld(p.xh, gxhat + (unsigned)(row * d + c0)); SeqVec<CW>::ld(p.ga, gamma + c0);
+  p.rs = grstd[row];
+}
 // LayerNorm backward: g (from gfun) -> dz = LNbwd(g) -> sDz (LDS, unmasked: the residual gradient), dz * dropout mask -> sDzm
 // (LDS: the next dgrad's A operand), both to global when gdz / gdzm are given (weight-gradient operands); the per-wave column
 // sums of g xhat / g (4 rows each) -> sP[wave][2][DP]; seq_ln_part sums them over the waves after the stage barrier.
 template <int DP, bool HALF, typename GFun>
 __device__ __forceinline__ void seq_ln_bwd(GFun gfun, float* sDz, float* sDzm, const int str, const int d, const float* __restrict__ gxhat,
                                            const float* __restrict__ grstd, const float* __restrict__ gamma, const SeqDropK& dk, const uint32_t key,
-                                           const uint32_t idx0, float* gdz, float* gdzm, float* sP, const int tid, const int rb) {
+                                           const uint32_t idx0, float* gdz, float* gdzm, float* sP, const int tid, const int rb,
+                                           const SeqLnBwdPre<DP / 16>* pre = nullptr) {
   constexpr int CW = DP / 16;
   if (HALF && tid >= 256) return;                            // 16 own rows: waves 0..3
   const int row = rb + (tid >> 4), seg = tid & 15, c0 = seg * CW, lane = tid & 63, wave = tid >> 6;
@@ -665,8 +729,16 @@ __device__ __forceinline__ void seq_ln_bwd(GFun gfun, float* sDz, float* sDzm, c
   float g[CW], xh[CW], ga[CW];
 #pragma unroll
   for (int e = 0; e < CW; ++e) { g[e] = 0.f; xh[e] = 0.f; ga[e] = 0.f; }
-  const float rs = grstd[row];
-  if (ok) { SeqVec<CW>::ld(xh, gxhat + o); SeqVec<CW>::ld(ga, gamma + c0); gfun(row, c0, g); }
+  float rs;
+  if (pre != nullptr) {                                      // (workgroup-uniform) saved x-hat / rstd / gamma requested at the phase's start
+    rs = pre->rs;
+#pragma unroll
+    for (int e = 0; e < CW; ++e) { xh[e] = pre->xh[e]; ga[e] = pre->ga[e]; }
+    if (ok) gfun(row, c0, g);
+  } else {
+    rs = grstd[row];
+    if (ok) { SeqVec<CW>::ld(xh, gxhat + o); SeqVec<CW>::ld(ga, gamma + c0); gfun(row, c0, g); }
+  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int e = 0; e < CW; ++e) { const float gd = g[e] * ga[e]; s1 += gd; s2 += gd * xh[e]; }
@@ -1291,6 +1363,14 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
   const SeqDropK dk = seq_dropk(a);
   const uint32_t idxd = (uint32_t)(r0 * d), idxf = (uint32_t)(r0 * F);   // dropout element index of this sequence's first row
   const float ascale = 1.0f / sqrtf((float)a.hd);
+  // d_model 32 in the SPLIT kernels (the ClosedHH YAMLs: 16 workgroups x 2 on a 256-CU chip, every stage one dependent chain): a stage's global
+  // operands -- weight fragments, bias / gamma / beta -- are requested one stage AHEAD, so that a phase pays the L2 round trip (1.8-2 k cycles)
+  // once at its head instead of once per stage; the fragments are 8 ... 48 registers here (64 per stage at d_model 128, where the same was
+  // measured slower in round 3).  Round 6.
+  constexpr bool PF32 = SPLIT && !QUAD && EXACT && DP == 32 && GT_SEQ_PF32;
+  SeqB<NK> ipre = SeqB<NK>();                                 // the next layer's in-proj fragment + bias chunk (requested in layer_rest)
+  float4 ipre_b = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool have_ipre = false;
   // rows rb .. rb + nrows - 1 of a [32][ncol] tile of this sequence, global -> LDS, 16 bytes per thread and pass
   auto load_rows = [&](float* dst, const int str, const float* src, const int ncol, const int rb_, const int nrows) {
     const int q4 = ncol >> 2;
@@ -1374,7 +1454,8 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
         const int col = n0 + 4 * lg;
         *reinterpret_cast<float4*>(&sQ[(rbx + l16) * SQ + col]) = make_float4(c0[0] + bi.x, c0[1] + bi.y, c0[2] + bi.z, c0[3] + bi.w);
         if (!HF) *reinterpret_cast<float4*>(&sQ[(16 + l16) * SQ + col]) = make_float4(c1[0] + bi.x, c1[1] + bi.y, c1[2] + bi.z, c1[3] + bi.w);
-      });
+      }, PF32 && HF && have_ipre, ipre, &ipre_b);
+      have_ipre = false;
     }
     GT_BARRIER();
     GT_STAMP(2 + 10 * l + 1);
@@ -1395,8 +1476,10 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
     // pair's two waves the two query tiles; SPLIT: wave w takes head h8 + w, query tile = the own half.  The qkv tile goes to global
     // here (saved for the backward) -- line-shaped, see seq_tile_out.
     if (save_qkv && sv0) seq_tile_out(wl + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
+    SeqLnPre<CW> ln1p, ln2p;                                  // (PF32) the two norms' gamma / beta and the bias in front of them
+    if constexpr (PF32) seq_ln_pre<CW>(ln1p, pl + a.p0.out_b, pl + a.p0.n1w, pl + a.p0.n1b, tid);
 #ifndef GT_SEQ_NO_PRE2
-    const bool preo = SPLIT && EXACT && DP > 64;              // the out-proj's fragment: in flight under the attention (which loads nothing)
+    const bool preo = SPLIT && EXACT && (DP > 64 || PF32);    // the out-proj's fragment: in flight under the attention (which loads nothing)
     SeqB<NK> bopre = SeqB<NK>();
     if (preo) bopre = seq_tiles_first<NK>(kf_out, d, d, wave, lane);
 #else
@@ -1429,6 +1512,11 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
     GT_BARRIER();
     GT_STAMP(sb + 2);
     // ---- out-proj (raw product -> sR part 0); the ctx tile also goes to global here (operand of the out-proj weight gradient)
+    // (PF32) ALL of FFN1's fragments + bias chunks: in flight under the out-proj and norm1.  (Requested ahead of the attention instead they
+    //  arrive under its P stores -- 106 KB per workgroup through the same 64 B/clk vector-memory path: the attention stage took 1.7 k cycles longer.)
+    constexpr int F1T = GT_SEQ_FMAX / (QUAD ? 256 : 128);    // FFN1 tiles per wave
+    SeqTilesAll<NK, F1T> f1p;
+    if constexpr (PF32) seq_tiles_all_load<NK, F1T>(f1p, kf_w1, d, F, pl + a.p0.b1, wave, lane);
     {
       if (sv1 && !(GT_SEQ_ACCT & 1)) seq_tile_out(wl + a.w0.ctx + r0 * d, sC, SX, d, tid, rb, NROW);
       if (DP <= 64 && !SPLIT) seq_mm_square(sC, SX, d, kf_out, sR, SRS, wave, lane);
@@ -1446,21 +1534,34 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
       const float* bo = pl + a.p0.out_b;
       seq_ln_fwd<DP, HALF>([&](int row, int c0, float (&z)[CW]) {
         float bi[CW], xr[CW];
-        SeqVec<CW>::ld(z, &sR[row * SRS + c0]); SeqVec<CW>::ld(bi, bo + c0); SeqVec<CW>::ld(xr, &sX[row * SX + c0]);
+        SeqVec<CW>::ld(z, &sR[row * SRS + c0]); SeqVec<CW>::ld(xr, &sX[row * SX + c0]);
+        if constexpr (PF32) {
+#pragma unroll
+          for (int e = 0; e < CW; ++e) bi[e] = ln1p.bi[e];
+        } else SeqVec<CW>::ld(bi, bo + c0);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, ((sv1 || fzl) && !(GT_SEQ_ACCT & 1)) ? wl + a.w0.x1 + r0 * d : nullptr, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb);
+      }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, ((sv1 || fzl) && !(GT_SEQ_ACCT & 1)) ? wl + a.w0.x1 + r0 * d : nullptr, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb,
+         PF32 ? &ln1p : nullptr);
     }
     GT_BARRIER();
     GT_STAMP(sb + 4);
     // ---- FFN1: hact = drop(relu(x1 W1^T + b1))     (QUAD: this partner's half of the columns, fc0 .. fc0 + F / 2)
     const int fc0 = QUAD ? cpart * (F >> 1) : 0, fcn = QUAD ? F >> 1 : F;
+    if constexpr (PF32) {                                        // norm2's parameters and the NEXT layer's in-proj fragment: in flight under FFN1 and FFN2
+      seq_ln_pre<CW>(ln2p, pl + a.p0.b2, pl + a.p0.n2w, pl + a.p0.n2b, tid);
+      if (l + 1 < a.L) {
+        const float* kfn = ws + a.pack_f + (int64_t)(l + 1) * a.kstride;
+        const int tcl = wave < (3 * d >> 4) ? wave : 0;
+        seq_b_load<NK, true>(ipre, kfn, d >> 4, tcl, 0, d >> 4, lane);
+        ipre_b = *reinterpret_cast<const float4*>(prm + (int64_t)(l + 1) * a.pstride + a.p0.in_b + 16 * tcl + 4 * lg);
+        have_ipre = true;
+      }
+    }
     {
       const uint32_t key = seq_key(dk, site0 + GT_SITE_FFN);
       GT_SUBSET(l == 1);                                         // (diagnostic builds: sub-stage stamps of this stage, wave 0)
-      seq_mm_tiles<NK, GT_SEQ_FMAX / (QUAD ? 256 : 128), EXACT, HALF>(sX1 + rb * SX, SX, d, kf_w1 + (size_t)(fc0 >> 4) * (d >> 4) * 256, fcn,
-                                                                      pl + a.p0.b1 + fc0, wave, lane,
-                                                                      [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
+      auto ffn1_epi = [&](int n0, const f32x4& c0, const f32x4& c1, const float4& bi) {
         const int col = fc0 + n0 + 4 * lg;
 #pragma unroll
         for (int h2 = 0; h2 < NH; ++h2) {
@@ -1474,7 +1575,9 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
           v.w = fmaxf(c[3] + bi.w, 0.f) * seq_dmul(dk, key, idxf + o + 3);
           *reinterpret_cast<float4*>(&sH[row * SH + col]) = v;
         }
-      });
+      };
+      if constexpr (PF32) seq_mm_tiles_all<NK, F1T, HALF>(sX1 + rb * SX, SX, d, fcn, wave, lane, f1p, ffn1_epi);
+      else seq_mm_tiles<NK, F1T, EXACT, HALF>(sX1 + rb * SX, SX, d, kf_w1 + (size_t)(fc0 >> 4) * (d >> 4) * 256, fcn, pl + a.p0.b1 + fc0, wave, lane, ffn1_epi);
     }
     const int nkf = F >> 4, kq0 = QUAD ? cpart * (nkf >> 1) : 0;            // QUAD: this partner's k-steps of FFN2, kq0 .. kq0 + nkf / 2
 #ifndef GT_SEQ_NO_PRE
@@ -1530,10 +1633,15 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
         } else {
           seq_parts_sum<CW>(z, sR, SRS, parts, row, c0);
         }
-        SeqVec<CW>::ld(bi, b2 + c0); SeqVec<CW>::ld(xr, &sX1[row * SX + c0]);
+        SeqVec<CW>::ld(xr, &sX1[row * SX + c0]);
+        if constexpr (PF32) {
+#pragma unroll
+          for (int e = 0; e < CW; ++e) bi[e] = ln2p.bi[e];
+        } else SeqVec<CW>::ld(bi, b2 + c0);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
-      }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, (sv0 || fzl) ? wl + a.w0.xout + r0 * d : nullptr, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid, rb);
+      }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, (sv0 || fzl) ? wl + a.w0.xout + r0 * d : nullptr, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid, rb,
+         PF32 ? &ln2p : nullptr);
     }
     GT_BARRIER();
     GT_STAMP(sb + 7);
@@ -1781,6 +1889,12 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
     GT_BARRIER();                                                 // (sP is rewritten by the first norm2 backward below)
     GT_STAMP(101);
   };
+  // d_model 32, SPLIT (round 6, as in the forward): the chain's saved LayerNorm operands are requested at the phase's start
+  constexpr bool PFB = SPLIT && !QUAD && EXACT && DP == 32 && GT_SEQ_PF32;
+  SeqLnBwdPre<CW> lb2p, lb1p;
+  bool have_lbp = false;                                     // (set by chain_prefetch, at the start of a phase > 0)
+  constexpr int F2T = GT_SEQ_FMAX / (QUAD ? 256 : 128);      // FFN2 dgrad tiles per wave
+  SeqTilesAll<NK, F2T> f2p;                                   // ALL of the FFN2 dgrad's fragments (requested at the chain's head)
   // ---- the row-local chain of layer l: norm2 backward .. out-proj dgrad -> dctx in sZ (own rows); ends with a barrier.
   // fromg: g = gradient w.r.t. this layer's output comes from sZ (layer L-1); else g = the in-proj dgrad parts of layer l+1 + its dz1
   auto chain = [&](const int l, const bool fromg) {
@@ -1797,6 +1911,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
     // load -> LDS copy in front of it made every thread sit out the cold L2 round trip before the stage's own loads were even issued
     // (norm2 bwd 7.5 k cycles against norm1 bwd's 3.6 k)
     static_assert(16 * GT_SEQ_FMAX / 4 <= 4 * GT_SEQ_NT, "four 16-byte loads per thread cover the 16 x F tile");
+    if constexpr (PFB) seq_tiles_all_load<NK, F2T, false>(f2p, kb_w2, d, F, nullptr, wave, lane);      // ALL of the FFN2 dgrad's fragments: in flight under the norm2 backward
     float4 hp0 = make_float4(0.f, 0.f, 0.f, 0.f), hp1 = hp0, hp2 = hp0, hp3 = hp0;     // (named: an indexed array went to scratch)
     // (QUAD: this partner's half of the columns, fc0 .. fc0 + F / 2)
     const int fc0 = QUAD ? cpart * (F >> 1) : 0, fcn = QUAD ? F >> 1 : F;
@@ -1821,7 +1936,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
           for (int e = 0; e < CW; ++e) g[e] += r[e];
         }
       }, sDZ, sC, SX, d, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, pl + a.p0.n2w, dk, key, idxd, sv0 ? tl + a.t0.dzA + r0 * d : nullptr,
-                           (dk.thr && sv0) ? tl + a.t0.dzAm + r0 * d : nullptr, sP, tid, rb);
+                           (dk.thr && sv0) ? tl + a.t0.dzAm + r0 * d : nullptr, sP, tid, rb, (PFB && have_lbp) ? &lb2p : nullptr);
     }
     if (SPLIT) {
       auto hst = [&](const int u, const float4& v) { const int e = tid + u * GT_SEQ_NT; if (e < hn) *reinterpret_cast<float4*>(sH + (rb + e / hq4) * SH + fc0 + (e % hq4) * 4) = v; };
@@ -1831,8 +1946,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
     GT_STAMP(sb);
     // ---- FFN2 dgrad: dhid = (dz2m W2) * [hact != 0] * 1/(1-p), in place over the hact tile in sH
     if (sv0) seq_ln_part<DP, HALF>(sP, part_at(jb), d, tid);
-    seq_mm_tiles<NK, GT_SEQ_FMAX / (QUAD ? 256 : 128), EXACT, HALF>(sC + rb * SX, SX, d, kb_w2 + (size_t)(fc0 >> 4) * (d >> 4) * 256, fcn, nullptr, wave, lane,
-                                                                    [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
+    auto ffn2d_epi = [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
       const int col = fc0 + n0 + 4 * lg;
 #pragma unroll
       for (int h2 = 0; h2 < (HALF ? 1 : 2); ++h2) {
@@ -1842,7 +1956,9 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
         *reinterpret_cast<float4*>(hp) = make_float4(ha.x != 0.f ? c[0] * mscale : 0.f, ha.y != 0.f ? c[1] * mscale : 0.f,
                                                      ha.z != 0.f ? c[2] * mscale : 0.f, ha.w != 0.f ? c[3] * mscale : 0.f);
       }
-    });
+    };
+    if constexpr (PFB) seq_mm_tiles_all<NK, F2T, HALF>(sC + rb * SX, SX, d, fcn, wave, lane, f2p, ffn2d_epi);
+    else seq_mm_tiles<NK, F2T, EXACT, HALF>(sC + rb * SX, SX, d, kb_w2 + (size_t)(fc0 >> 4) * (d >> 4) * 256, fcn, nullptr, wave, lane, ffn2d_epi);
     const int nkf = F >> 4, kq0 = QUAD ? cpart * (nkf >> 1) : 0;            // QUAD: this partner's k-steps of the FFN1 dgrad
 #ifndef GT_SEQ_NO_PRE
     const bool pre1 = QUAD ? ((nkf >> 1) & 7) == 0 : (SPLIT && seq_splitk_pre_ok(F, d));
@@ -1857,6 +1973,8 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
 #endif
     GT_BARRIER();
     GT_STAMP(sb + 1);
+    SeqB<NK> bodpre = SeqB<NK>();                             // (PFB) the out-proj dgrad's fragment: in flight under the FFN1 dgrad and the norm1 backward
+    if constexpr (PFB) bodpre = seq_tiles_first<NK>(kb_out, d, d, wave, lane);
     // ---- FFN1 dgrad (K = F: split over the waves) -> partial tiles; dhid goes to global (operand of both FFN weight gradients)
     if constexpr (QUAD) {
       // the own half of the contraction, one column tile per wave; the partial tiles are swapped with the partner (seq_xchg_*), both sum
@@ -1897,7 +2015,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
 #pragma unroll
         for (int e = 0; e < CW; ++e) g[e] += r[e];
       }, sDZ, sC, SX, d, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, pl + a.p0.n1w, dk, key, idxd, sv0 ? tl + a.t0.dzB + r0 * d : nullptr,
-                           (dk.thr && sv0) ? tl + a.t0.dzBm + r0 * d : nullptr, sP, tid, rb);
+                           (dk.thr && sv0) ? tl + a.t0.dzBm + r0 * d : nullptr, sP, tid, rb, (PFB && have_lbp) ? &lb1p : nullptr);
     }
     GT_BARRIER();
     GT_STAMP(sb + 3);
@@ -1913,7 +2031,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
       seq_mm_tiles<NK, 1, EXACT, HALF>(sC + rb * SX, SX, d, kb_out, d, nullptr, wave, lane, [&](int n0, const f32x4& c0, const f32x4& c1, const float4&) {
         *reinterpret_cast<float4*>(&sZ[(rb + l16) * SX + n0 + 4 * lg]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
         if (!HALF) *reinterpret_cast<float4*>(&sZ[(16 + l16) * SX + n0 + 4 * lg]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
-      });
+      }, PFB, bodpre);
     GT_BARRIER();
     GT_STAMP(sb + 4);
   };
@@ -1921,6 +2039,22 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
   // from LDS; dq / dk / dv replace q / k / v of the head in place -- every wave of the round has finished reading before anyone
   // stores: third barrier), own rows of dqkv -> global (operand of the in-proj weight gradient), in-proj dgrad (K = 3 d: split over
   // the waves) -> partial tiles; ends with a barrier
+  // (PFB) the chain of layer l - 1 follows the attention backward + in-proj dgrad of layer l: its two norms' saved operands (x-hat, rstd, gamma: three
+  // small loads per thread each) are requested at the phase's START.  Measured alternatives for these AND the chain's bigger operands (the own rows of
+  // the hact tile, the FFN2 dgrad's fragments: 106 KB per workgroup): at the in-proj dgrad's head that stage waits for them (its own fragment loads are
+  // branchy at K = 96: the compiler's vmcnt(0) covers everything in flight, + 2.4 k cycles); between the two passes of the attention backward the
+  // second pass takes 2.8 k longer; the big ones at the phase's start sit under the attention's state and P loads (+ 1.3 k).  They stay at the chain's head.
+  auto chain_prefetch = [&](const int l) {
+    if constexpr (PFB) {
+      if (l > 0) {
+        const float* wp = ws + (int64_t)(l - 1) * a.wstride;
+        const float* pp = prm + (int64_t)(l - 1) * a.pstride;
+        seq_ln_bwd_pre<CW>(lb2p, d, wp + a.w0.xhat2 + r0 * d, wp + a.w0.rstd2 + r0, pp + a.p0.n2w, tid, rb);
+        seq_ln_bwd_pre<CW>(lb1p, d, wp + a.w0.xhat1 + r0 * d, wp + a.w0.rstd1 + r0, pp + a.p0.n1w, tid, rb);
+        have_lbp = true;
+      }
+    }
+  };
   SeqPRow prow = SeqPRow();                                  // head_dim-2 attention: this thread's P row, requested at the start of the phase
   SeqPPre ppre = SeqPPre();                                  // MFMA attention: the wave's P values of the first round of heads, likewise
   bool have_ppre = false;
@@ -2037,6 +2171,9 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
     load_rows(sZ, SX, ws + a.dctx + ((a.phase - 1) & 1) * hand + r0 * d, d, 0, 32);                         // dctx of the whole sequence
     load_rows(sQ, SQ, ws + (int64_t)l * a.wstride + a.w0.qkv + r0 * 3 * d, 3 * d, 0, 32);                   // its saved q / k / v
     load_rows(sDZ, SX, ws + (int64_t)l * a.tstride + a.t0.dzB + r0 * d, d, rb, NROW);                        // dz1 of layer l, own rows
+#if GT_SEQ_PFB_LN
+    chain_prefetch(l);
+#endif
     GT_BARRIER();
     GT_STAMP(400 + 4 * a.phase);
     attn_inproj(l);
