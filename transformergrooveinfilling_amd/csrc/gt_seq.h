@@ -71,6 +71,10 @@ __shared__ long long* gt_sub_ptr;      // sub-stage stamps of ONE matmul stage (
 #ifndef GT_SEQ_PFB_LN
 #define GT_SEQ_PFB_LN 1    /* ... and the backward chain's LayerNorm operands at the phase's start (A/B switch) */
 #endif
+#ifndef GT_SEQ_PFLN128
+#define GT_SEQ_PFLN128 0   /* d_model 128, SPLIT / QUAD kernels: the LayerNorm passes' small operands (bias / gamma / beta; backward: x-hat / rstd / gamma) requested ahead, as at
+                              d_model 32 -- measured 0.3-0.5 % SLOWER on the headline (0.1991 vs 0.1982 ms, three interleaved bench pairs, profiles/r06_ab_pfln128.txt): off */
+#endif
 #ifndef GT_SEQ_PF32
 #define GT_SEQ_PF32 1      /* d_model 32, SPLIT kernels: every stage's global operands requested a stage ahead (round 6); 0: as before */
 #endif
@@ -1368,6 +1372,7 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
   // once at its head instead of once per stage; the fragments are 8 ... 48 registers here (64 per stage at d_model 128, where the same was
   // measured slower in round 3).  Round 6.
   constexpr bool PF32 = SPLIT && !QUAD && EXACT && DP == 32 && GT_SEQ_PF32;
+  constexpr bool PFLN = PF32 || (SPLIT && EXACT && DP == 128 && GT_SEQ_PFLN128);     // the LayerNorm parameters alone: at d_model 128 too (24 registers per norm)
   SeqB<NK> ipre = SeqB<NK>();                                 // the next layer's in-proj fragment + bias chunk (requested in layer_rest)
   float4 ipre_b = make_float4(0.f, 0.f, 0.f, 0.f);
   bool have_ipre = false;
@@ -1477,7 +1482,7 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
     // here (saved for the backward) -- line-shaped, see seq_tile_out.
     if (save_qkv && sv0) seq_tile_out(wl + a.w0.qkv + r0 * 3 * d, sQ, SQ, 3 * d, tid, rb, NROW);
     SeqLnPre<CW> ln1p, ln2p;                                  // (PF32) the two norms' gamma / beta and the bias in front of them
-    if constexpr (PF32) seq_ln_pre<CW>(ln1p, pl + a.p0.out_b, pl + a.p0.n1w, pl + a.p0.n1b, tid);
+    if constexpr (PFLN) seq_ln_pre<CW>(ln1p, pl + a.p0.out_b, pl + a.p0.n1w, pl + a.p0.n1b, tid);
 #ifndef GT_SEQ_NO_PRE2
     const bool preo = SPLIT && EXACT && (DP > 64 || PF32);    // the out-proj's fragment: in flight under the attention (which loads nothing)
     SeqB<NK> bopre = SeqB<NK>();
@@ -1535,21 +1540,21 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
       seq_ln_fwd<DP, HALF>([&](int row, int c0, float (&z)[CW]) {
         float bi[CW], xr[CW];
         SeqVec<CW>::ld(z, &sR[row * SRS + c0]); SeqVec<CW>::ld(xr, &sX[row * SX + c0]);
-        if constexpr (PF32) {
+        if constexpr (PFLN) {
 #pragma unroll
           for (int e = 0; e < CW; ++e) bi[e] = ln1p.bi[e];
         } else SeqVec<CW>::ld(bi, bo + c0);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
       }, sX1, SX, d, pl + a.p0.n1w, pl + a.p0.n1b, ((sv1 || fzl) && !(GT_SEQ_ACCT & 1)) ? wl + a.w0.x1 + r0 * d : nullptr, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, tid, rb,
-         PF32 ? &ln1p : nullptr);
+         PFLN ? &ln1p : nullptr);
     }
     GT_BARRIER();
     GT_STAMP(sb + 4);
     // ---- FFN1: hact = drop(relu(x1 W1^T + b1))     (QUAD: this partner's half of the columns, fc0 .. fc0 + F / 2)
     const int fc0 = QUAD ? cpart * (F >> 1) : 0, fcn = QUAD ? F >> 1 : F;
-    if constexpr (PF32) {                                        // norm2's parameters and the NEXT layer's in-proj fragment: in flight under FFN1 and FFN2
-      seq_ln_pre<CW>(ln2p, pl + a.p0.b2, pl + a.p0.n2w, pl + a.p0.n2b, tid);
+    if constexpr (PFLN) seq_ln_pre<CW>(ln2p, pl + a.p0.b2, pl + a.p0.n2w, pl + a.p0.n2b, tid);     // norm2's parameters ...
+    if constexpr (PF32) {                                        // ... and the NEXT layer's in-proj fragment: in flight under FFN1 and FFN2
       if (l + 1 < a.L) {
         const float* kfn = ws + a.pack_f + (int64_t)(l + 1) * a.kstride;
         const int tcl = wave < (3 * d >> 4) ? wave : 0;
@@ -1634,14 +1639,14 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
           seq_parts_sum<CW>(z, sR, SRS, parts, row, c0);
         }
         SeqVec<CW>::ld(xr, &sX1[row * SX + c0]);
-        if constexpr (PF32) {
+        if constexpr (PFLN) {
 #pragma unroll
           for (int e = 0; e < CW; ++e) bi[e] = ln2p.bi[e];
         } else SeqVec<CW>::ld(bi, b2 + c0);
 #pragma unroll
         for (int e = 0; e < CW; ++e) z[e] = (z[e] + bi[e]) * seq_dmul(dk, key, idxd + (uint32_t)(row * d + c0 + e)) + xr[e];
       }, sX, SX, d, pl + a.p0.n2w, pl + a.p0.n2b, (sv0 || fzl) ? wl + a.w0.xout + r0 * d : nullptr, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, tid, rb,
-         PF32 ? &ln2p : nullptr);
+         PFLN ? &ln2p : nullptr);
     }
     GT_BARRIER();
     GT_STAMP(sb + 7);
@@ -1891,6 +1896,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
   };
   // d_model 32, SPLIT (round 6, as in the forward): the chain's saved LayerNorm operands are requested at the phase's start
   constexpr bool PFB = SPLIT && !QUAD && EXACT && DP == 32 && GT_SEQ_PF32;
+  constexpr bool PFBLN = PFB || (SPLIT && !QUAD && EXACT && DP == 128 && GT_SEQ_PFLN128);    // the LayerNorm operands alone: at d_model 128 too (17 registers per norm)
   SeqLnBwdPre<CW> lb2p, lb1p;
   bool have_lbp = false;                                     // (set by chain_prefetch, at the start of a phase > 0)
   constexpr int F2T = GT_SEQ_FMAX / (QUAD ? 256 : 128);      // FFN2 dgrad tiles per wave
@@ -1936,7 +1942,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
           for (int e = 0; e < CW; ++e) g[e] += r[e];
         }
       }, sDZ, sC, SX, d, wl + a.w0.xhat2 + r0 * d, wl + a.w0.rstd2 + r0, pl + a.p0.n2w, dk, key, idxd, sv0 ? tl + a.t0.dzA + r0 * d : nullptr,
-                           (dk.thr && sv0) ? tl + a.t0.dzAm + r0 * d : nullptr, sP, tid, rb, (PFB && have_lbp) ? &lb2p : nullptr);
+                           (dk.thr && sv0) ? tl + a.t0.dzAm + r0 * d : nullptr, sP, tid, rb, (PFBLN && have_lbp) ? &lb2p : nullptr);
     }
     if (SPLIT) {
       auto hst = [&](const int u, const float4& v) { const int e = tid + u * GT_SEQ_NT; if (e < hn) *reinterpret_cast<float4*>(sH + (rb + e / hq4) * SH + fc0 + (e % hq4) * 4) = v; };
@@ -2015,7 +2021,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
 #pragma unroll
         for (int e = 0; e < CW; ++e) g[e] += r[e];
       }, sDZ, sC, SX, d, wl + a.w0.xhat1 + r0 * d, wl + a.w0.rstd1 + r0, pl + a.p0.n1w, dk, key, idxd, sv0 ? tl + a.t0.dzB + r0 * d : nullptr,
-                           (dk.thr && sv0) ? tl + a.t0.dzBm + r0 * d : nullptr, sP, tid, rb, (PFB && have_lbp) ? &lb1p : nullptr);
+                           (dk.thr && sv0) ? tl + a.t0.dzBm + r0 * d : nullptr, sP, tid, rb, (PFBLN && have_lbp) ? &lb1p : nullptr);
     }
     GT_BARRIER();
     GT_STAMP(sb + 3);
@@ -2045,7 +2051,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
   // branchy at K = 96: the compiler's vmcnt(0) covers everything in flight, + 2.4 k cycles); between the two passes of the attention backward the
   // second pass takes 2.8 k longer; the big ones at the phase's start sit under the attention's state and P loads (+ 1.3 k).  They stay at the chain's head.
   auto chain_prefetch = [&](const int l) {
-    if constexpr (PFB) {
+    if constexpr (PFBLN) {
       if (l > 0) {
         const float* wp = ws + (int64_t)(l - 1) * a.wstride;
         const float* pp = prm + (int64_t)(l - 1) * a.pstride;
