@@ -30,6 +30,8 @@ SHAPES = [
     ("C5 precision 2, S=27, bs512 on one GPU", dict(d_model=512, n_heads=8, dim_feedforward=512, num_encoder_layers=6, num_decoder_layers=0, dropout=0.3, embedding_size_src=27, precision="autocast"), 512),
     ("RandomLow_lm yaml d256/H2/F2048/L8 bs32", dict(d_model=256, n_heads=2, dim_feedforward=2048, num_encoder_layers=8, num_decoder_layers=0, dropout=0.16), 32),
     ("Random_test_large yaml d256/H16/F64/L11 bs16", dict(d_model=256, n_heads=16, dim_feedforward=64, num_encoder_layers=11, num_decoder_layers=0, dropout=0.15), 16),
+    # the reference CLI's own defaults (ref:train.py:43-62 = configs/hyperparameter_defaults.yaml: what `train.py --experiment X` runs without a --config)
+    ("CLI defaults d64/H16/F256/L7 bs16", dict(d_model=64, n_heads=16, dim_feedforward=256, num_encoder_layers=7, num_decoder_layers=0, dropout=0.2), 16),
 ]
 
 
