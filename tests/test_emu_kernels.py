@@ -313,9 +313,12 @@ def test_sequence_resident_kernels(cfg, B, p):
                                      # (row, head): the ClosedHH YAML shape above and its F 256 sibling; d_model 128 with 64 heads of 2
                                      # (32 x 64 pairs > 512 threads) falls back to the zero-padded MFMA form -- there also through QUAD
                                      (cfg_dict(32, 16, 256, 1), 3, 0.1), (cfg_dict(128, 64, 32, 1), 1, 0.1),
-                                     (cfg_dict(32, 16, 64, 1), 1, 0.0)])     # head_dim 2 without dropout: the saved keep bits are read and overruled
+                                     (cfg_dict(32, 16, 64, 1), 1, 0.0),      # head_dim 2 without dropout: the saved keep bits are read and overruled
+                                     # round 6: d_model 64 with 16 heads of 4 (the reference CLI's default shape) on the same schedule and the same
+                                     # vector-ALU attention (seq_attn_*_small<4>), with the stage-ahead operand requests of the d_model-32 kernels
+                                     (cfg_dict(64, 16, 256, 2), 2, 0.2), (cfg_dict(64, 16, 512, 1), 1, 0.0)])
 def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
-    """d_model 128 / 32, SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels.
+    """d_model 128 / 32 (/ 64 with 16 heads), SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels.
     At d_model 128 "split" also means: weight gradients as rider workgroups of the backward phases + the tail launch (gt_seq_wg.h)"""
     parity.check_step("emu", cfg, B, p, seq="split")
     parity.check_step("emu", cfg, B, p, seq="whole")
@@ -332,6 +335,7 @@ def test_sequence_resident_train_step_and_predict():
     parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.2)
     parity.check_train_step("emu", cfg_dict(128, 4, 32, 2), 2, 0.2, seq="split")      # loss fused into the last forward phase, 4 workgroups
     parity.check_train_step("emu", cfg_dict(128, 8, 48, 1), 3, 0.1, seq="whole")
+    parity.check_train_step("emu", cfg_dict(64, 16, 256, 2), 2, 0.2)                       # the reference CLI's default shape: SPLIT by shape (round 6)
     parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.0, algo=1)               # the fused update + pack kernel, Adam branch
     parity.check_bucketed_backward("emu", cfg_dict(32, 4, 16, 2), 2, 0.25, 1, exact=True)      # one bucket: the backward is one launch
     # riders: after backward phase p everything from layer L - p + 1 on is final -> two buckets, bit-exact (one owner per gradient tile)

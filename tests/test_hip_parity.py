@@ -21,13 +21,15 @@ C4 = cfg_dict(512, 8, 512, 2)                     # d_model 512 / 8 heads (layer
 SYM = cfg_dict(64, 16, 64, 2, embedding_size_src=27)
 YAML_LM = cfg_dict(256, 2, 2048, 2)               # InfillingRandomLow_lm_training.yaml (dim_feedforward 2048, L 8: layers reduced for oracle time)
 YAML_LARGE = cfg_dict(256, 16, 64, 3)             # InfillingRandom_test_large.yaml (16 heads of 16, dim_feedforward 64, L 11: layers reduced)
+CLI_DEFAULT = cfg_dict(64, 16, 256, 7)            # ref:train.py:43-62 / hyperparameter_defaults.yaml: what train.py runs without a --config (16 heads of 4)
 
 
 @pytest.mark.parametrize("cfg,B,p", [(ENC, 2, 0.0), (ENC, 5, 0.25), (ENCDEC, 3, 0.0), (ENCDEC, 2, 0.25), (C1, 32, 0.18),
                                      (YAML_HH, 16, 0.24), (SYM, 3, 0.1), (cfg_dict(16, 16, 16, 1), 1, 0.0),
                                      (C2, 8, 0.0), (C2, 64, 0.24), (YAML_KS, 4, 0.3), (C3, 4, 0.0), (C3, 3, 0.3),
                                      (C4, 4, 0.0), (C4, 3, 0.15), (cfg_dict(64, 4, 2048, 1), 2, 0.16),
-                                     (YAML_LM, 32, 0.16), (YAML_LARGE, 16, 0.15)])      # the two YAMLs at their own batch sizes
+                                     (YAML_LM, 32, 0.16), (YAML_LARGE, 16, 0.15),       # the two YAMLs at their own batch sizes
+                                     (CLI_DEFAULT, 16, 0.2), (cfg_dict(64, 16, 512, 2), 64, 0.1)])   # d_model 64 / 16 heads on the SPLIT schedule (round 6)
 def test_step_parity(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 
@@ -71,7 +73,7 @@ def test_optimizers():
     parity.check_optimizers("hip", C2, 2)
 
 
-@pytest.mark.parametrize("cfg,B,p", [(ENC, 4, 0.2), (ENCDEC, 2, 0.1), (C2, 16, 0.24)])
+@pytest.mark.parametrize("cfg,B,p", [(ENC, 4, 0.2), (ENCDEC, 2, 0.1), (C2, 16, 0.24), (cfg_dict(64, 16, 256, 2), 16, 0.2)])
 def test_train_step(cfg, B, p):
     parity.check_train_step("hip", cfg, B, p)
 

@@ -41,7 +41,7 @@ GT_DP_GRAPH=1 GT_DP_OVERLAP=1 python bench.py --no-cpu-baseline --force-dp | tai
 for i in 0 1; do GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py $i > $O/seq_stamps_$i.txt 2>&1; done     # (the shipped path of these shapes: SPLIT)
 GT_SEQ_SPLIT=1 GT_LIB_PATH=$L/libgroove_stamps.so python tools/seq_stamps.py 2 > $O/seq_stamps_c2.txt 2>&1
 python tools/wg_unit_bench.py 64 > $O/wg_unit_bench.txt 2>&1
-for i in 0 1 4 5 6 7 9 11 12 13 14 15; do python tools/class_profile.py $i > $O/class_profile_$i.txt 2>&1; done
+for i in 0 1 4 5 6 7 9 11 12 13 14 15 16; do python tools/class_profile.py $i > $O/class_profile_$i.txt 2>&1; done
 ./tools/ubench/gemm_bench > $O/gemm_bench.txt 2>&1
 for s in "2048 512 512" "2048 1536 512" "2048 512 1536" "8192 256 256" "8192 768 256"; do echo "== $s" >> $O/gemm_bench_mid.txt; ./tools/ubench/gemm_bench $s 2>&1 | grep -E "gemm64|gemm32.h|^NN|32x32   <|64x64   <2,2,2,2,BK32" >> $O/gemm_bench_mid.txt; done
 python tools/predict_bench.py > $O/predict.txt 2>&1

@@ -323,7 +323,7 @@ static WLayout ws_layout(const gt_config& c) {
     W.pack_f = add(W.pack_stride * c.n_enc_layers); W.pack_b = add(W.pack_stride * c.n_enc_layers);
     W.seq_dctx = add(2 * M * d);
     if (d == 128) { W.seq_xchg_n = 2 * gt_seq_xchg_floats(c.batch); W.seq_xchg = add(W.seq_xchg_n); }    // (two regions: the forward's, and backward phase 0's when fused behind it)
-    if (d == 32 && c.n_heads == 16) { W.seq_amask_stride = BH * 32; W.seq_amask = add(W.seq_amask_stride * c.n_enc_layers); }   // (behind everything else: no other offset moves)
+    if ((d == 32 || d == 64) && c.n_heads == 16) { W.seq_amask_stride = BH * 32; W.seq_amask = add(W.seq_amask_stride * c.n_enc_layers); }   // (behind everything else: no other offset moves)
   }
   if (!seq_supported(c) && (d == 256 || d == 512) && M % 64 == 0) { W.rowx_n = gt_rowx_floats(M, (int)d); W.rowx = add(W.rowx_n); }
   if (bf16_shadows(c)) {
@@ -1148,7 +1148,9 @@ static int xchg_cus() {
   return masked ? 0 : seq_cu_count();
 }
 static bool seq_split(const gt_config& c) {
-  if (c.d_model != 128 && c.d_model != 32) return false;
+  // d_model 64 (round 6): the reference CLI's default shape alone -- 16 heads of 4, on the vector-ALU attention of the head_dim-2 YAMLs
+  if (c.d_model == 64 && !(c.n_heads == 16 && c.dim_ff >= 256)) return false;
+  if (c.d_model != 128 && c.d_model != 32 && c.d_model != 64) return false;
   if (g_seq_split < 0) { const char* e = getenv("GT_SEQ_SPLIT"); if (e) g_seq_split = e[0] != '0'; }
   if (g_seq_split >= 0) return g_seq_split != 0;
   // d_model 32: only where a sequence's FFN is MFMA-issue-bound on its one CU (ClosedHH YAML, F 512, bs 16: 0.313 -> 0.290 ms); the

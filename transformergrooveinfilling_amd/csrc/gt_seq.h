@@ -75,6 +75,9 @@ __shared__ long long* gt_sub_ptr;      // sub-stage stamps of ONE matmul stage (
 #define GT_SEQ_PFLN128 0   /* d_model 128, SPLIT / QUAD kernels: the LayerNorm passes' small operands (bias / gamma / beta; backward: x-hat / rstd / gamma) requested ahead, as at
                               d_model 32 -- measured 0.3-0.5 % SLOWER on the headline (0.1991 vs 0.1982 ms, three interleaved bench pairs, profiles/r06_ab_pfln128.txt): off */
 #endif
+#ifndef GT_SEQ_PF64
+#define GT_SEQ_PF64 1      /* ... and of d_model 64 (the reference CLI's default shape: 16 heads of 4) */
+#endif
 #ifndef GT_SEQ_PF32
 #define GT_SEQ_PF32 1      /* d_model 32, SPLIT kernels: every stage's global operands requested a stage ahead (round 6); 0: as before */
 #endif
@@ -1371,7 +1374,7 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
   // operands -- weight fragments, bias / gamma / beta -- are requested one stage AHEAD, so that a phase pays the L2 round trip (1.8-2 k cycles)
   // once at its head instead of once per stage; the fragments are 8 ... 48 registers here (64 per stage at d_model 128, where the same was
   // measured slower in round 3).  Round 6.
-  constexpr bool PF32 = SPLIT && !QUAD && EXACT && DP == 32 && GT_SEQ_PF32;
+  constexpr bool PF32 = SPLIT && !QUAD && EXACT && (DP == 32 || (DP == 64 && GT_SEQ_PF64)) && GT_SEQ_PF32;
   constexpr bool PFLN = PF32 || (SPLIT && EXACT && DP == 128 && GT_SEQ_PFLN128);     // the LayerNorm parameters alone: at d_model 128 too (24 registers per norm)
   SeqB<NK> ipre = SeqB<NK>();                                 // the next layer's in-proj fragment + bias chunk (requested in layer_rest)
   float4 ipre_b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1492,13 +1495,13 @@ __device__ __forceinline__ bool seq_fwd_body(const SeqArgs& a, float* const lds)
     const SeqB<NK> bopre = SeqB<NK>();
 #endif
     bool vattn = false;
-    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
-      vattn = a.hd == 2 && a.H == 16;                         // (d_model 32; the backward's P staging is written for 16 heads)
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && (DP == 32 || DP == 64)) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
+      vattn = a.hd == DP / 16 && a.H == 16;                   // (16 heads of 2 at d_model 32, of 4 at d_model 64: the backward's P staging is written for 16 heads)
       if (vattn) {
         const uint32_t key = seq_key(dk, site0 + GT_SITE_ATTN);
         float* Pseq = wl + a.w0.P + (size_t)(b * a.H) * 1024;
         const uint32_t pseq = (uint32_t)(b * a.H * 1024);
-        seq_attn_fwd_small<2>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sC, SX, dk, key, reinterpret_cast<uint32_t*>(ws + a.amask + (int64_t)l * a.amask_stride) + b * a.H * 32, rb, NROW, tid);
+        seq_attn_fwd_small<DP / 16>(sQ, SQ, d, a.H, ascale, Pseq, pseq, sC, SX, dk, key, reinterpret_cast<uint32_t*>(ws + a.amask + (int64_t)l * a.amask_stride) + b * a.H * 32, rb, NROW, tid);
       }
     }
     if (!vattn) {
@@ -1895,7 +1898,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
     GT_STAMP(101);
   };
   // d_model 32, SPLIT (round 6, as in the forward): the chain's saved LayerNorm operands are requested at the phase's start
-  constexpr bool PFB = SPLIT && !QUAD && EXACT && DP == 32 && GT_SEQ_PF32;
+  constexpr bool PFB = SPLIT && !QUAD && EXACT && (DP == 32 || (DP == 64 && GT_SEQ_PF64)) && GT_SEQ_PF32;
   constexpr bool PFBLN = PFB || (SPLIT && !QUAD && EXACT && DP == 128 && GT_SEQ_PFLN128);    // the LayerNorm operands alone: at d_model 128 too (17 registers per norm)
   SeqLnBwdPre<CW> lb2p, lb1p;
   bool have_lbp = false;                                     // (set by chain_prefetch, at the start of a phase > 0)
@@ -2076,18 +2079,18 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
 #endif
     SeqB<8> bqpre = SeqB<8>();
     bool vattn = false;
-    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
-      vattn = a.hd == 2 && a.H == 16;
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && (DP == 32 || DP == 64)) {        // (SPLIT kernels only: in the whole-sequence kernels the extra live range spills)
+      vattn = a.hd == DP / 16 && a.H == 16;
       if (vattn) {                                              // (sR is free here: H x 32 row sums)
         static_assert(G::FFN >= 16 * 1024 && G::RES >= 2 * 16 * 32 && !ALIAS, "head_dim-2 attention backward: P image in the FFN tile, row sums + keep bits in sR");
-        SeqAttnSmallG<2> G;
-        seq_attn_bwd_small_a<2>(G, sQ, SQ, d, a.H, ascale, prow, sH, sZ, SX, dk, sR, tid);
+        SeqAttnSmallG<DP / 16> G;
+        seq_attn_bwd_small_a<DP / 16>(G, sQ, SQ, d, a.H, ascale, prow, sH, sZ, SX, dk, sR, tid);
         GT_BARRIER();
         GT_STAMP(400 + 4 * a.phase + 1);
-        seq_attn_bwd_small_b<2>(G, sQ, SQ, d, a.H, ascale, sH, sZ, SX, dk, sR, rb, NROW, tid);
+        seq_attn_bwd_small_b<DP / 16>(G, sQ, SQ, d, a.H, ascale, sH, sZ, SX, dk, sR, rb, NROW, tid);
         GT_BARRIER();
         GT_STAMP(400 + 4 * a.phase + 2);
-        seq_attn_bwd_small_store<2>(G, sQ, SQ, d, a.H, rb, NROW, tid);
+        seq_attn_bwd_small_store<DP / 16>(G, sQ, SQ, d, a.H, rb, NROW, tid);
 #ifndef GT_SEQ_NO_PRE4
         if (preq) bqpre = seq_splitk_first(kb, 3 * d, d, wave, lane);
 #endif
@@ -2164,13 +2167,13 @@ __device__ __forceinline__ void seq_bwd_body(const SeqArgs& a, float* const lds)
     GT_STAMP(160 + 2 * a.phase);
     const int64_t hand = (int64_t)a.B * 32 * d;                                                             // floats per hand-over buffer
     bool vpre = false;
-    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) vpre = a.hd == 2 && a.H == 16;
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && (DP == 32 || DP == 64)) vpre = a.hd == DP / 16 && a.H == 16;
     if (GT_SEQ_PPRE && !vpre && (wave >> 1) < a.H) {
       ppre = seq_attn_p_load(ws + (int64_t)l * a.wstride + a.w0.P + (size_t)(b * a.H + (wave >> 1)) * 1024, wave & 1, lane);
       have_ppre = true;
     }
-    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && DP == 32) {
-      if (a.hd == 2 && a.H == 16)
+    if constexpr (PAD && SPLIT && GT_SEQ_VATTN && (DP == 32 || DP == 64)) {
+      if (a.hd == DP / 16 && a.H == 16)
         prow = seq_attn_bwd_small_load(ws + (int64_t)l * a.wstride + a.w0.P + (size_t)(b * a.H) * 1024,
                                        reinterpret_cast<const uint32_t*>(ws + a.amask + (int64_t)l * a.amask_stride) + b * a.H * 32, tid);
     }
