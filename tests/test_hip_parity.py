@@ -29,7 +29,8 @@ CLI_DEFAULT = cfg_dict(64, 16, 256, 7)            # ref:train.py:43-62 / hyperpa
                                      (C2, 8, 0.0), (C2, 64, 0.24), (YAML_KS, 4, 0.3), (C3, 4, 0.0), (C3, 3, 0.3),
                                      (C4, 4, 0.0), (C4, 3, 0.15), (cfg_dict(64, 4, 2048, 1), 2, 0.16),
                                      (YAML_LM, 32, 0.16), (YAML_LARGE, 16, 0.15),       # the two YAMLs at their own batch sizes
-                                     (CLI_DEFAULT, 16, 0.2), (cfg_dict(64, 16, 512, 2), 64, 0.1)])   # d_model 64 / 16 heads on the SPLIT schedule (round 6)
+                                     (CLI_DEFAULT, 16, 0.2), (cfg_dict(64, 16, 512, 2), 64, 0.1),    # d_model 64 / 16 heads on the SPLIT schedule (round 6)
+                                     (cfg_dict(64, 8, 256, 3), 16, 0.2)])                            # ... and 8 heads of 8 (zero-padded MFMA attention)
 def test_step_parity(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 
