@@ -317,7 +317,8 @@ def test_sequence_resident_kernels(cfg, B, p):
                                      # round 6: d_model 64 with 16 heads of 4 (the reference CLI's default shape) on the same schedule and the same
                                      # vector-ALU attention (seq_attn_*_small<4>), with the stage-ahead operand requests of the d_model-32 kernels
                                      (cfg_dict(64, 16, 256, 2), 2, 0.2), (cfg_dict(64, 16, 512, 1), 1, 0.0),
-                                     (cfg_dict(64, 8, 256, 1), 2, 0.1)])     # ... 8 heads of 8: the same instantiation, zero-padded MFMA attention
+                                     (cfg_dict(64, 8, 256, 1), 2, 0.1),      # ... 8 heads of 8: the same instantiation, zero-padded MFMA attention
+                                     (cfg_dict(64, 4, 256, 1), 2, 0.2), (cfg_dict(64, 1, 512, 1), 1, 0.0)])   # ... head-dim classes 16 and 64
 def test_sequence_resident_kernels_two_workgroups_per_sequence(cfg, B, p):
     """d_model 128 / 32 (/ 64 with 16 heads), SPLIT mode: 16 token rows per workgroup, one launch per phase -- the same numbers as the whole-sequence kernels.
     At d_model 128 "split" also means: weight gradients as rider workgroups of the backward phases + the tail launch (gt_seq_wg.h)"""

@@ -30,7 +30,8 @@ CLI_DEFAULT = cfg_dict(64, 16, 256, 7)            # ref:train.py:43-62 / hyperpa
                                      (C4, 4, 0.0), (C4, 3, 0.15), (cfg_dict(64, 4, 2048, 1), 2, 0.16),
                                      (YAML_LM, 32, 0.16), (YAML_LARGE, 16, 0.15),       # the two YAMLs at their own batch sizes
                                      (CLI_DEFAULT, 16, 0.2), (cfg_dict(64, 16, 512, 2), 64, 0.1),    # d_model 64 / 16 heads on the SPLIT schedule (round 6)
-                                     (cfg_dict(64, 8, 256, 3), 16, 0.2)])                            # ... and 8 heads of 8 (zero-padded MFMA attention)
+                                     (cfg_dict(64, 8, 256, 3), 16, 0.2),                             # ... and 8 heads of 8 (zero-padded MFMA attention)
+                                     (cfg_dict(64, 4, 256, 3), 16, 0.2), (cfg_dict(64, 2, 512, 2), 32, 0.1)])   # ... head-dim classes 16 / 32
 def test_step_parity(cfg, B, p):
     parity.check_step("hip", cfg, B, p)
 

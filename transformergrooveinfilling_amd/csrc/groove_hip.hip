@@ -1148,9 +1148,9 @@ static int xchg_cus() {
   return masked ? 0 : seq_cu_count();
 }
 static bool seq_split(const gt_config& c) {
-  // d_model 64 (round 6): narrow heads (head-dim class 0: the one SPLIT instantiation at this width) and a wide FFN -- the reference CLI's default
-  // shape (16 heads of 4: on the vector-ALU attention of the head_dim-2 YAMLs) and its 8-head sibling (zero-padded MFMA attention)
-  if (c.d_model == 64 && !(c.d_model / c.n_heads < 16 && c.dim_ff >= 256)) return false;
+  // d_model 64 (round 6): with a wide FFN -- the reference CLI's default shape (16 heads of 4: on the vector-ALU attention of the head_dim-2 YAMLs)
+  // and its siblings of the sweep grids (8 heads of 8: zero-padded MFMA attention; 4 / 2 / 1 heads: head-dim classes 16 / 32 / 64)
+  if (c.d_model == 64 && c.dim_ff < 256) return false;
   if (c.d_model != 128 && c.d_model != 32 && c.d_model != 64) return false;
   if (g_seq_split < 0) { const char* e = getenv("GT_SEQ_SPLIT"); if (e) g_seq_split = e[0] != '0'; }
   if (g_seq_split >= 0) return g_seq_split != 0;

@@ -14,7 +14,12 @@
     if ((hc) == 0) gt_launch(K<32, 0, true, true>, grid, block, s, a);             \
     else if ((hc) == 16) gt_launch(K<32, 16, true, true>, grid, block, s, a);      \
     else gt_launch(K<32, 32, true, true>, grid, block, s, a);                      \
-  } else if ((dm) == 64) gt_launch(K<64, 0, true, true>, grid, block, s, a);       /* (narrow heads only: seq_split) */ \
+  } else if ((dm) == 64) {                                                         \
+    if ((hc) == 0) gt_launch(K<64, 0, true, true>, grid, block, s, a);             \
+    else if ((hc) == 16) gt_launch(K<64, 16, true, true>, grid, block, s, a);      \
+    else if ((hc) == 32) gt_launch(K<64, 32, true, true>, grid, block, s, a);      \
+    else gt_launch(K<64, 64, true, true>, grid, block, s, a);                      \
+  }                                                                                \
   else if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);         \
   else if ((hc) == 16) gt_launch(K<128, 16, true, true>, grid, block, s, a);       \
   else if ((hc) == 32) gt_launch(K<128, 32, true, true>, grid, block, s, a);       \
