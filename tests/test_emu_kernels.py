@@ -335,6 +335,8 @@ def test_rider_weight_gradients_edge_shapes(cfg, B, p):
 
 def test_sequence_resident_train_step_and_predict():
     parity.check_train_step("emu", cfg_dict(32, 4, 16, 2), 2, 0.2)
+    parity.check_train_step("emu", cfg_dict(32, 16, 16, 2), 2, 0.2)                        # 16 heads: SPLIT by shape at any F (round 6: the vector-ALU attention)
+    parity.check_step("emu", cfg_dict(64, 16, 64, 1), 2, 0.1)
     parity.check_train_step("emu", cfg_dict(128, 4, 32, 2), 2, 0.2, seq="split")      # loss fused into the last forward phase, 4 workgroups
     parity.check_train_step("emu", cfg_dict(128, 8, 48, 1), 3, 0.1, seq="whole")
     parity.check_train_step("emu", cfg_dict(64, 16, 256, 2), 2, 0.2)                       # the reference CLI's default shape: SPLIT by shape (round 6)

@@ -1148,15 +1148,16 @@ static int xchg_cus() {
   return masked ? 0 : seq_cu_count();
 }
 static bool seq_split(const gt_config& c) {
-  // d_model 64 (round 6): with a wide FFN -- the reference CLI's default shape (16 heads of 4: on the vector-ALU attention of the head_dim-2 YAMLs)
-  // and its siblings of the sweep grids (8 heads of 8: zero-padded MFMA attention; 4 / 2 / 1 heads: head-dim classes 16 / 32 / 64)
-  if (c.d_model == 64 && c.dim_ff < 256) return false;
   if (c.d_model != 128 && c.d_model != 32 && c.d_model != 64) return false;
   if (g_seq_split < 0) { const char* e = getenv("GT_SEQ_SPLIT"); if (e) g_seq_split = e[0] != '0'; }
   if (g_seq_split >= 0) return g_seq_split != 0;
-  // d_model 32: only where a sequence's FFN is MFMA-issue-bound on its one CU (ClosedHH YAML, F 512, bs 16: 0.313 -> 0.290 ms); the
-  // testing YAML (F 16) is a latency chain that more launches only lengthen (0.141 -> 0.160)
-  if (c.d_model == 32 && c.dim_ff < 256) return false;
+  // d_model 32 / 64 by shape.  With 16 heads (head_dim 2 / 4) ALWAYS: these kernels alone have the vector-ALU attention, which the zero-padded MFMA
+  // form of the whole-sequence kernels loses to at every F (round 6: d32 / H16 / F 64 0.222 -> 0.162 ms, F 128 0.232 -> 0.169; the ClosedHH YAML
+  // and the reference CLI's default shape -- d64 / H16 / F 256: 0.370 -> 0.260 -- are the wide end of the same family).  Otherwise only where a
+  // sequence's FFN is MFMA-issue-bound on its one CU, F >= 256 (round 2: ClosedHH 0.313 -> 0.290; round 6 at d_model 64: 4 heads 0.259 -> 0.232, 1 head
+  // at F 512 0.352 -> 0.285): a narrow FFN is a latency chain that more launches only lengthen (testing YAML, F 16: 0.141 -> 0.160; d32 / H4 / F 128:
+  // 0.147 -> 0.156)
+  if (c.d_model <= 64 && c.dim_ff < 256 && c.n_heads != 16) return false;
   return 2 * c.batch <= seq_cu_count();
 }
 // Riders (gt_seq_wg.h): the SPLIT backward phases of the d_model-128 kernels carry the weight gradients on the CUs the sequence
