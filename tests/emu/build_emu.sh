@@ -1,5 +1,5 @@
 #!/bin/bash
-# TEST INFRASTRUCTURE: build the host fiber-emulator flavour of the kernels (no GPU needed).  The same three translation
+# TEST INFRASTRUCTURE: build the host fiber-emulator flavour of the kernels (no GPU needed).  The same four translation
 # units as the HIP build, compiled as C++ in parallel; the emulator runtime (GT_EMU_IMPL) lives in the first one.
 set -e
 here="$(cd "$(dirname "$0")" && pwd)"
@@ -13,6 +13,7 @@ pids=()
 g++ $flags -DGT_EMU_IMPL -c "$src/groove_hip.hip" -o "$obj/groove_hip.o" "$@" & pids+=($!)
 g++ $flags -c "$src/groove_seq_fwd.hip" -o "$obj/groove_seq_fwd.o" "$@" & pids+=($!)
 g++ $flags -c "$src/groove_seq_bwd.hip" -o "$obj/groove_seq_bwd.o" "$@" & pids+=($!)
+g++ $flags -c "$src/groove_seq64.hip" -o "$obj/groove_seq64.o" "$@" & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-g++ -shared -fPIC "$obj"/groove_hip.o "$obj"/groove_seq_fwd.o "$obj"/groove_seq_bwd.o -o "$outlib"
+g++ -shared -fPIC "$obj"/groove_hip.o "$obj"/groove_seq_fwd.o "$obj"/groove_seq_bwd.o "$obj"/groove_seq64.o -o "$outlib"
 echo "built $outlib"

@@ -14,7 +14,7 @@ from transformergrooveinfilling_amd import _lib, layout  # noqa: E402
 
 EMU_SO = os.environ.get("GT_EMU_LIB_PATH") or os.path.join(ROOT, "tests", "emu", "libgroove_emu.so")   # override: tile-rule variants
 _SRC = [os.path.join(ROOT, "transformergrooveinfilling_amd", "csrc", f)
-        for f in ("groove_hip.hip", "groove_seq_fwd.hip", "groove_seq_bwd.hip", "gt_common.h", "gt_gemm.h", "gt_gemm32.h", "gt_gemm64.h", "gt_seq.h", "gt_seq_wg.h",
+        for f in ("groove_hip.hip", "groove_seq_fwd.hip", "groove_seq_bwd.hip", "groove_seq64.hip", "gt_common.h", "gt_gemm.h", "gt_gemm32.h", "gt_gemm64.h", "gt_seq.h", "gt_seq_wg.h",
                   "gt_seq_api.h", "gt_attn.h", "gt_misc.h")] + \
        [os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "include", "groove_hip.h")]
 

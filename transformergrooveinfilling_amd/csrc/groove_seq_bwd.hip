@@ -14,13 +14,7 @@
     if ((hc) == 0) gt_launch(K<32, 0, true, true>, grid, block, s, a);             \
     else if ((hc) == 16) gt_launch(K<32, 16, true, true>, grid, block, s, a);      \
     else gt_launch(K<32, 32, true, true>, grid, block, s, a);                      \
-  } else if ((dm) == 64) {                                                         \
-    if ((hc) == 0) gt_launch(K<64, 0, true, true>, grid, block, s, a);             \
-    else if ((hc) == 16) gt_launch(K<64, 16, true, true>, grid, block, s, a);      \
-    else if ((hc) == 32) gt_launch(K<64, 32, true, true>, grid, block, s, a);      \
-    else gt_launch(K<64, 64, true, true>, grid, block, s, a);                      \
-  }                                                                                \
-  else if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);         \
+  } else if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);       \
   else if ((hc) == 16) gt_launch(K<128, 16, true, true>, grid, block, s, a);       \
   else if ((hc) == 32) gt_launch(K<128, 32, true, true>, grid, block, s, a);       \
   else gt_launch(K<128, 64, true, true>, grid, block, s, a);
@@ -34,6 +28,7 @@ void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsign
   const dim3 grid(nblocks), block(GT_SEQ_NT);
   // QUAD: phase 0 with four workgroups per sequence (d_model 128; no attention in that phase, so one head-dim class serves all)
   if (quad) { gt_launch(seq_bwd_kernel<128, 32, true, true, true>, grid, block, s, a); return; }
+  if (split && d_model == 64) { gt_seq_launch_bwd64(a, hc, nblocks, s); return; }      // (a translation unit of its own: groove_seq64.hip)
   if (split) { GT_SEQ_LAUNCH_SPLIT(seq_bwd_kernel, d_model, hc, grid, block, s, a) }
   else { GT_SEQ_DISPATCH(seq_bwd_kernel, d_model, hc, grid, block, s, a) }
 }

@@ -14,13 +14,7 @@
     if ((hc) == 0) gt_launch(K<32, 0, true, true>, grid, block, s, a);             \
     else if ((hc) == 16) gt_launch(K<32, 16, true, true>, grid, block, s, a);      \
     else gt_launch(K<32, 32, true, true>, grid, block, s, a);                      \
-  } else if ((dm) == 64) {                                                         \
-    if ((hc) == 0) gt_launch(K<64, 0, true, true>, grid, block, s, a);             \
-    else if ((hc) == 16) gt_launch(K<64, 16, true, true>, grid, block, s, a);      \
-    else if ((hc) == 32) gt_launch(K<64, 32, true, true>, grid, block, s, a);      \
-    else gt_launch(K<64, 64, true, true>, grid, block, s, a);                      \
-  }                                                                                \
-  else if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);         \
+  } else if ((hc) == 0) gt_launch(K<128, 0, true, true>, grid, block, s, a);       \
   else if ((hc) == 16) gt_launch(K<128, 16, true, true>, grid, block, s, a);       \
   else if ((hc) == 32) gt_launch(K<128, 32, true, true>, grid, block, s, a);       \
   else gt_launch(K<128, 64, true, true>, grid, block, s, a);
@@ -40,6 +34,7 @@ void gt_seq_launch_fwd(const SeqArgs& a, int d_model, int hc, bool split, unsign
     else gt_launch(seq_fwd_kernel<128, 64, true, true, true>, grid, block, s, a);
     return;
   }
+  if (split && d_model == 64) { gt_seq_launch_fwd64(a, hc, nblocks, s); return; }      // (a translation unit of its own: groove_seq64.hip)
   if (split) { GT_SEQ_LAUNCH_SPLIT(seq_fwd_kernel, d_model, hc, grid, block, s, a) }
   else { GT_SEQ_DISPATCH(seq_fwd_kernel, d_model, hc, grid, block, s, a) }
 }

@@ -60,3 +60,6 @@ static inline int64_t gt_seq_xchg_floats(int batch) { return 16 + (int64_t)4 * b
 void gt_seq_launch_fb(const SeqArgs& a, unsigned nblocks, hipStream_t s);
 void gt_seq_launch_bwd(const SeqArgs& a, int d_model, int hc, bool split, unsigned nblocks, hipStream_t s, bool quad = false);
 void gt_seq_launch_tail(const SeqArgs& a, unsigned nblocks, hipStream_t s);
+// the SPLIT kernels of d_model 64 (groove_seq64.hip: a code object of their own); hc = head-dim class 0 / 16 / 32 / 64
+void gt_seq_launch_fwd64(const SeqArgs& a, int hc, unsigned nblocks, hipStream_t s);
+void gt_seq_launch_bwd64(const SeqArgs& a, int hc, unsigned nblocks, hipStream_t s);
