@@ -1,5 +1,5 @@
 # final measurements of a revision (run on the GPU box through gpurun): tools/gpu_final.sh TAG
-# (build first: csrc/build.sh, tools/build_variant.sh stamps groove_hip,groove_seq_fwd,groove_seq_bwd -DGT_SEQ_STAMPS, tools/ubench/gemm_bench)
+# (build first: csrc/build.sh, tools/build_variant.sh stamps groove_hip,groove_seq_fwd,groove_seq_bwd,groove_seq64 -DGT_SEQ_STAMPS, tools/ubench/gemm_bench)
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r06_final}
 O=gpurun_out/final_$TAG
